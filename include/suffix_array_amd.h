@@ -1,0 +1,107 @@
+/*
+ * suffix_array_amd.h -- C ABI of the MI355X-native suffix-array construction engine.
+ *
+ * Drop-in boundary for ONE path of hucsmn/suffix_array: `SuffixArray::new(&[u8])`
+ * -> `saca()` -> `cdivsufsort::sort_in_place`.  Citations are file:line in the reference
+ * crate (v0.5.0).  Plain pointers and sizes only; no C++ or torch types cross this ABI.
+ *
+ * Output contract (reference src/saca.rs:9-15, src/sa.rs:72-84): the n non-empty suffixes of
+ * T in ascending unsigned-lexicographic order (a proper prefix sorts first), as start offsets.
+ * All suffixes are distinct, so the array is unique: the result is bit-identical to the
+ * crate's divsufsort path on the same bytes.
+ *
+ * Every entry point is synchronous, thread-safe and re-entrant; the library keeps no pointer
+ * to caller memory after returning and never writes past the stated output length.  There is
+ * NO CPU fallback: without a usable HIP device the calls return SA_AMD_ENODEVICE.
+ */
+#ifndef SUFFIX_ARRAY_AMD_H
+#define SUFFIX_ARRAY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes; 0 / -1 / -2 keep the meaning of libdivsufsort's return value that the
+ * reference's dependency asserts on (call site reference src/saca.rs:14) */
+#define SA_AMD_OK          0
+#define SA_AMD_EINVAL     (-1)   /* null pointer with n > 0, n < 0, bad device ordinal */
+#define SA_AMD_ENOMEM     (-2)   /* host or device allocation failed */
+#define SA_AMD_EHIP       (-3)   /* HIP runtime error (launch, copy, sync) */
+#define SA_AMD_ENODEVICE  (-4)   /* no HIP device visible */
+#define SA_AMD_EINTERNAL  (-5)   /* refinement did not converge (cannot happen for valid input) */
+
+/* reference src/saca.rs:6  `pub const MAX_LENGTH: usize = std::i32::MAX as usize;` */
+#define SA_AMD_MAX_LENGTH 2147483647
+
+/* reference src/saca.rs:6 as a callable, for FFI users that cannot read macros */
+int32_t sa_amd_max_length(void);
+
+/*
+ * Replaces the C engine the reference binds: `int divsufsort(const unsigned char *T, int *SA,
+ * int n)` behind `cdivsufsort::sort_in_place(&[u8], &mut [i32])` (reference src/saca.rs:3,14).
+ * T: n bytes (host), any byte values.  SA: n entries (host), contents on entry arbitrary
+ * (reference src/sa.rs:31 re-uses an old buffer).  n == 0 is a successful no-op.
+ */
+int32_t sa_amd_divsufsort(const uint8_t *T, int32_t *SA, int32_t n);
+
+/*
+ * Replaces `pub fn saca(s: &[u8], sa: &mut [u32])` itself (reference src/saca.rs:9-15):
+ * SA has n + 1 entries, SA[0] = n (src/saca.rs:13), SA[1..=n] as above.  The two asserts of
+ * src/saca.rs:10-11 become the caller's job (lengths are implied by n).
+ */
+int32_t sa_amd_saca_u8(const uint8_t *T, uint32_t *SA, int32_t n);
+
+/*
+ * Batch of independent texts, text i built on HIP device `device[i]` (NULL: i mod device
+ * count), one host thread per device, no inter-device traffic.
+ * status[i] receives the per-text code; the return value is the first non-zero status or 0.
+ * Each SA[i] has n[i] + 1 entries (layout of sa_amd_saca_u8).
+ */
+int32_t sa_amd_saca_batch(const uint8_t *const *T, uint32_t *const *SA, const int32_t *n,
+                          const int32_t *device, int32_t count, int32_t *status);
+
+/* ---- device-resident entry points (text already in HBM; used by bench.py) ---- */
+
+typedef struct sa_amd_stats {
+    int32_t sigma;            /* distinct byte values in T */
+    int32_t bits_per_symbol;  /* packed code width */
+    int32_t symbols_per_key;  /* symbols in the initial 64-bit key */
+    int32_t rounds;           /* prefix-doubling refinement rounds after the initial sort */
+    int32_t sort_passes;      /* 8-bit radix passes executed in total */
+    int32_t reserved;
+    int64_t sorted_elements;  /* sum over sort passes of elements moved */
+    int64_t unresolved_after_initial; /* suffixes still in groups > 1 after the initial sort */
+} sa_amd_stats;
+
+/* bytes of device scratch sa_amd_saca_device needs for a text of n bytes */
+int64_t sa_amd_workspace_bytes(int32_t n);
+
+/*
+ * dT: n bytes in device memory; dSA: n + 1 uint32 in device memory (layout of sa_amd_saca_u8);
+ * dWork: sa_amd_workspace_bytes(n) bytes of device scratch, 256-byte aligned; stream: a
+ * hipStream_t (NULL = default stream) on the current device.  Blocks until the array is
+ * complete (the refinement loop reads a 4-byte counter back per round).  stats may be NULL.
+ */
+int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n, void *dWork,
+                           int64_t work_bytes, void *stream, sa_amd_stats *stats);
+
+/* number of visible HIP devices (0 when none; never initialises a context by itself) */
+int32_t sa_amd_device_count(void);
+
+const char *sa_amd_strerror(int32_t code);
+const char *sa_amd_version(void);
+
+/* ---- primitive test hooks: exercised by tests/ to localise a failing kernel ---- */
+
+/* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit); host buffers */
+int32_t sa_amd_test_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit,
+                               int32_t end_bit);
+/* initial packed keys of a text (host buffers; keys has n entries); returns bits in *bits, symbols in *k */
+int32_t sa_amd_test_build_keys(const uint8_t *T, int32_t n, uint64_t *keys, int32_t *bits, int32_t *k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUFFIX_ARRAY_AMD_H */

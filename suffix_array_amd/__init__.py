@@ -1,0 +1,220 @@
+"""suffix_array_amd -- host-side mirror of the reference's construction interface.
+
+The product is the C-ABI library ``libsuffix_array_amd.so`` (include/suffix_array_amd.h); this
+package is the thin Python binding used by tests and bench.py.  Names, argument meaning and
+error behaviour follow the reference crate for the one path that is in scope:
+
+    SuffixArray.new / set / len / is_empty / into_parts / from_parts / unchecked_from_parts
+        reference src/sa.rs:23-70, integrity check src/sa.rs:72-84
+    saca(s, sa), MAX_LENGTH
+        reference src/saca.rs:6-15
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+__all__ = ["MAX_LENGTH", "saca", "SuffixArray", "SuffixArrayError", "lib", "library_path", "Stats",
+           "saca_batch", "workspace_bytes", "saca_device_ptr"]
+
+#: reference src/saca.rs:6
+MAX_LENGTH = 2**31 - 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libsuffix_array_amd.so"
+_lib: Optional[ctypes.CDLL] = None
+
+
+class SuffixArrayError(RuntimeError):
+    """Engine failure (the reference panics on a non-zero return of its C engine)."""
+
+    def __init__(self, code: int, what: str):
+        super().__init__(f"suffix_array_amd: {what} (status {code})")
+        self.code = code
+
+
+class Stats(ctypes.Structure):
+    """sa_amd_stats of include/suffix_array_amd.h"""
+    _fields_ = [("sigma", ctypes.c_int32), ("bits_per_symbol", ctypes.c_int32),
+                ("symbols_per_key", ctypes.c_int32), ("rounds", ctypes.c_int32),
+                ("sort_passes", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("sorted_elements", ctypes.c_int64), ("unresolved_after_initial", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def lib() -> ctypes.CDLL:
+    """Load the C-ABI library (built in-tree by __graft_entry__.build()); fail loudly if absent."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)")
+        L = ctypes.CDLL(path)
+        c_u8p, c_vp = ctypes.c_void_p, ctypes.c_void_p
+        L.sa_amd_max_length.restype = ctypes.c_int32
+        L.sa_amd_divsufsort.argtypes = [c_u8p, c_vp, ctypes.c_int32]
+        L.sa_amd_divsufsort.restype = ctypes.c_int32
+        L.sa_amd_saca_u8.argtypes = [c_u8p, c_vp, ctypes.c_int32]
+        L.sa_amd_saca_u8.restype = ctypes.c_int32
+        L.sa_amd_saca_batch.argtypes = [c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]
+        L.sa_amd_saca_batch.restype = ctypes.c_int32
+        L.sa_amd_workspace_bytes.argtypes = [ctypes.c_int32]
+        L.sa_amd_workspace_bytes.restype = ctypes.c_int64
+        L.sa_amd_saca_device.argtypes = [c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int64, c_vp, c_vp]
+        L.sa_amd_saca_device.restype = ctypes.c_int32
+        L.sa_amd_device_count.restype = ctypes.c_int32
+        L.sa_amd_strerror.argtypes = [ctypes.c_int32]
+        L.sa_amd_strerror.restype = ctypes.c_char_p
+        L.sa_amd_version.restype = ctypes.c_char_p
+        L.sa_amd_test_sort_pairs.argtypes = [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+        L.sa_amd_test_sort_pairs.restype = ctypes.c_int32
+        L.sa_amd_test_build_keys.argtypes = [c_vp, ctypes.c_int32, c_vp, c_vp, c_vp]
+        L.sa_amd_test_build_keys.restype = ctypes.c_int32
+        _lib = L
+    return _lib
+
+
+def _check(code: int) -> None:
+    if code != 0:
+        raise SuffixArrayError(code, lib().sa_amd_strerror(code).decode())
+
+
+def _as_u8(s) -> np.ndarray:
+    if isinstance(s, np.ndarray):
+        if s.dtype != np.uint8 or not s.flags.c_contiguous:
+            raise TypeError("text must be a contiguous uint8 array")
+        return s
+    return np.frombuffer(bytes(s), dtype=np.uint8) if len(s) else np.zeros(0, dtype=np.uint8)
+
+
+def saca(s, sa: np.ndarray) -> None:
+    """``pub fn saca(s: &[u8], sa: &mut [u32])`` -- reference src/saca.rs:9-15.
+
+    ``sa`` is a caller-owned uint32 array of ``len(s) + 1`` entries whose prior contents are
+    irrelevant; on return ``sa[0] == len(s)`` and ``sa[1:]`` holds the sorted suffix offsets.
+    The reference's two ``assert!``s (src/saca.rs:10-11) are AssertionErrors here.
+    """
+    t = _as_u8(s)
+    assert t.size <= MAX_LENGTH                       # src/saca.rs:10
+    assert t.size + 1 == sa.size                      # src/saca.rs:11
+    if sa.dtype != np.uint32 or not sa.flags.c_contiguous or not sa.flags.writeable:
+        raise TypeError("sa must be a writable contiguous uint32 array")
+    _check(lib().sa_amd_saca_u8(t.ctypes.data, sa.ctypes.data, t.size))
+
+
+def divsufsort(s, sa: np.ndarray) -> None:
+    """The C engine's own signature (n int32 entries, no sentinel) -- call site reference src/saca.rs:14."""
+    t = _as_u8(s)
+    assert t.size == sa.size and sa.dtype == np.int32
+    _check(lib().sa_amd_divsufsort(t.ctypes.data, sa.ctypes.data, t.size))
+
+
+def saca_batch(texts, devices=None):
+    """Independent texts, one device each; returns the list of uint32 arrays."""
+    ts = [_as_u8(t) for t in texts]
+    outs = [np.empty(t.size + 1, dtype=np.uint32) for t in ts]
+    cnt = len(ts)
+    T = (ctypes.c_void_p * cnt)(*[t.ctypes.data for t in ts])
+    S = (ctypes.c_void_p * cnt)(*[o.ctypes.data for o in outs])
+    N = (ctypes.c_int32 * cnt)(*[t.size for t in ts])
+    D = (ctypes.c_int32 * cnt)(*devices) if devices is not None else None
+    st = (ctypes.c_int32 * cnt)()
+    rc = lib().sa_amd_saca_batch(T, S, N, D, cnt, st)
+    _check(rc)
+    return outs
+
+
+def workspace_bytes(n: int) -> int:
+    return int(lib().sa_amd_workspace_bytes(n))
+
+
+def saca_device_ptr(text_ptr: int, sa_ptr: int, n: int, work_ptr: int, work_bytes: int, stream: int = 0,
+                    stats: Optional[Stats] = None) -> None:
+    """Device-resident build (raw device pointers, e.g. torch ``tensor.data_ptr()``)."""
+    _check(lib().sa_amd_saca_device(text_ptr, sa_ptr, n, work_ptr, work_bytes, stream,
+                                    ctypes.byref(stats) if stats is not None else None))
+
+
+def _check_integrity(s: np.ndarray, sa: np.ndarray) -> bool:
+    """reference src/sa.rs:72-84, in its linear-time equivalent form:
+    a length check, then every adjacent pair must be strictly increasing as byte slices."""
+    n = s.size
+    if n + 1 != sa.size:                              # src/sa.rs:73-75
+        return False
+    if n == 0:
+        return int(sa[0]) == 0                        # sa[0] > n would panic in the reference
+    if sa.max() > n:
+        raise IndexError("suffix offset out of range (the reference panics here, src/sa.rs:77-78)")
+    if n <= 64:                                       # literal form for tiny inputs
+        b = s.tobytes()
+        return all(b[int(sa[i - 1]):] < b[int(sa[i]):] for i in range(1, n + 1))
+    if int(sa[0]) != n:
+        return False
+    rank = np.full(n + 1, -1, dtype=np.int64)
+    rank[sa] = np.arange(n + 1)
+    if (rank < 0).any():
+        return False
+    a, b = sa[1:-1].astype(np.int64), sa[2:].astype(np.int64)
+    ca, cb = s[a], s[b]
+    ok = (ca < cb) | ((ca == cb) & (rank[a + 1] < rank[b + 1]))
+    return bool(ok.all())
+
+
+class SuffixArray:
+    """Mirror of ``SuffixArray<'a>`` for the construction path (reference src/sa.rs:13-70)."""
+
+    def __init__(self, s):
+        """``SuffixArray::new`` -- reference src/sa.rs:23-27."""
+        self._s = _as_u8(s)
+        self._sa = np.zeros(self._s.size + 1, dtype=np.uint32)     # vec![0; s.len() + 1]
+        saca(self._s, self._sa)
+        self._bkt = None
+
+    @classmethod
+    def new(cls, s) -> "SuffixArray":
+        return cls(s)
+
+    def set(self, s) -> None:
+        """``SuffixArray::set`` -- reference src/sa.rs:30-33 (like the reference it re-runs
+        construction into the resized buffer and leaves the stored text and buckets alone)."""
+        t = _as_u8(s)
+        self._sa = np.resize(self._sa, t.size + 1)
+        saca(t, self._sa)
+
+    def len(self) -> int:                              # src/sa.rs:41-43
+        return int(self._s.size)
+
+    def is_empty(self) -> bool:                        # src/sa.rs:46-48
+        return self.len() == 0
+
+    def into_parts(self):                              # src/sa.rs:51-53
+        return self._s, self._sa
+
+    @classmethod
+    def from_parts(cls, s, sa) -> Optional["SuffixArray"]:
+        """reference src/sa.rs:57-64: compose and check integrity; None when the check fails."""
+        obj = cls.unchecked_from_parts(s, sa)
+        return obj if _check_integrity(obj._s, obj._sa) else None
+
+    @classmethod
+    def unchecked_from_parts(cls, s, sa) -> "SuffixArray":   # src/sa.rs:68-70
+        obj = cls.__new__(cls)
+        obj._s = _as_u8(s)
+        obj._sa = np.ascontiguousarray(sa, dtype=np.uint32)
+        obj._bkt = None
+        return obj
+
+    def __array__(self, dtype=None):                   # From<SuffixArray> for Vec<u32>, src/sa.rs:364-368
+        return self._sa if dtype is None else self._sa.astype(dtype)

@@ -1,0 +1,78 @@
+"""Seeded synthetic corpora (ctypes binding of csrc/textgen.c) for BASELINE.json's configs.
+
+C1/C2/C5 uniform bytes, C3 English-like Zipf word model, C4 DNA-like sigma=4 -- the offline
+analogues of the reference's benchmark data (reference benches/utils.rs:17-45, :206-210).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def _gen():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libsa_textgen.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} not found: run __graft_entry__.build()")
+        L = ctypes.CDLL(path)
+        L.sa_gen_uniform.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64]
+        L.sa_gen_sigma.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32]
+        L.sa_gen_dna.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64]
+        L.sa_gen_dna_repeats.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double]
+        L.sa_gen_english.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32]
+        L.sa_gen_english.restype = ctypes.c_int32
+        _lib = L
+    return _lib
+
+
+def uniform(n: int, seed: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    _gen().sa_gen_uniform(out.ctypes.data, n, seed)
+    return out
+
+
+def sigma(n: int, seed: int, sigma: int, base: int = 0) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    _gen().sa_gen_sigma(out.ctypes.data, n, seed, sigma, base)
+    return out
+
+
+def dna(n: int, seed: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    _gen().sa_gen_dna(out.ctypes.data, n, seed)
+    return out
+
+
+def dna_repeats(n: int, seed: int, fraction: float = 0.2) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    _gen().sa_gen_dna_repeats(out.ctypes.data, n, seed, fraction)
+    return out
+
+
+def english(n: int, seed: int, vocab: int = 50000) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    rc = _gen().sa_gen_english(out.ctypes.data, n, seed, vocab)
+    if rc:
+        raise MemoryError("sa_gen_english")
+    return out
+
+
+#: BASELINE.md section 2 workloads: name -> (generator, n, seed)
+WORKLOADS = {
+    "c1_uniform_1k": (uniform, 1 << 10, 1),
+    "c2_uniform_64m": (uniform, 64 << 20, 2),
+    "c3_english_256m": (english, 256 << 20, 3),
+    "c4_dna_1g": (dna, 1 << 30, 4),
+    "c5_uniform_512m": (uniform, 512 << 20, 50),
+}
+
+
+def workload(name: str, rank: int = 0, n_override: int | None = None) -> np.ndarray:
+    gen, n, seed = WORKLOADS[name]
+    return gen(n_override if n_override is not None else n, seed + rank)

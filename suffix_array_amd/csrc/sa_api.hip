@@ -1,0 +1,415 @@
+// sa_api.hip -- host pipeline and C ABI (include/suffix_array_amd.h) of the MI355X-native
+// suffix-array construction engine.  Replaces the body of `saca()` (reference
+// src/saca.rs:9-15) and the C engine behind `cdivsufsort::sort_in_place` (src/saca.rs:14).
+//
+// There is deliberately no CPU fallback in this file: every entry point runs the HIP
+// kernels of sa_kernels.hpp or returns an error code.
+#include "sa_kernels.hpp"
+#include "../../include/suffix_array_amd.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace sa {
+
+static bool debug_sync()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SA_AMD_DEBUG_SYNC"); v = (e && *e && *e != '0') ? 1 : 0; }
+    return v == 1;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            if (getenv("SA_AMD_VERBOSE"))                                                          \
+                fprintf(stderr, "suffix_array_amd: %s -> %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? SA_AMD_ENOMEM : SA_AMD_EHIP;                        \
+        }                                                                                          \
+    } while (0)
+
+#define LAUNCH_CHECK(st)                                                                           \
+    do {                                                                                           \
+        HIP_TRY(hipGetLastError());                                                                \
+        if (debug_sync()) HIP_TRY(hipStreamSynchronize(st));                                       \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int bit_length(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+constexpr int SORT_MAX_WG = 1024;   // 256 CUs x 4 resident workgroups (38 KB LDS each)
+
+struct SortGrid { int G; int64_t tiles_per_wg; };
+static SortGrid sort_grid(int64_t count)
+{
+    const int64_t tiles = ceil_div(count, SORT_TILE);
+    SortGrid g;
+    g.tiles_per_wg = ceil_div(tiles, SORT_MAX_WG);
+    if (g.tiles_per_wg < 1) g.tiles_per_wg = 1;
+    g.G = (int)ceil_div(tiles, g.tiles_per_wg);
+    if (g.G < 1) g.G = 1;
+    return g;
+}
+
+// device scratch layout for a text of n bytes
+struct Workspace {
+    uint64_t *keysA, *keysB;
+    uint32_t *valsA, *valsB, *isa, *U0, *U1, *G0, *G1;
+    uint32_t *spine, *tcnt, *thead, *hist, *total;
+    size_t bytes;
+};
+
+static Workspace carve(void *base, int64_t n)
+{
+    Workspace w;
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off = align_up(off + b, 256); return (char *)base + o; };
+    w.keysA = (uint64_t *)take(N * 8);
+    w.keysB = (uint64_t *)take(N * 8);
+    w.valsA = (uint32_t *)take(N * 4);
+    w.valsB = (uint32_t *)take(N * 4);
+    w.isa = (uint32_t *)take(N * 4);
+    w.U0 = (uint32_t *)take(N * 4);
+    w.U1 = (uint32_t *)take(N * 4);
+    w.G0 = (uint32_t *)take(N * 4);
+    w.G1 = (uint32_t *)take(N * 4);
+    w.spine = (uint32_t *)take((size_t)RADIX * SORT_MAX_WG * 4);
+    const size_t rr_tiles = (size_t)ceil_div((int64_t)N, RR_TILE);
+    w.tcnt = (uint32_t *)take(rr_tiles * 4);
+    w.thead = (uint32_t *)take(rr_tiles * 4);
+    w.hist = (uint32_t *)take(256 * 4);
+    w.total = (uint32_t *)take(256);
+    w.bytes = off;
+    return w;
+}
+
+struct SortResult { uint64_t *keys; uint32_t *vals; int passes; };
+
+// stable LSD sort of `count` pairs on key bits [begin_bit, end_bit); ping-pongs between in/alt
+static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, uint32_t *vals_alt, int64_t count,
+                      int begin_bit, int end_bit, uint32_t *spine, hipStream_t st, SortResult *res)
+{
+    res->keys = keys_in; res->vals = vals_in; res->passes = 0;
+    if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
+    const SortGrid g = sort_grid(count);
+    uint64_t *kin = keys_in, *kout = keys_alt;
+    uint32_t *vin = vals_in, *vout = vals_alt;
+    for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
+        const int nb = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
+        const uint32_t dmask = (1u << nb) - 1u;
+        hipLaunchKernelGGL(k_radix_upsweep, dim3(g.G), dim3(SORT_THREADS), 0, st, kin, spine, count, shift, dmask,
+                           g.tiles_per_wg, g.G);
+        LAUNCH_CHECK(st);
+        hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(SPINE_THREADS), 0, st, spine, (int64_t)RADIX * g.G,
+                           (uint32_t *)nullptr);
+        LAUNCH_CHECK(st);
+        hipLaunchKernelGGL(k_radix_downsweep, dim3(g.G), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, spine, count,
+                           shift, dmask, g.tiles_per_wg, g.G);
+        LAUNCH_CHECK(st);
+        uint64_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *tv = vin; vin = vout; vout = tv;
+        res->passes++;
+    }
+    res->keys = kin; res->vals = vin;
+    return SA_AMD_OK;
+}
+
+static void make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out)
+{
+    int sigma = 0;
+    for (int c = 0; c < 256; ++c) {
+        if (hist[c]) P->code[c] = (uint8_t)sigma++;
+        else P->code[c] = 0;
+    }
+    int bits = bit_length((uint64_t)(sigma > 1 ? sigma - 1 : 1));
+    if (bits < 1) bits = 1;
+    P->bits = bits;
+    P->k = 64 / bits;
+    const int used = P->k * bits;
+    P->mask = used >= 64 ? ~0ull : ((1ull << used) - 1ull);
+    *sigma_out = sigma;
+}
+
+static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWork, int64_t work_bytes, hipStream_t st,
+                        sa_amd_stats *stats)
+{
+    const int64_t n = n32;
+    sa_amd_stats local;
+    memset(&local, 0, sizeof(local));
+    if (n == 0) {
+        hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, 0u);
+        LAUNCH_CHECK(st);
+        HIP_TRY(hipStreamSynchronize(st));
+        if (stats) *stats = local;
+        return SA_AMD_OK;
+    }
+    Workspace w = carve(dWork, n);
+    if ((int64_t)w.bytes > work_bytes) return SA_AMD_EINVAL;
+    uint32_t *SA = dSA + 1;
+
+    // 1. sigma = 256 histogram -> symbol codes, bits per symbol, symbols per key
+    HIP_TRY(hipMemsetAsync(w.hist, 0, 256 * 4, st));
+    {
+        int64_t blocks = ceil_div(ceil_div(n, 16), BH_THREADS);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_byte_hist, dim3((unsigned)blocks), dim3(BH_THREADS), 0, st, dT, n, w.hist);
+        LAUNCH_CHECK(st);
+    }
+    uint32_t hist[256];
+    HIP_TRY(hipMemcpyAsync(hist, w.hist, sizeof(hist), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    KeyParams P;
+    int sigma;
+    make_key_params(hist, &P, &sigma);
+    local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
+
+    // 2. packed keys, 3. initial sort
+    hipLaunchKernelGGL(k_build_keys, dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P, w.keysA,
+                       w.valsA);
+    LAUNCH_CHECK(st);
+    SortResult sr;
+    int rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, P.k * P.bits, w.spine, st, &sr);
+    if (rc) return rc;
+    local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
+
+    // 4. ranks of the initial groups, SA write, compaction of the tied suffixes
+    uint32_t *Ucur = w.U0, *Unext = w.U1, *Gcur = w.G0, *Gnext = w.G1;
+    uint32_t *Vcur = (sr.vals == w.valsA) ? w.valsB : w.valsA;
+    int64_t tiles = ceil_div(n, RR_TILE);
+    hipLaunchKernelGGL(k_rr_count<true>, dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, (const uint32_t *)nullptr,
+                       n, w.tcnt, w.thead);
+    LAUNCH_CHECK(st);
+    hipLaunchKernelGGL(k_rr_scan, dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total);
+    LAUNCH_CHECK(st);
+    hipLaunchKernelGGL(k_rr_apply<true>, dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, sr.vals,
+                       (const uint32_t *)nullptr, n, w.tcnt, w.thead, SA, w.isa, Ucur, Gcur, Vcur);
+    LAUNCH_CHECK(st);
+    uint32_t m32 = 0;
+    HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int64_t m = m32;
+    local.unresolved_after_initial = m;
+
+    // 5. prefix doubling on the tied suffixes only
+    const int key2_bits = bit_length((uint64_t)(2 * n));
+    const int g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
+    int64_t h = P.k;
+    while (m > 0) {
+        if (local.rounds >= 40) return SA_AMD_EINTERNAL;
+        uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+        int64_t gblocks = ceil_div(m, GK_THREADS);
+        if (gblocks > 8192) gblocks = 8192;
+        hipLaunchKernelGGL(k_gather_key2, dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st, Vcur, Gcur, w.isa, m, n, h,
+                           key2_bits, w.keysA);
+        LAUNCH_CHECK(st);
+        rc = sort_pairs(w.keysA, Vcur, w.keysB, Valt, m, 0, key2_bits + g_bits, w.spine, st, &sr);
+        if (rc) return rc;
+        local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m;
+        uint32_t *Vnext = (sr.vals == w.valsA) ? w.valsB : w.valsA;
+        tiles = ceil_div(m, RR_TILE);
+        hipLaunchKernelGGL(k_rr_count<false>, dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, Ucur, m, w.tcnt,
+                           w.thead);
+        LAUNCH_CHECK(st);
+        hipLaunchKernelGGL(k_rr_scan, dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total);
+        LAUNCH_CHECK(st);
+        hipLaunchKernelGGL(k_rr_apply<false>, dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, sr.vals, Ucur, m,
+                           w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext);
+        LAUNCH_CHECK(st);
+        HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        m = m32;
+        uint32_t *t;
+        t = Ucur; Ucur = Unext; Unext = t;
+        t = Gcur; Gcur = Gnext; Gnext = t;
+        Vcur = Vnext;
+        h *= 2;
+        local.rounds++;
+    }
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);   // reference src/saca.rs:13
+    LAUNCH_CHECK(st);
+    HIP_TRY(hipStreamSynchronize(st));
+    if (stats) *stats = local;
+    return SA_AMD_OK;
+}
+
+static int pick_device()
+{
+    const char *e = getenv("SA_AMD_DEVICE");
+    return e ? atoi(e) : -1;   // -1: keep the calling thread's current device
+}
+
+// host buffers in, host buffers out; out_off = 1 writes SA[0] = n too (saca layout)
+static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_sentinel, int device)
+{
+    if (n < 0 || (n > 0 && (!T || !SA_host)) || (with_sentinel && !SA_host)) return SA_AMD_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SA_AMD_ENODEVICE;
+    if (device >= ndev) return SA_AMD_EINVAL;
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    if (n == 0) { if (with_sentinel) SA_host[0] = 0; return SA_AMD_OK; }
+    uint8_t *dT = nullptr; uint32_t *dSA = nullptr; void *dW = nullptr;
+    const int64_t wb = sa_amd_workspace_bytes(n);
+    int rc = SA_AMD_OK;
+    hipStream_t st = nullptr;
+    auto cleanup = [&]() { if (dT) (void)hipFree(dT); if (dSA) (void)hipFree(dSA); if (dW) (void)hipFree(dW); if (st) (void)hipStreamDestroy(st); };
+    auto hip_rc = [&](hipError_t e) { return e == hipSuccess ? SA_AMD_OK : (e == hipErrorOutOfMemory ? SA_AMD_ENOMEM : SA_AMD_EHIP); };
+    if ((rc = hip_rc(hipStreamCreate(&st)))) { cleanup(); return rc; }
+    if ((rc = hip_rc(hipMalloc((void **)&dT, (size_t)n)))) { cleanup(); return rc; }
+    if ((rc = hip_rc(hipMalloc((void **)&dSA, ((size_t)n + 1) * 4)))) { cleanup(); return rc; }
+    if ((rc = hip_rc(hipMalloc(&dW, (size_t)wb)))) { cleanup(); return rc; }
+    if ((rc = hip_rc(hipMemcpyAsync(dT, T, (size_t)n, hipMemcpyHostToDevice, st)))) { cleanup(); return rc; }
+    rc = build_device(dT, dSA, n, dW, wb, st, nullptr);
+    if (rc == SA_AMD_OK) {
+        if (with_sentinel) rc = hip_rc(hipMemcpyAsync(SA_host, dSA, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
+        else rc = hip_rc(hipMemcpyAsync(SA_host, dSA + 1, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        if (rc == SA_AMD_OK) rc = hip_rc(hipStreamSynchronize(st));
+    }
+    cleanup();
+    return rc;
+}
+
+}  // namespace sa
+
+extern "C" {
+
+#define SA_EXPORT __attribute__((visibility("default")))
+
+SA_EXPORT int32_t sa_amd_max_length(void) { return SA_AMD_MAX_LENGTH; }
+
+SA_EXPORT int32_t sa_amd_divsufsort(const uint8_t *T, int32_t *SA, int32_t n)
+{
+    return sa::build_host(T, (uint32_t *)SA, n, false, sa::pick_device());
+}
+
+SA_EXPORT int32_t sa_amd_saca_u8(const uint8_t *T, uint32_t *SA, int32_t n)
+{
+    return sa::build_host(T, SA, n, true, sa::pick_device());
+}
+
+SA_EXPORT int32_t sa_amd_saca_batch(const uint8_t *const *T, uint32_t *const *SA, const int32_t *n, const int32_t *device,
+                                    int32_t count, int32_t *status)
+{
+    if (count < 0 || (count > 0 && (!T || !SA || !n))) return SA_AMD_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SA_AMD_ENODEVICE;
+    std::vector<int32_t> st((size_t)count, SA_AMD_OK);
+    std::vector<std::vector<int>> per_dev((size_t)ndev);
+    for (int i = 0; i < count; ++i) {
+        const int d = device ? device[i] : i % ndev;
+        if (d < 0 || d >= ndev) { st[(size_t)i] = SA_AMD_EINVAL; continue; }
+        per_dev[(size_t)d].push_back(i);
+    }
+    std::vector<std::thread> workers;
+    for (int d = 0; d < ndev; ++d) {
+        if (per_dev[(size_t)d].empty()) continue;
+        workers.emplace_back([&, d]() {
+            for (int i : per_dev[(size_t)d]) st[(size_t)i] = sa::build_host(T[i], SA[i], n[i], true, d);
+        });
+    }
+    for (auto &t : workers) t.join();
+    int32_t first = SA_AMD_OK;
+    for (int i = 0; i < count; ++i) {
+        if (status) status[i] = st[(size_t)i];
+        if (first == SA_AMD_OK && st[(size_t)i] != SA_AMD_OK) first = st[(size_t)i];
+    }
+    return first;
+}
+
+SA_EXPORT int64_t sa_amd_workspace_bytes(int32_t n)
+{
+    if (n < 0) return -1;
+    return (int64_t)sa::carve(nullptr, n).bytes;
+}
+
+SA_EXPORT int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n, void *dWork, int64_t work_bytes,
+                                     void *stream, sa_amd_stats *stats)
+{
+    if (n < 0 || !dSA || (n > 0 && (!dT || !dWork))) return SA_AMD_EINVAL;
+    return sa::build_device(dT, dSA, n, dWork, work_bytes, (hipStream_t)stream, stats);
+}
+
+SA_EXPORT int32_t sa_amd_device_count(void)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
+    return ndev;
+}
+
+SA_EXPORT const char *sa_amd_strerror(int32_t code)
+{
+    switch (code) {
+    case SA_AMD_OK: return "ok";
+    case SA_AMD_EINVAL: return "invalid argument";
+    case SA_AMD_ENOMEM: return "out of memory";
+    case SA_AMD_EHIP: return "HIP runtime error";
+    case SA_AMD_ENODEVICE: return "no HIP device";
+    case SA_AMD_EINTERNAL: return "internal error: refinement did not converge";
+    default: return "unknown error";
+    }
+}
+
+SA_EXPORT const char *sa_amd_version(void) { return "suffix_array_amd 0.1.0 (gfx950)"; }
+
+SA_EXPORT int32_t sa_amd_test_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit, int32_t end_bit)
+{
+    using namespace sa;
+    if (count < 0 || (count > 0 && (!keys || !vals)) || begin_bit < 0 || end_bit > 64) return SA_AMD_EINVAL;
+    if (sa_amd_device_count() <= 0) return SA_AMD_ENODEVICE;
+    if (count == 0) return SA_AMD_OK;
+    uint64_t *dk = nullptr; uint32_t *dv = nullptr, *spine = nullptr;
+    const size_t N = (size_t)count;
+    HIP_TRY(hipMalloc((void **)&dk, N * 8 * 2));
+    HIP_TRY(hipMalloc((void **)&dv, N * 4 * 2));
+    HIP_TRY(hipMalloc((void **)&spine, (size_t)RADIX * SORT_MAX_WG * 4));
+    HIP_TRY(hipMemcpy(dk, keys, N * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv, vals, N * 4, hipMemcpyHostToDevice));
+    SortResult sr;
+    int rc = sort_pairs(dk, dv, dk + N, dv + N, count, begin_bit, end_bit, spine, nullptr, &sr);
+    if (rc == SA_AMD_OK) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(keys, sr.keys, N * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(vals, sr.vals, N * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dk); (void)hipFree(dv); (void)hipFree(spine);
+    return rc;
+}
+
+SA_EXPORT int32_t sa_amd_test_build_keys(const uint8_t *T, int32_t n, uint64_t *keys, int32_t *bits, int32_t *k)
+{
+    using namespace sa;
+    if (n <= 0 || !T || !keys) return SA_AMD_EINVAL;
+    if (sa_amd_device_count() <= 0) return SA_AMD_ENODEVICE;
+    uint8_t *dT = nullptr; uint64_t *dk = nullptr; uint32_t *dv = nullptr, *dh = nullptr;
+    HIP_TRY(hipMalloc((void **)&dT, (size_t)n));
+    HIP_TRY(hipMalloc((void **)&dk, (size_t)n * 8));
+    HIP_TRY(hipMalloc((void **)&dv, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&dh, 1024));
+    HIP_TRY(hipMemcpy(dT, T, (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dh, 0, 1024));
+    int64_t blocks = ceil_div(ceil_div((int64_t)n, 16), BH_THREADS);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_byte_hist, dim3((unsigned)blocks), dim3(BH_THREADS), 0, nullptr, dT, (int64_t)n, dh);
+    uint32_t hist[256];
+    HIP_TRY(hipMemcpy(hist, dh, 1024, hipMemcpyDeviceToHost));
+    KeyParams P; int sigma;
+    make_key_params(hist, &P, &sigma);
+    hipLaunchKernelGGL(k_build_keys, dim3((unsigned)ceil_div((int64_t)n, KB_TILE)), dim3(KB_THREADS), 0, nullptr, dT,
+                       (int64_t)n, P, dk, dv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(keys, dk, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (bits) *bits = P.bits;
+    if (k) *k = P.k;
+    (void)hipFree(dT); (void)hipFree(dk); (void)hipFree(dv); (void)hipFree(dh);
+    return SA_AMD_OK;
+}
+
+}  // extern "C"

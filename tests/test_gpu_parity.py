@@ -1,0 +1,166 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+bytes.  Bit-exact everywhere (integer / index work)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import suffix_array_amd as sa
+from suffix_array_amd import corpus
+from conftest import KNOWN_ANSWERS, adversarial_cases
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build(text):
+    return sa.SuffixArray(text).into_parts()[1]
+
+
+def test_device_visible():
+    assert sa.lib().sa_amd_device_count() >= 1
+
+
+# ---- primitives -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("count,bits", [(1, (0, 64)), (2, (0, 64)), (63, (0, 64)), (4095, (0, 64)), (4096, (0, 64)),
+                                        (4097, (0, 64)), (100_000, (0, 64)), (1_000_003, (0, 64)),
+                                        (300_000, (0, 24)), (300_000, (8, 40)), (300_000, (5, 62)),
+                                        (5_000_000, (0, 64))])
+def test_radix_sort_pairs(count, bits):
+    rng = np.random.default_rng(count + bits[1])
+    keys = rng.integers(0, 2**64, count, dtype=np.uint64)
+    if count > 10:
+        keys[count // 3: count // 3 + count // 10] &= np.uint64(0xFF)       # many duplicates
+    vals = np.arange(count, dtype=np.uint32)
+    lo, hi = bits
+    mask = np.uint64((1 << hi) - 1) if hi < 64 else np.uint64(2**64 - 1)
+    field = (keys & mask) >> np.uint64(lo)
+    order = np.argsort(field, kind="stable")
+    k2, v2 = keys.copy(), vals.copy()
+    assert sa.lib().sa_amd_test_sort_pairs(k2.ctypes.data, v2.ctypes.data, count, lo, hi) == 0
+    assert np.array_equal(v2, vals[order])          # stable: equal fields keep input order
+    assert np.array_equal(k2, keys[order])
+
+
+def test_radix_sort_constant_and_skewed_digits():
+    count = 777_777
+    keys = np.full(count, 0x0102030405060708, dtype=np.uint64)
+    keys[::1000] = 7
+    vals = np.arange(count, dtype=np.uint32)
+    order = np.argsort(keys, kind="stable")
+    k2, v2 = keys.copy(), vals.copy()
+    assert sa.lib().sa_amd_test_sort_pairs(k2.ctypes.data, v2.ctypes.data, count, 0, 64) == 0
+    assert np.array_equal(v2, vals[order]) and np.array_equal(k2, keys[order])
+
+
+@pytest.mark.parametrize("gen,n", [("uniform", 100_003), ("dna", 70_001), ("english", 50_000), ("unary", 5000)])
+def test_build_keys(gen, n):
+    import pd_model
+    text = {"uniform": lambda: corpus.uniform(n, 1), "dna": lambda: corpus.dna(n, 1),
+            "english": lambda: corpus.english(n, 1), "unary": lambda: np.full(n, 65, dtype=np.uint8)}[gen]()
+    keys = np.zeros(n, dtype=np.uint64)
+    bits, k = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
+    assert sa.lib().sa_amd_test_build_keys(text.ctypes.data, n, keys.ctypes.data, bits.ctypes.data, k.ctypes.data) == 0
+    code, ebits, ek = pd_model.alphabet(text)
+    assert (int(bits[0]), int(k[0])) == (ebits, ek)
+    sym = np.concatenate([code[text], np.zeros(ek, dtype=np.uint64)])
+    exp = np.zeros(n, dtype=np.uint64)
+    for j in range(ek):
+        exp = (exp << np.uint64(ebits)) | sym[j:j + n]
+    assert np.array_equal(keys, exp)
+
+
+# ---- the path itself --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("text,expected", KNOWN_ANSWERS)
+def test_known_answers(text, expected):
+    assert build(text).tolist() == expected
+
+
+def test_golden_fixtures():
+    manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    for name in manifest:
+        text = open(os.path.join(GOLDEN, name + ".text"), "rb").read()
+        exp = np.fromfile(os.path.join(GOLDEN, name + ".sa.u32le"), dtype="<u4")
+        assert np.array_equal(build(text), exp), name
+
+
+@pytest.mark.parametrize("name", sorted(adversarial_cases()))
+def test_adversarial(oracle, name):
+    s = adversarial_cases()[name]
+    assert np.array_equal(build(s), oracle.sais(s))
+
+
+def test_conversion_correctness(oracle):
+    """reference src/tests.rs:13-17: random bytes, n in [0, 4096): new().into_parts() must pass
+    from_parts (check_integrity) -- and here also equal the oracle bit for bit."""
+    rng = np.random.default_rng(20240)
+    for it in range(150):
+        n = int(rng.integers(0, 4096))
+        s = rng.integers(0, 256, n, dtype=np.uint8)
+        text, arr = sa.SuffixArray(s).into_parts()
+        assert sa.SuffixArray.from_parts(text, arr) is not None
+        assert oracle.check_integrity(s, arr) == 1
+        assert np.array_equal(arr, oracle.sais(s))
+
+
+def test_small_alphabets_and_ragged_lengths(oracle):
+    rng = np.random.default_rng(7)
+    for it in range(120):
+        n = int(rng.integers(0, 20000))
+        sigma = int(rng.choice([1, 2, 3, 4, 5, 9, 17, 33, 65, 129, 256]))
+        base = int(rng.integers(0, 257 - sigma))
+        s = (rng.integers(0, sigma, n) + base).astype(np.uint8)
+        assert np.array_equal(build(s), oracle.sais(s)), (n, sigma, base)
+
+
+def test_set_reuses_buffer_with_stale_contents(oracle):
+    """reference src/sa.rs:30-33: set() re-runs construction into a previously used buffer"""
+    obj = sa.SuffixArray(b"mississippi")
+    obj.set(b"banana")
+    assert obj.into_parts()[1].tolist() == [6, 5, 3, 1, 0, 4, 2]
+    obj.set(corpus.english(5000, 9))
+    assert np.array_equal(obj.into_parts()[1], oracle.sais(corpus.english(5000, 9)))
+
+
+def test_divsufsort_entry_point(oracle):
+    """the C engine's signature (reference src/saca.rs:14): n int32 entries, no sentinel slot"""
+    s = corpus.uniform(100_000, 5)
+    out = np.full(s.size, -1, dtype=np.int32)
+    sa.divsufsort(s, out)
+    assert np.array_equal(out.astype(np.uint32), oracle.sais(s)[1:])
+
+
+@pytest.mark.parametrize("gen,n,seed", [("uniform", 1 << 20, 2), ("english", 1 << 20, 3), ("dna", 1 << 20, 4),
+                                        ("dna_repeats", 1 << 20, 5), ("english", (4 << 20) + 1, 6),
+                                        ("uniform", (16 << 20) - 1, 7), ("dna", 16 << 20, 8)])
+def test_medium_sizes_bit_exact(oracle, gen, n, seed):
+    text = getattr(corpus, gen)(n, seed)
+    assert np.array_equal(build(text), oracle.sais(text))
+
+
+def test_batch_entry_point(oracle):
+    texts = [corpus.uniform(50_000, 50 + i) for i in range(3)] + [np.zeros(0, dtype=np.uint8), corpus.dna(30_000, 1)]
+    outs = sa.saca_batch(texts)
+    for t, o in zip(texts, outs):
+        assert np.array_equal(o, oracle.sais(t))
+
+
+def test_degenerate_large_runs(oracle):
+    for s in (np.full(1 << 20, 0, dtype=np.uint8), np.tile(np.array([1, 2], dtype=np.uint8), 1 << 19),
+              np.full((1 << 20) + 3, 255, dtype=np.uint8)):
+        assert np.array_equal(build(s), oracle.sais(s))
+
+
+# ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------
+
+@pytest.mark.parametrize("name", ["c2_uniform_64m", "c3_english_256m"])
+def test_full_size_configs(oracle, name):
+    text = corpus.workload(name)
+    arr = build(text)
+    assert arr[0] == text.size
+    assert oracle.verify(text, arr) == 1          # linear-time form of reference src/sa.rs:72-84
+    if text.size <= (64 << 20):
+        assert np.array_equal(arr, oracle.sais(text))
