@@ -93,6 +93,14 @@ int32_t sa_amd_device_count(void);
 const char *sa_amd_strerror(int32_t code);
 const char *sa_amd_version(void);
 
+/* ---- per-kernel timing (HIP events on the launch stream), per calling thread ----
+ * begin() zeroes and enables the counters for builds issued by this thread; end() disables them and
+ * copies up to `capacity` classes out (ms = summed event time, launches, units = elements or bytes
+ * processed); returns the number of kernel classes.  Used by bench.py for the roofline line. */
+void sa_amd_profile_begin(void);
+int32_t sa_amd_profile_end(double *ms, int64_t *launches, int64_t *units, int32_t capacity);
+const char *sa_amd_profile_kernel_name(int32_t index);
+
 /* ---- primitive test hooks: exercised by tests/ to localise a failing kernel ---- */
 
 /* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit); host buffers */

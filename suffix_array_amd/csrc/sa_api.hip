@@ -42,6 +42,48 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int bit_length(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
+enum KClass { KC_BYTE_HIST = 0, KC_BUILD_KEYS, KC_UPSWEEP, KC_SPINE, KC_DOWNSWEEP, KC_RR_COUNT, KC_RR_SCAN, KC_RR_APPLY,
+              KC_GATHER, KC_MISC, KC_COUNT };
+static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys", "k_radix_upsweep", "k_excl_scan_u32",
+                                                    "k_radix_downsweep", "k_rr_count", "k_rr_scan", "k_rr_apply",
+                                                    "k_gather_key2", "misc" };
+struct Profiler {
+    bool on = false;
+    struct Rec { int cls; hipEvent_t a, b; int64_t units; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double ms[KC_COUNT] = { 0 };
+    int64_t launches[KC_COUNT] = { 0 }, units[KC_COUNT] = { 0 };
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void begin(int cls, int64_t u, hipStream_t st)
+    {
+        if (!on) return;
+        Rec r; r.cls = cls; r.units = u; r.a = get(); r.b = get();
+        (void)hipEventRecord(r.a, st);
+        recs.push_back(r);
+    }
+    void end(hipStream_t st) { if (on && !recs.empty()) (void)hipEventRecord(recs.back().b, st); }
+    void resolve()   // call after the stream has been synchronised
+    {
+        for (auto &r : recs) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.cls] += t; launches[r.cls]++; units[r.cls] += r.units; }
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+};
+static thread_local Profiler g_prof;
+#define PROF(cls, units, st, launch_stmt)                                                          \
+    do { g_prof.begin(cls, units, st); launch_stmt; g_prof.end(st); LAUNCH_CHECK(st); } while (0)
+
 constexpr int SORT_MAX_WG = 1024;   // 256 CUs x 4 resident workgroups (38 KB LDS each)
 
 struct SortGrid { int G; int64_t tiles_per_wg; };
@@ -103,15 +145,12 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
     for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
         const int nb = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
         const uint32_t dmask = (1u << nb) - 1u;
-        hipLaunchKernelGGL(k_radix_upsweep, dim3(g.G), dim3(SORT_THREADS), 0, st, kin, spine, count, shift, dmask,
-                           g.tiles_per_wg, g.G);
-        LAUNCH_CHECK(st);
-        hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(SPINE_THREADS), 0, st, spine, (int64_t)RADIX * g.G,
-                           (uint32_t *)nullptr);
-        LAUNCH_CHECK(st);
-        hipLaunchKernelGGL(k_radix_downsweep, dim3(g.G), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, spine, count,
-                           shift, dmask, g.tiles_per_wg, g.G);
-        LAUNCH_CHECK(st);
+        PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.G), dim3(SORT_THREADS), 0, st, kin, spine, count, shift, dmask,
+                           g.tiles_per_wg, g.G));
+        PROF(KC_SPINE, (int64_t)RADIX * g.G, st, hipLaunchKernelGGL((k_excl_scan_u32), dim3(1), dim3(SPINE_THREADS), 0, st, spine, (int64_t)RADIX * g.G,
+                           (uint32_t *)nullptr));
+        PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((k_radix_downsweep), dim3(g.G), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, spine, count,
+                           shift, dmask, g.tiles_per_wg, g.G));
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
         res->passes++;
@@ -143,8 +182,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     sa_amd_stats local;
     memset(&local, 0, sizeof(local));
     if (n == 0) {
-        hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, 0u);
-        LAUNCH_CHECK(st);
+        PROF(KC_MISC, 1, st, hipLaunchKernelGGL((k_set_u32), dim3(1), dim3(1), 0, st, dSA, 0u));
         HIP_TRY(hipStreamSynchronize(st));
         if (stats) *stats = local;
         return SA_AMD_OK;
@@ -159,8 +197,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         int64_t blocks = ceil_div(ceil_div(n, 16), BH_THREADS);
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(k_byte_hist, dim3((unsigned)blocks), dim3(BH_THREADS), 0, st, dT, n, w.hist);
-        LAUNCH_CHECK(st);
+        PROF(KC_BYTE_HIST, n, st, hipLaunchKernelGGL((k_byte_hist), dim3((unsigned)blocks), dim3(BH_THREADS), 0, st, dT, n, w.hist));
     }
     uint32_t hist[256];
     HIP_TRY(hipMemcpyAsync(hist, w.hist, sizeof(hist), hipMemcpyDeviceToHost, st));
@@ -171,9 +208,8 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
 
     // 2. packed keys, 3. initial sort
-    hipLaunchKernelGGL(k_build_keys, dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P, w.keysA,
-                       w.valsA);
-    LAUNCH_CHECK(st);
+    PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P, w.keysA,
+                       w.valsA));
     SortResult sr;
     int rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, P.k * P.bits, w.spine, st, &sr);
     if (rc) return rc;
@@ -183,14 +219,11 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     uint32_t *Ucur = w.U0, *Unext = w.U1, *Gcur = w.G0, *Gnext = w.G1;
     uint32_t *Vcur = (sr.vals == w.valsA) ? w.valsB : w.valsA;
     int64_t tiles = ceil_div(n, RR_TILE);
-    hipLaunchKernelGGL(k_rr_count<true>, dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, (const uint32_t *)nullptr,
-                       n, w.tcnt, w.thead);
-    LAUNCH_CHECK(st);
-    hipLaunchKernelGGL(k_rr_scan, dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total);
-    LAUNCH_CHECK(st);
-    hipLaunchKernelGGL(k_rr_apply<true>, dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, sr.vals,
-                       (const uint32_t *)nullptr, n, w.tcnt, w.thead, SA, w.isa, Ucur, Gcur, Vcur);
-    LAUNCH_CHECK(st);
+    PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, (const uint32_t *)nullptr,
+                       n, w.tcnt, w.thead));
+    PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+    PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, sr.vals,
+                       (const uint32_t *)nullptr, n, w.tcnt, w.thead, SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n));
     uint32_t m32 = 0;
     HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -206,22 +239,18 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
         int64_t gblocks = ceil_div(m, GK_THREADS);
         if (gblocks > 8192) gblocks = 8192;
-        hipLaunchKernelGGL(k_gather_key2, dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st, Vcur, Gcur, w.isa, m, n, h,
-                           key2_bits, w.keysA);
-        LAUNCH_CHECK(st);
+        PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st, Vcur, Gcur, w.isa, m, n, h,
+                           key2_bits, w.keysA));
         rc = sort_pairs(w.keysA, Vcur, w.keysB, Valt, m, 0, key2_bits + g_bits, w.spine, st, &sr);
         if (rc) return rc;
         local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m;
         uint32_t *Vnext = (sr.vals == w.valsA) ? w.valsB : w.valsA;
         tiles = ceil_div(m, RR_TILE);
-        hipLaunchKernelGGL(k_rr_count<false>, dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, Ucur, m, w.tcnt,
-                           w.thead);
-        LAUNCH_CHECK(st);
-        hipLaunchKernelGGL(k_rr_scan, dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total);
-        LAUNCH_CHECK(st);
-        hipLaunchKernelGGL(k_rr_apply<false>, dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, sr.vals, Ucur, m,
-                           w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext);
-        LAUNCH_CHECK(st);
+        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, Ucur, m, w.tcnt,
+                           w.thead));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, sr.vals, Ucur, m,
+                           w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext, (uint32_t)n));
         HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         m = m32;
@@ -235,6 +264,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);   // reference src/saca.rs:13
     LAUNCH_CHECK(st);
     HIP_TRY(hipStreamSynchronize(st));
+    g_prof.resolve();
     if (stats) *stats = local;
     return SA_AMD_OK;
 }
@@ -353,6 +383,31 @@ SA_EXPORT const char *sa_amd_strerror(int32_t code)
     case SA_AMD_EINTERNAL: return "internal error: refinement did not converge";
     default: return "unknown error";
     }
+}
+
+SA_EXPORT void sa_amd_profile_begin(void)
+{
+    sa::Profiler &p = sa::g_prof;
+    p.on = true;
+    for (int i = 0; i < sa::KC_COUNT; ++i) { p.ms[i] = 0; p.launches[i] = 0; p.units[i] = 0; }
+}
+
+SA_EXPORT int32_t sa_amd_profile_end(double *ms, int64_t *launches, int64_t *units, int32_t capacity)
+{
+    sa::Profiler &p = sa::g_prof;
+    p.on = false;
+    const int cnt = capacity < sa::KC_COUNT ? capacity : sa::KC_COUNT;
+    for (int i = 0; i < cnt; ++i) {
+        if (ms) ms[i] = p.ms[i];
+        if (launches) launches[i] = p.launches[i];
+        if (units) units[i] = p.units[i];
+    }
+    return sa::KC_COUNT;
+}
+
+SA_EXPORT const char *sa_amd_profile_kernel_name(int32_t i)
+{
+    return (i >= 0 && i < sa::KC_COUNT) ? sa::kclass_names[i] : "";
 }
 
 SA_EXPORT const char *sa_amd_version(void) { return "suffix_array_amd 0.1.0 (gfx950)"; }

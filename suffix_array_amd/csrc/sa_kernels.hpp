@@ -249,8 +249,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_upsweep(const uint64_t *
         const uint32_t d0 = digit_of(q.x, shift, dmask), d1 = digit_of(q.y, shift, dmask);
         // constant digits (all-equal high bits) would serialise the LDS atomic 64 ways
         const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d0);
+        const uint32_t active = (uint32_t)__popcll(__ballot(1));   // evaluated by every active lane
         if (__all(d0 == f && d1 == f)) {
-            if (lane_id() == 0) atomicAdd(&mine[f], (uint32_t)(2 * __popcll(__ballot(1))));
+            if (lane_id() == 0) atomicAdd(&mine[f], 2u * active);
         } else {
             atomicAdd(&mine[d0], 1u);
             atomicAdd(&mine[d1], 1u);
@@ -504,7 +505,8 @@ template <bool FIRST>
 __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ V, const uint32_t *__restrict__ U, int64_t m,
     const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_head, uint32_t *__restrict__ SA,
-    uint32_t *__restrict__ ISA, uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo)
+    uint32_t *__restrict__ ISA, uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo,
+    uint32_t n_text)
 {
     __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
     const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
@@ -535,8 +537,8 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         const int64_t i = idx0 + r;
         if (i < m) {
             if ((f.head >> r) & 1u) run = slot[r] + 1u;
-            SA[slot[r]] = v[r];
-            ISA[v[r]] = run;
+            if (slot[r] < n_text) SA[slot[r]] = v[r];
+            if (v[r] < n_text) ISA[v[r]] = run;
             if ((f.tied >> r) & 1u) { Uo[off] = slot[r]; Go[off] = run - 1u; Vo[off] = v[r]; ++off; }
         }
     }
