@@ -45,7 +45,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
 enum KClass { KC_BYTE_HIST = 0, KC_BUILD_KEYS, KC_UPSWEEP, KC_SPINE, KC_DOWNSWEEP, KC_RR_COUNT, KC_RR_SCAN, KC_RR_APPLY,
               KC_GATHER, KC_MISC, KC_COUNT };
-static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys", "k_radix_upsweep", "k_excl_scan_u32",
+static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys", "k_radix_upsweep", "k_spine_rows",
                                                     "k_radix_downsweep", "k_rr_count", "k_rr_scan", "k_rr_apply",
                                                     "k_gather_key2", "misc" };
 struct Profiler {
@@ -102,7 +102,7 @@ static SortGrid sort_grid(int64_t count)
 struct Workspace {
     uint64_t *keysA, *keysB;
     uint32_t *valsA, *valsB, *isa, *U0, *U1, *G0, *G1;
-    uint32_t *spine, *tcnt, *thead, *hist, *total;
+    uint32_t *spine, *digit_tot, *tcnt, *thead, *hist, *total;
     size_t bytes;
 };
 
@@ -122,6 +122,7 @@ static Workspace carve(void *base, int64_t n)
     w.G0 = (uint32_t *)take(N * 4);
     w.G1 = (uint32_t *)take(N * 4);
     w.spine = (uint32_t *)take((size_t)RADIX * SORT_MAX_WG * 4);
+    w.digit_tot = (uint32_t *)take(RADIX * 4);
     const size_t rr_tiles = (size_t)ceil_div((int64_t)N, RR_TILE);
     w.tcnt = (uint32_t *)take(rr_tiles * 4);
     w.thead = (uint32_t *)take(rr_tiles * 4);
@@ -133,9 +134,13 @@ static Workspace carve(void *base, int64_t n)
 
 struct SortResult { uint64_t *keys; uint32_t *vals; int passes; };
 
-// stable LSD sort of `count` pairs on key bits [begin_bit, end_bit); ping-pongs between in/alt
+// stable LSD sort of `count` pairs on key bits [begin_bit, end_bit); ping-pongs between in/alt.
+// spine: RADIX * SORT_MAX_WG words, digit_tot: RADIX words.  final_vals (optional): the LAST pass
+// writes its values there instead of into the ping-pong buffer (the initial sort delivers
+// straight into SA this way).
 static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, uint32_t *vals_alt, int64_t count,
-                      int begin_bit, int end_bit, uint32_t *spine, hipStream_t st, SortResult *res)
+                      int begin_bit, int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals,
+                      hipStream_t st, SortResult *res)
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
@@ -145,14 +150,18 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
     for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
         const int nb = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
         const uint32_t dmask = (1u << nb) - 1u;
-        PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.G), dim3(SORT_THREADS), 0, st, kin, spine, count, shift, dmask,
-                           g.tiles_per_wg, g.G));
-        PROF(KC_SPINE, (int64_t)RADIX * g.G, st, hipLaunchKernelGGL((k_excl_scan_u32), dim3(1), dim3(SPINE_THREADS), 0, st, spine, (int64_t)RADIX * g.G,
-                           (uint32_t *)nullptr));
-        PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((k_radix_downsweep), dim3(g.G), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, spine, count,
-                           shift, dmask, g.tiles_per_wg, g.G));
+        const bool last = shift + RADIX_BITS >= end_bit;
+        uint32_t *vdst = (last && final_vals) ? final_vals : vout;
+        PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.G), dim3(SORT_THREADS), 0, st, kin, spine,
+                                                       count, shift, dmask, g.tiles_per_wg, g.G));
+        PROF(KC_SPINE, (int64_t)RADIX * g.G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st,
+                                                                    spine, digit_tot, g.G));
+        PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((k_radix_downsweep), dim3(g.G), dim3(SORT_THREADS), 0, st, kin, vin,
+                                                         kout, vdst, spine, digit_tot, count, shift, dmask, g.tiles_per_wg, g.G));
         uint64_t *tk = kin; kin = kout; kout = tk;
-        uint32_t *tv = vin; vin = vout; vout = tv;
+        uint32_t *free_v = vin;     // the values just consumed become the next scratch target
+        vin = vdst;
+        vout = free_v;
         res->passes++;
     }
     res->keys = kin; res->vals = vin;
@@ -211,24 +220,31 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P, w.keysA,
                        w.valsA));
     SortResult sr;
-    int rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, P.k * P.bits, w.spine, st, &sr);
+    int rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, P.k * P.bits, w.spine, w.digit_tot, SA, st, &sr);
     if (rc) return rc;
     local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
+    if (sr.vals != SA) {   // n == 1: no pass ran, the values are still in the input buffer
+        PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_copy_u32), dim3(1), dim3(256), 0, st, sr.vals, SA, n));
+    }
 
-    // 4. ranks of the initial groups, SA write, compaction of the tied suffixes
+    // 4. group heads of the initial order; how many suffixes are still tied with a neighbour
     uint32_t *Ucur = w.U0, *Unext = w.U1, *Gcur = w.G0, *Gnext = w.G1;
-    uint32_t *Vcur = (sr.vals == w.valsA) ? w.valsB : w.valsA;
+    uint32_t *Vcur = w.valsA;
     int64_t tiles = ceil_div(n, RR_TILE);
-    PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, (const uint32_t *)nullptr,
-                       n, w.tcnt, w.thead));
+    PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys,
+                                                (const uint32_t *)nullptr, n, w.tcnt, w.thead));
     PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-    PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, sr.vals,
-                       (const uint32_t *)nullptr, n, w.tcnt, w.thead, SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n));
     uint32_t m32 = 0;
     HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     int64_t m = m32;
     local.unresolved_after_initial = m;
+    if (m > 0) {
+        // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
+        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                    SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n));
+    }
 
     // 5. prefix doubling on the tied suffixes only
     const int key2_bits = bit_length((uint64_t)(2 * n));
@@ -241,7 +257,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         if (gblocks > 8192) gblocks = 8192;
         PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st, Vcur, Gcur, w.isa, m, n, h,
                            key2_bits, w.keysA));
-        rc = sort_pairs(w.keysA, Vcur, w.keysB, Valt, m, 0, key2_bits + g_bits, w.spine, st, &sr);
+        rc = sort_pairs(w.keysA, Vcur, w.keysB, Valt, m, 0, key2_bits + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
         if (rc) return rc;
         local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m;
         uint32_t *Vnext = (sr.vals == w.valsA) ? w.valsB : w.valsA;
@@ -249,7 +265,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, Ucur, m, w.tcnt,
                            w.thead));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, sr.vals, Ucur, m,
+        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, sr.vals, Ucur, m,
                            w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext, (uint32_t)n));
         HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -422,11 +438,11 @@ SA_EXPORT int32_t sa_amd_test_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t
     const size_t N = (size_t)count;
     HIP_TRY(hipMalloc((void **)&dk, N * 8 * 2));
     HIP_TRY(hipMalloc((void **)&dv, N * 4 * 2));
-    HIP_TRY(hipMalloc((void **)&spine, (size_t)RADIX * SORT_MAX_WG * 4));
+    HIP_TRY(hipMalloc((void **)&spine, ((size_t)RADIX * SORT_MAX_WG + RADIX) * 4));
     HIP_TRY(hipMemcpy(dk, keys, N * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dv, vals, N * 4, hipMemcpyHostToDevice));
     SortResult sr;
-    int rc = sort_pairs(dk, dv, dk + N, dv + N, count, begin_bit, end_bit, spine, nullptr, &sr);
+    int rc = sort_pairs(dk, dv, dk + N, dv + N, count, begin_bit, end_bit, spine, spine + (size_t)RADIX * SORT_MAX_WG, nullptr, nullptr, &sr);
     if (rc == SA_AMD_OK) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(keys, sr.keys, N * 8, hipMemcpyDeviceToHost));

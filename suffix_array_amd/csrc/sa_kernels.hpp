@@ -283,6 +283,20 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_excl_scan_u32(uint32_t *__res
     if (out_total && threadIdx.x == 0) *out_total = tot;
 }
 
+// Spine of one radix pass: block d turns counts[d][0..G) into exclusive prefixes (in place) and
+// writes the digit total; the downsweep prologue scans the 256 totals itself.  G <= 1024.
+__global__ __launch_bounds__(SPINE_THREADS) void k_spine_rows(uint32_t *__restrict__ counts,
+                                                               uint32_t *__restrict__ digit_tot, int G)
+{
+    __shared__ uint32_t lds[SPINE_THREADS / WAVE + 1];
+    const int d = blockIdx.x, g = threadIdx.x;
+    const uint32_t c = g < G ? counts[(int64_t)d * G + g] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_sum<SPINE_THREADS>(c, lds, &tot);
+    if (g < G) counts[(int64_t)d * G + g] = ex;
+    if (g == 0) digit_tot[d] = tot;
+}
+
 template <bool FULL>
 __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                           uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
@@ -377,15 +391,20 @@ __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ keys_in, 
 
 __global__ __launch_bounds__(SORT_THREADS) void k_radix_downsweep(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, int64_t n, int shift, uint32_t dmask,
-    int64_t tiles_per_wg, int G)
+    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
+    int64_t n, int shift, uint32_t dmask, int64_t tiles_per_wg, int G)
 {
     __shared__ __attribute__((aligned(16))) uint64_t lds_kv[SORT_TILE];
     __shared__ uint32_t wave_hist[SORT_WAVES][RADIX];
     __shared__ uint32_t digit_base[RADIX];
     __shared__ uint32_t run_off[RADIX];
     __shared__ uint32_t scan_lds[SORT_WAVES + 1];
-    run_off[threadIdx.x] = spine[(int64_t)threadIdx.x * G + blockIdx.x];
+    {
+        // global start of digit d = totals of the smaller digits + this workgroup's row prefix
+        uint32_t all;
+        const uint32_t gbase = block_excl_sum<SORT_THREADS>(digit_tot[threadIdx.x], scan_lds, &all);
+        run_off[threadIdx.x] = gbase + spine[(int64_t)threadIdx.x * G + blockIdx.x];
+    }
     __syncthreads();
     const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
     for (int64_t t = 0; t < tiles_per_wg; ++t) {
@@ -501,7 +520,7 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict_
     if (threadIdx.x == 0) *out_total = tot;
 }
 
-template <bool FIRST>
+template <bool FIRST, bool WRITE_SA>
 __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ V, const uint32_t *__restrict__ U, int64_t m,
     const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_head, uint32_t *__restrict__ SA,
@@ -537,7 +556,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         const int64_t i = idx0 + r;
         if (i < m) {
             if ((f.head >> r) & 1u) run = slot[r] + 1u;
-            if (slot[r] < n_text) SA[slot[r]] = v[r];
+            if (WRITE_SA && slot[r] < n_text) SA[slot[r]] = v[r];
             if (v[r] < n_text) ISA[v[r]] = run;
             if ((f.tied >> r) & 1u) { Uo[off] = slot[r]; Go[off] = run - 1u; Vo[off] = v[r]; ++off; }
         }
@@ -568,5 +587,11 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_key2(const uint32_t *__re
 }
 
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
+
+__global__ __launch_bounds__(256) void k_copy_u32(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
 
 }  // namespace sa
