@@ -88,3 +88,19 @@ def test_from_parts_checks_integrity(oracle):
     shifted = good.copy(); shifted[0] = 0
     assert sa.SuffixArray.from_parts(text, shifted) is None
     assert sa.SuffixArray.unchecked_from_parts(text, bad).len() == len(text)
+
+
+def test_cpp_mirror_header_compiles(tmp_path):
+    """include/suffix_array_amd.hpp (C++ host mirror of the reference interface) is valid C++17"""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "suffix_array_amd.hpp"\n'
+                   'int main() { const unsigned char t[] = "banana";\n'
+                   '  auto a = suffix_array::SuffixArray::from_parts(t, 6, {6, 5, 3, 1, 0, 4, 2});\n'
+                   '  auto b = suffix_array::SuffixArray::from_parts(t, 6, {6, 5, 3, 1, 0, 2, 4});\n'
+                   '  return (a.has_value() && !b.has_value() && a->len() == 6) ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "suffix_array_amd"), "-lsuffix_array_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "suffix_array_amd")])
+    assert subprocess.call([str(exe)]) == 0
