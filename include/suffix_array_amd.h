@@ -70,7 +70,7 @@ typedef struct sa_amd_stats {
     int32_t symbols_per_key;  /* symbols in the initial 64-bit key */
     int32_t rounds;           /* prefix-doubling refinement rounds after the initial sort */
     int32_t sort_passes;      /* 8-bit radix passes executed in total */
-    int32_t reserved;
+    int32_t sparse_mode;      /* 1: few tied suffixes, ranks looked up in the sorted keys instead of a full ISA */
     int64_t sorted_elements;  /* sum over sort passes of elements moved */
     int64_t unresolved_after_initial; /* suffixes still in groups > 1 after the initial sort */
 } sa_amd_stats;
@@ -86,6 +86,9 @@ int64_t sa_amd_workspace_bytes(int32_t n);
  */
 int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n, void *dWork,
                            int64_t work_bytes, void *stream, sa_amd_stats *stats);
+
+/* statistics of the most recent build issued by the calling thread (any entry point) */
+void sa_amd_last_stats(sa_amd_stats *out);
 
 /* number of visible HIP devices (0 when none; never initialises a context by itself) */
 int32_t sa_amd_device_count(void);

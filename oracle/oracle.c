@@ -248,3 +248,26 @@ ORACLE_API void oracle_bucket_table(const uint8_t *s, int64_t n, uint32_t *bkt)
     uint32_t sum = 0;                                             /* src/sa.rs:112-116 */
     for (int64_t i = 0; i < len; ++i) { sum += bkt[i]; bkt[i] = sum; }
 }
+
+/* ------------------------------------------------------------------ */
+/* LCP array by Kasai et al. (analysis helper for DESIGN.md: how deep  */
+/* must suffixes be compared before they are unique).  lcp[i] = LCP of */
+/* the suffixes at sa[i-1] and sa[i], lcp[0] = 0; sa has n+1 entries.  */
+/* ------------------------------------------------------------------ */
+ORACLE_API int32_t oracle_lcp_kasai(const uint8_t *s, int64_t n, const uint32_t *sa, uint32_t *lcp)
+{
+    uint32_t *rank = (uint32_t *)malloc(((size_t)n + 1) * sizeof(uint32_t));
+    if (!rank) return -2;
+    for (int64_t i = 0; i <= n; ++i) rank[sa[i]] = (uint32_t)i;
+    int64_t h = 0;
+    lcp[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t r = rank[i];          /* r >= 1 because the empty suffix has rank 0 */
+        int64_t j = sa[r - 1];
+        while (i + h < n && j + h < n && s[i + h] == s[j + h]) ++h;
+        lcp[r] = (uint32_t)h;
+        if (h > 0) --h;
+    }
+    free(rank);
+    return 0;
+}

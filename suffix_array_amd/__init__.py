@@ -42,11 +42,11 @@ class Stats(ctypes.Structure):
     """sa_amd_stats of include/suffix_array_amd.h"""
     _fields_ = [("sigma", ctypes.c_int32), ("bits_per_symbol", ctypes.c_int32),
                 ("symbols_per_key", ctypes.c_int32), ("rounds", ctypes.c_int32),
-                ("sort_passes", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("sort_passes", ctypes.c_int32), ("sparse_mode", ctypes.c_int32),
                 ("sorted_elements", ctypes.c_int64), ("unresolved_after_initial", ctypes.c_int64)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 def library_path() -> str:
@@ -75,6 +75,8 @@ def lib() -> ctypes.CDLL:
         L.sa_amd_saca_device.argtypes = [c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int64, c_vp, c_vp]
         L.sa_amd_saca_device.restype = ctypes.c_int32
         L.sa_amd_device_count.restype = ctypes.c_int32
+        L.sa_amd_last_stats.argtypes = [c_vp]
+        L.sa_amd_last_stats.restype = None
         L.sa_amd_strerror.argtypes = [ctypes.c_int32]
         L.sa_amd_strerror.restype = ctypes.c_char_p
         L.sa_amd_version.restype = ctypes.c_char_p
@@ -139,6 +141,13 @@ def saca_batch(texts, devices=None):
     rc = lib().sa_amd_saca_batch(T, S, N, D, cnt, st)
     _check(rc)
     return outs
+
+
+def last_stats() -> dict:
+    """statistics of the most recent build issued by this thread"""
+    st = Stats()
+    lib().sa_amd_last_stats(ctypes.byref(st))
+    return st.as_dict()
 
 
 def workspace_bytes(n: int) -> int:

@@ -81,17 +81,64 @@ struct Profiler {
     }
 };
 static thread_local Profiler g_prof;
+static thread_local sa_amd_stats g_last_stats;
 #define PROF(cls, units, st, launch_stmt)                                                          \
     do { g_prof.begin(cls, units, st); launch_stmt; g_prof.end(st); LAUNCH_CHECK(st); } while (0)
 
-constexpr int SORT_MAX_WG = 1024;   // 256 CUs x 4 resident workgroups (38 KB LDS each)
+constexpr int64_t SPARSE_DIV = 64;  // sparse refinement when at most n / 64 suffixes are tied after the initial sort
+constexpr int SORT_MAX_WG = 1024;   // spine rows are scanned by one 1024-thread block
 
-struct SortGrid { int G; int64_t tiles_per_wg; };
+// downsweep configurations (threads, items per thread, min waves per SIMD); SA_AMD_SORT_VARIANT
+// selects one at run time for A/B measurements, the default is the fastest measured on MI355X
+typedef void (*DownsweepFn)(const uint64_t *, const uint32_t *, uint64_t *, uint32_t *, const uint32_t *,
+                            const uint32_t *, int64_t, int, uint32_t, int64_t, int);
+struct SortVariant { int threads, items, wg_per_cu; DownsweepFn fn; const char *name; };
+static const SortVariant sort_variants[] = {
+    { 256, 16, 4, k_radix_downsweep<256, 16, 1>, "256x16" },
+    { 256, 16, 4, k_radix_downsweep<256, 16, 4>, "256x16 <=128 vgpr" },
+    { 512, 16, 1, k_radix_downsweep<512, 16, 1>, "512x16" },
+    { 512, 16, 2, k_radix_downsweep<512, 16, 4>, "512x16 <=128 vgpr" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8>, "1024x8 <=64 vgpr" },
+    { 256, 8, 4, k_radix_downsweep<256, 8, 4>, "256x8 <=128 vgpr" },
+    { 512, 8, 4, k_radix_downsweep<512, 8, 8>, "512x8 <=64 vgpr" },
+    { 256, 12, 4, k_radix_downsweep<256, 12, 4>, "256x12 <=128 vgpr" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 1>, "1024x8 ABLATION sequential stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 2>, "1024x8 ABLATION no ballot matching (wrong results)" },
+    { 1024, 16, 1, k_radix_downsweep<1024, 16, 4>, "1024x16 <=128 vgpr" },
+    { 1024, 12, 1, k_radix_downsweep<1024, 12, 4>, "1024x12 <=128 vgpr" },
+    { 512, 16, 1, k_radix_downsweep<512, 16, 2, 1>, "512x16 ABLATION sequential stores" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 4>, "1024x8 nt loads" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 8>, "1024x8 nt stores" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 12>, "1024x8 nt loads+stores" },
+    { 1024, 8, 1, k_radix_downsweep<1024, 8, 8, 0>, "1024x8, 256 workgroups" },
+    { 512, 12, 1, k_radix_downsweep_wc<512, 12, false>, "write-combined 512x12" },
+    { 512, 12, 1, k_radix_downsweep_wc<512, 12, true>, "write-combined 512x12 prefetch" },
+    { 512, 8, 1, k_radix_downsweep_wc<512, 8, true>, "write-combined 512x8 prefetch" },
+    { 1024, 4, 1, k_radix_downsweep_wc<1024, 4, true>, "write-combined 1024x4 prefetch" },
+    { 1024, 6, 1, k_radix_downsweep_wc<1024, 6, true>, "write-combined 1024x6 prefetch" },
+};
+constexpr int SORT_DEFAULT_VARIANT = 0;
+static const SortVariant &sort_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SA_AMD_SORT_VARIANT");
+        v = e ? atoi(e) : SORT_DEFAULT_VARIANT;
+        if (v < 0 || v >= (int)(sizeof(sort_variants) / sizeof(sort_variants[0]))) v = SORT_DEFAULT_VARIANT;
+    }
+    return sort_variants[v];
+}
+
+struct SortGrid { int G; int64_t tiles_per_wg; int tile; };
 static SortGrid sort_grid(int64_t count)
 {
-    const int64_t tiles = ceil_div(count, SORT_TILE);
+    const SortVariant &sv = sort_variant();
     SortGrid g;
-    g.tiles_per_wg = ceil_div(tiles, SORT_MAX_WG);
+    g.tile = sv.threads * sv.items;
+    const int64_t tiles = ceil_div(count, g.tile);
+    int max_wg = 256 * sv.wg_per_cu;
+    if (max_wg > SORT_MAX_WG) max_wg = SORT_MAX_WG;
+    g.tiles_per_wg = ceil_div(tiles, max_wg);
     if (g.tiles_per_wg < 1) g.tiles_per_wg = 1;
     g.G = (int)ceil_div(tiles, g.tiles_per_wg);
     if (g.G < 1) g.G = 1;
@@ -102,7 +149,7 @@ static SortGrid sort_grid(int64_t count)
 struct Workspace {
     uint64_t *keysA, *keysB;
     uint32_t *valsA, *valsB, *isa, *U0, *U1, *G0, *G1;
-    uint32_t *spine, *digit_tot, *tcnt, *thead, *hist, *total;
+    uint32_t *spine, *digit_tot, *tcnt, *thead, *hist, *total, *has_isa;
     size_t bytes;
 };
 
@@ -128,6 +175,7 @@ static Workspace carve(void *base, int64_t n)
     w.thead = (uint32_t *)take(rr_tiles * 4);
     w.hist = (uint32_t *)take(256 * 4);
     w.total = (uint32_t *)take(256);
+    w.has_isa = (uint32_t *)take((N + 31) / 32 * 4);
     w.bytes = off;
     return w;
 }
@@ -145,6 +193,7 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
     res->keys = keys_in; res->vals = vals_in; res->passes = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
     const SortGrid g = sort_grid(count);
+    const SortVariant &sv = sort_variant();
     uint64_t *kin = keys_in, *kout = keys_alt;
     uint32_t *vin = vals_in, *vout = vals_alt;
     for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
@@ -153,11 +202,13 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
         const bool last = shift + RADIX_BITS >= end_bit;
         uint32_t *vdst = (last && final_vals) ? final_vals : vout;
         PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.G), dim3(SORT_THREADS), 0, st, kin, spine,
-                                                       count, shift, dmask, g.tiles_per_wg, g.G));
+                                                       count, shift, dmask, g.tiles_per_wg * g.tile, g.G));
         PROF(KC_SPINE, (int64_t)RADIX * g.G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st,
                                                                     spine, digit_tot, g.G));
-        PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((k_radix_downsweep), dim3(g.G), dim3(SORT_THREADS), 0, st, kin, vin,
-                                                         kout, vdst, spine, digit_tot, count, shift, dmask, g.tiles_per_wg, g.G));
+        PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((sv.fn), dim3(g.G), dim3(sv.threads), 0, st,
+                                                         (const uint64_t *)kin, (const uint32_t *)vin, kout, vdst,
+                                                         (const uint32_t *)spine, (const uint32_t *)digit_tot, count, shift,
+                                                         dmask, g.tiles_per_wg, g.G));
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *free_v = vin;     // the values just consumed become the next scratch target
         vin = vdst;
@@ -239,11 +290,25 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     HIP_TRY(hipStreamSynchronize(st));
     int64_t m = m32;
     local.unresolved_after_initial = m;
-    if (m > 0) {
-        // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
-        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+    // few tied suffixes: do not build the ISA (n random writes); ranks of untouched suffixes are
+    // looked up in the sorted initial keys instead (k_gather_key2_sparse)
+    const bool sparse = m > 0 && m <= n / SPARSE_DIV && !getenv("SA_AMD_FORCE_DENSE");
+    local.sparse_mode = sparse ? 1 : 0;
+    uint64_t *rkA = w.keysA, *rkB = w.keysB;          // key buffers of the refinement rounds
+    const uint64_t *sorted0 = sr.keys;
+    if (m > 0 && sparse) {
+        uint64_t *other = (sr.keys == w.keysA) ? w.keysB : w.keysA;   // keep the sorted initial keys intact
+        rkA = other;
+        rkB = other + (((size_t)n / 2 + 1) & ~(size_t)1);
+        HIP_TRY(hipMemsetAsync(w.has_isa, 0, ((size_t)n + 31) / 32 * 4, st));
+        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                    SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n));
+                                                    SA, w.isa, Ucur, Gcur, Vcur, 0u, w.has_isa));
+    } else if (m > 0) {
+        // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
+        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                    SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr));
     }
 
     // 5. prefix doubling on the tied suffixes only
@@ -255,9 +320,14 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
         int64_t gblocks = ceil_div(m, GK_THREADS);
         if (gblocks > 8192) gblocks = 8192;
-        PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st, Vcur, Gcur, w.isa, m, n, h,
-                           key2_bits, w.keysA));
-        rc = sort_pairs(w.keysA, Vcur, w.keysB, Valt, m, 0, key2_bits + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
+        if (sparse)
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2_sparse), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, (const uint32_t *)Gcur, (const uint32_t *)w.isa,
+                                                      (const uint32_t *)w.has_isa, sorted0, dT, P, m, n, h, key2_bits, rkA));
+        else
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st, Vcur, Gcur,
+                                                      w.isa, m, n, h, key2_bits, rkA));
+        rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, key2_bits + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
         if (rc) return rc;
         local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m;
         uint32_t *Vnext = (sr.vals == w.valsA) ? w.valsB : w.valsA;
@@ -265,8 +335,14 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, Ucur, m, w.tcnt,
                            w.thead));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, sr.vals, Ucur, m,
-                           w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext, (uint32_t)n));
+        if (sparse)
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                        (uint32_t)n, w.has_isa));
+        else
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                        (uint32_t)n, (uint32_t *)nullptr));
         HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         m = m32;
@@ -281,6 +357,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     LAUNCH_CHECK(st);
     HIP_TRY(hipStreamSynchronize(st));
     g_prof.resolve();
+    g_last_stats = local;
     if (stats) *stats = local;
     return SA_AMD_OK;
 }
@@ -379,6 +456,11 @@ SA_EXPORT int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n
 {
     if (n < 0 || !dSA || (n > 0 && (!dT || !dWork))) return SA_AMD_EINVAL;
     return sa::build_device(dT, dSA, n, dWork, work_bytes, (hipStream_t)stream, stats);
+}
+
+SA_EXPORT void sa_amd_last_stats(sa_amd_stats *out)
+{
+    if (out) *out = sa::g_last_stats;
 }
 
 SA_EXPORT int32_t sa_amd_device_count(void)

@@ -220,9 +220,6 @@ constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / WAVE;
-constexpr int SORT_ITEMS = 16;
-constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;    // 4096
-constexpr int SORT_WAVE_ELEMS = WAVE * SORT_ITEMS;      // 1024
 
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, uint32_t dmask)
 {
@@ -232,16 +229,16 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, uint32_t d
 __global__ __launch_bounds__(SORT_THREADS) void k_radix_upsweep(const uint64_t *__restrict__ keys,
                                                                  uint32_t *__restrict__ counts, int64_t n,
                                                                  int shift, uint32_t dmask,
-                                                                 int64_t tiles_per_wg, int G)
+                                                                 int64_t chunk_elems, int G)
 {
     __shared__ uint32_t h[SORT_WAVES][RADIX];
     for (int i = threadIdx.x; i < SORT_WAVES * RADIX; i += SORT_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
     uint32_t *mine = h[wave_id()];
-    const int64_t begin = (int64_t)blockIdx.x * tiles_per_wg * SORT_TILE;
-    int64_t end = begin + tiles_per_wg * SORT_TILE;
+    const int64_t begin = (int64_t)blockIdx.x * chunk_elems;
+    int64_t end = begin + chunk_elems;
     if (end > n) end = n;
-    // two keys (16 B) per lane per step; begin is a multiple of SORT_TILE so the pairs are aligned
+    // two keys (16 B) per lane per step; chunk_elems is a multiple of the tile size so the pairs are aligned
     const int64_t npair = (end - begin) / 2;
     const ulonglong2 *K2 = (const ulonglong2 *)(keys + begin);
     for (int64_t i = threadIdx.x; i < npair; i += SORT_THREADS) {
@@ -297,126 +294,361 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_spine_rows(uint32_t *__restri
     if (g == 0) digit_tot[d] = tot;
 }
 
-template <bool FULL>
+// One tile of THREADS * ITEMS pairs.  Element order inside the tile is wave-striped
+// (e = wave * 64 * ITEMS + item * 64 + lane), so every global load is a contiguous 512-B (keys) or
+// 256-B (values) burst per wave and "item-major, lane-minor" is the tile order that stability
+// is defined on.
+//
+// Ranking: for every item the lanes of a wave that hold the same digit are found with 8 ballots.
+// x accumulates, per lane, the lanes that differ from it in some digit bit (ballot XOR the lane's
+// own bit, sign-extended), so ~x is the match mask; v_mbcnt gives the number of matching lanes
+// below, v_bcnt the group size.  The lowest matching lane reads-then-bumps the wave's LDS counter
+// of that digit (no atomics: one wave executes its LDS operations in order).
+template <int THREADS, int ITEMS, bool FULL, int ABLATE>
 __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                           uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                           int64_t base, int valid, int shift, uint32_t dmask,
                                           uint64_t *lds_kv, uint32_t (*wave_hist)[RADIX], uint32_t *digit_base,
                                           uint32_t *run_off, uint32_t *scan_lds)
 {
+    constexpr int NWAVES = THREADS / WAVE;
+    constexpr int WAVE_ELEMS = WAVE * ITEMS;
+    static_assert(THREADS >= RADIX, "one thread per digit is assumed");
+    static_assert(ITEMS % 4 == 0, "digits are packed four to a register");
     const int tid = threadIdx.x, l = lane_id(), w = wave_id();
-    const uint64_t lt_mask = (1ull << l) - 1ull;
-    uint64_t key[SORT_ITEMS];
-    uint32_t val[SORT_ITEMS];
-    uint32_t pos[SORT_ITEMS];
-    // wave-striped loads: element e = w * 1024 + j * 64 + l
+    const int e0 = w * WAVE_ELEMS + l;
+    uint64_t key[ITEMS];
+    uint32_t pos[ITEMS];
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const int e = w * SORT_WAVE_ELEMS + j * WAVE + l;
-        if (FULL || e < valid) { key[j] = keys_in[base + e]; val[j] = vals_in[base + e]; }
-        else { key[j] = ~0ull; val[j] = 0; }
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = e0 + j * WAVE;
+        key[j] = (FULL || e < valid) ? ((ABLATE & 4) ? __builtin_nontemporal_load(keys_in + base + e) : keys_in[base + e]) : ~0ull;
     }
-    for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS) (&wave_hist[0][0])[i] = 0;
+    for (int i = tid; i < NWAVES * RADIX; i += THREADS) (&wave_hist[0][0])[i] = 0;
     __syncthreads();
-    // rank inside the wave: lanes with the same digit are found with 8 ballots
+    uint32_t *my_hist = wave_hist[w];
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const int e = w * SORT_WAVE_ELEMS + j * WAVE + l;
-        const bool ok = FULL || e < valid;
+    for (int j = 0; j < ITEMS; ++j) {
+        const bool ok = FULL || (e0 + j * WAVE) < valid;
         const uint32_t d = digit_of(key[j], shift, dmask);
-        uint64_t m = __ballot(ok);
+        if (ABLATE == 2) {   // timing-only build: no ballot matching (every lane pretends to be alone)
+            const uint32_t prior = my_hist[d];
+            if (ok) my_hist[d] = prior + 1;
+            pos[j] = prior;
+            continue;
+        }
+        uint32_t xlo = 0, xhi = 0;
+        if (!FULL) { const uint64_t okm = __ballot(ok); xlo = ~(uint32_t)okm; xhi = ~(uint32_t)(okm >> 32); }
 #pragma unroll
         for (int b = 0; b < RADIX_BITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
+            const uint32_t sel = (uint32_t)((int32_t)(d << (31 - b)) >> 31);      // 0 or ~0: my bit b
+            const uint64_t bal = __ballot(sel != 0);
+            xlo |= (uint32_t)bal ^ sel;
+            xhi |= (uint32_t)(bal >> 32) ^ sel;
         }
-        const uint32_t prior = wave_hist[w][d];
-        const uint32_t below = (uint32_t)__popcll(m & lt_mask);
-        if (ok && below == 0) wave_hist[w][d] = prior + (uint32_t)__popcll(m);
+        const uint32_t mlo = ~xlo, mhi = ~xhi;
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        const uint32_t prior = my_hist[d];
+        if (ok && below == 0) my_hist[d] = prior + (uint32_t)(__popc(mlo) + __popc(mhi));
         pos[j] = prior + below;
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);   // keep the items apart: interleaving them only adds SGPR pressure
+    }
+    // the values are only needed after the keys have left; issue their loads now so that the
+    // latency hides behind the prefix step and the key scatter
+    uint32_t val[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = e0 + j * WAVE;
+        val[j] = (FULL || e < valid) ? ((ABLATE & 4) ? __builtin_nontemporal_load(vals_in + base + e) : vals_in[base + e]) : 0u;
     }
     __syncthreads();
-    // thread d: turn the per-wave counts of digit d into per-wave offsets, scan the digit totals
+    // thread d: per-wave counts of digit d -> per-wave offsets; exclusive scan of the digit totals
     uint32_t tot = 0;
-    {
+    if (tid < RADIX) {
 #pragma unroll
-        for (int ww = 0; ww < SORT_WAVES; ++ww) {
+        for (int ww = 0; ww < NWAVES; ++ww) {
             const uint32_t cnt = wave_hist[ww][tid];
             wave_hist[ww][tid] = tot;
             tot += cnt;
         }
     }
     uint32_t tile_total;
-    const uint32_t dbase = block_excl_sum<SORT_THREADS>(tot, scan_lds, &tile_total);
-    digit_base[tid] = dbase;
+    const uint32_t dbase = block_excl_sum<THREADS>(tot, scan_lds, &tile_total);
+    if (tid < RADIX) digit_base[tid] = dbase;
     __syncthreads();
-    // scatter keys into LDS in sorted order
+    // keys -> LDS in sorted order, then out: a digit's run leaves as one contiguous burst
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const int e = w * SORT_WAVE_ELEMS + j * WAVE + l;
+    for (int j = 0; j < ITEMS; ++j) {
         const uint32_t d = digit_of(key[j], shift, dmask);
-        pos[j] += digit_base[d] + wave_hist[w][d];
-        if (FULL || e < valid) lds_kv[pos[j]] = key[j];
+        pos[j] += digit_base[d] + my_hist[d];
+        if (FULL || (e0 + j * WAVE) < valid) lds_kv[pos[j]] = key[j];
     }
     __syncthreads();
-    uint32_t gpos[SORT_ITEMS];
+    uint32_t dpack[ITEMS / 4];      // digits of the elements this thread writes out, 4 per register
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const int idx = tid + j * SORT_THREADS;
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = tid + j * THREADS;
+        if ((j & 3) == 0) dpack[j >> 2] = 0;
         if (FULL || idx < valid) {
             const uint64_t kx = lds_kv[idx];
             const uint32_t d = digit_of(kx, shift, dmask);
-            gpos[j] = run_off[d] + ((uint32_t)idx - digit_base[d]);
-            keys_out[gpos[j]] = kx;
+            dpack[j >> 2] |= d << (8 * (j & 3));
+            if (ABLATE == 1) keys_out[base + idx] = kx;   // timing-only build: sequential instead of scattered stores
+            else if (ABLATE & 8) __builtin_nontemporal_store(kx, keys_out + (run_off[d] + ((uint32_t)idx - digit_base[d])));
+            else keys_out[run_off[d] + ((uint32_t)idx - digit_base[d])] = kx;
         }
     }
     __syncthreads();
     uint32_t *lds_v = (uint32_t *)lds_kv;
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const int e = w * SORT_WAVE_ELEMS + j * WAVE + l;
-        if (FULL || e < valid) lds_v[pos[j]] = val[j];
-    }
+    for (int j = 0; j < ITEMS; ++j)
+        if (FULL || (e0 + j * WAVE) < valid) lds_v[pos[j]] = val[j];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const int idx = tid + j * SORT_THREADS;
-        if (FULL || idx < valid) vals_out[gpos[j]] = lds_v[idx];
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = tid + j * THREADS;
+        if (FULL || idx < valid) {
+            const uint32_t d = (dpack[j >> 2] >> (8 * (j & 3))) & 255u;
+            if (ABLATE == 1) vals_out[base + idx] = lds_v[idx];
+            else if (ABLATE & 8) __builtin_nontemporal_store(lds_v[idx], vals_out + (run_off[d] + ((uint32_t)idx - digit_base[d])));
+            else vals_out[run_off[d] + ((uint32_t)idx - digit_base[d])] = lds_v[idx];
+        }
     }
-    run_off[tid] += tot;     // thread d owns run_off[d]; the next tile starts behind a barrier
+    __syncthreads();
+    if (tid < RADIX) run_off[tid] += tot;     // thread d owns run_off[d]; the next tile starts behind a barrier
     __syncthreads();
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void k_radix_downsweep(
+// MINW = minimum waves per SIMD the register allocation has to allow (launch-bounds 2nd argument)
+template <int THREADS, int ITEMS, int MINW, int ABLATE = 0>
+__global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
     int64_t n, int shift, uint32_t dmask, int64_t tiles_per_wg, int G)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t lds_kv[SORT_TILE];
-    __shared__ uint32_t wave_hist[SORT_WAVES][RADIX];
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int NWAVES = THREADS / WAVE;
+    __shared__ __attribute__((aligned(16))) uint64_t lds_kv[TILE];
+    __shared__ uint32_t wave_hist[NWAVES][RADIX];
     __shared__ uint32_t digit_base[RADIX];
     __shared__ uint32_t run_off[RADIX];
-    __shared__ uint32_t scan_lds[SORT_WAVES + 1];
+    __shared__ uint32_t scan_lds[NWAVES + 1];
     {
         // global start of digit d = totals of the smaller digits + this workgroup's row prefix
         uint32_t all;
-        const uint32_t gbase = block_excl_sum<SORT_THREADS>(digit_tot[threadIdx.x], scan_lds, &all);
-        run_off[threadIdx.x] = gbase + spine[(int64_t)threadIdx.x * G + blockIdx.x];
+        const uint32_t t = threadIdx.x < RADIX ? digit_tot[threadIdx.x] : 0u;
+        const uint32_t gbase = block_excl_sum<THREADS>(t, scan_lds, &all);
+        if (threadIdx.x < RADIX) run_off[threadIdx.x] = gbase + spine[(int64_t)threadIdx.x * G + blockIdx.x];
     }
     __syncthreads();
     const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
     for (int64_t t = 0; t < tiles_per_wg; ++t) {
-        const int64_t base = (tile0 + t) * SORT_TILE;
+        const int64_t base = (tile0 + t) * TILE;
         if (base >= n) break;
         const int64_t rem = n - base;
-        if (rem >= SORT_TILE)
-            sort_tile<true>(keys_in, vals_in, keys_out, vals_out, base, SORT_TILE, shift, dmask, lds_kv, wave_hist,
-                            digit_base, run_off, scan_lds);
+        if (rem >= TILE)
+            sort_tile<THREADS, ITEMS, true, ABLATE>(keys_in, vals_in, keys_out, vals_out, base, TILE, shift, dmask, lds_kv,
+                                            wave_hist, digit_base, run_off, scan_lds);
         else
-            sort_tile<false>(keys_in, vals_in, keys_out, vals_out, base, (int)rem, shift, dmask, lds_kv, wave_hist,
-                             digit_base, run_off, scan_lds);
+            sort_tile<THREADS, ITEMS, false, ABLATE>(keys_in, vals_in, keys_out, vals_out, base, (int)rem, shift, dmask, lds_kv,
+                                             wave_hist, digit_base, run_off, scan_lds);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_radix_downsweep_wc: the same pass with LDS write combining.
+//
+// Measured on MI355X (profiles/r01_ablation.txt): with the plain tile scatter above, a digit's run
+// leaves a tile as ~16-32 elements at an arbitrary offset, i.e. as partial 128-B lines that the
+// per-XCD L2 has to keep until the workgroup's next tile completes them; the same kernel with
+// sequential stores runs 1.8x faster.  Here every workgroup keeps, per digit, the (< 16) elements
+// that do not yet fill a 16-element granule in an LDS carry buffer and only ever stores whole,
+// 16-element-aligned granules (128 B of keys, 64 B of values), except once per (workgroup, digit)
+// at the two ends of its chunk.
+//
+// Per tile and digit d (thread d does the bookkeeping):
+//   cur[d]   next global position of digit d in this workgroup's chunk
+//   wr[d]    everything below has been stored; pending = cur - wr < 16 elements sit in carry[d]
+//   stream   = carry (pending) followed by the tile's elements of digit d in rank order
+//   new wr   = cur' rounded down to 16 if that is beyond wr; the span [wr, new wr) is stored as
+//              granules, 16 consecutive lanes per granule; the rest of the stream becomes the carry
+// ------------------------------------------------------------------------------------------
+constexpr int WC_GR = 16;   // granule, elements
+
+template <int THREADS, int ITEMS, bool PREFETCH>
+__global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
+    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
+    int64_t n, int shift, uint32_t dmask, int64_t tiles_per_wg, int G)
+{
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int NWAVES = THREADS / WAVE;
+    constexpr int WAVE_ELEMS = WAVE * ITEMS;
+    constexpr int MAXGROUPS = TILE / WC_GR + RADIX;
+    static_assert(THREADS >= RADIX, "one thread per digit is assumed");
+    __shared__ __attribute__((aligned(16))) uint64_t stage_k[TILE];
+    __shared__ __attribute__((aligned(16))) uint64_t carry_k[RADIX * WC_GR];
+    __shared__ __attribute__((aligned(16))) uint32_t stage_v[TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t carry_v[RADIX * WC_GR];
+    __shared__ uint32_t wave_hist[NWAVES][RADIX];
+    __shared__ __attribute__((aligned(16))) uint4 drec[RADIX];     // per digit: {A, gbase, o | pending << 8 | left << 16, digit_base}
+    __shared__ uint32_t gstart[RADIX + 1];                          // exclusive scan of the granule counts
+    __shared__ uint32_t spanq[RADIX];                               // span (stream elements stored this tile)
+    __shared__ uint32_t cur[RADIX], wr[RADIX];
+    __shared__ uint8_t group_digit[MAXGROUPS];
+    __shared__ uint32_t scan_lds[NWAVES + 1];
+
+    const int tid = threadIdx.x, l = lane_id(), w = wave_id();
+    {
+        uint32_t all;
+        const uint32_t t = tid < RADIX ? digit_tot[tid] : 0u;
+        const uint32_t gbase = block_excl_sum<THREADS>(t, scan_lds, &all);
+        if (tid < RADIX) {
+            const uint32_t s0 = gbase + spine[(int64_t)tid * G + blockIdx.x];
+            cur[tid] = s0;
+            wr[tid] = s0;
+        }
+    }
+    __syncthreads();
+    uint32_t *my_hist = wave_hist[w];
+    const int e0 = w * WAVE_ELEMS + l;
+    const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
+    uint64_t key[ITEMS];
+    uint32_t val[ITEMS];
+    auto load_tile = [&](int64_t tb) {     // keys and values of the tile starting at element tb
+        const int64_t rem = n - tb;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int e = e0 + j * WAVE;
+            const bool in = e < rem;
+            key[j] = in ? keys_in[tb + e] : ~0ull;
+            val[j] = in ? vals_in[tb + e] : 0u;
+        }
+    };
+    if (PREFETCH && tile0 * TILE < n) load_tile(tile0 * TILE);
+    for (int64_t t = 0; t < tiles_per_wg; ++t) {
+        const int64_t base = (tile0 + t) * TILE;
+        if (base >= n) break;
+        const int valid = (n - base) >= TILE ? TILE : (int)(n - base);
+        const bool full = valid == TILE;
+        uint32_t pos[ITEMS];
+        if (!PREFETCH) load_tile(base);
+        for (int i = tid; i < NWAVES * RADIX; i += THREADS) (&wave_hist[0][0])[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool ok = full || (e0 + j * WAVE) < valid;
+            const uint32_t d = digit_of(key[j], shift, dmask);
+            const uint64_t okm = __ballot(ok);
+            uint32_t xlo = ~(uint32_t)okm, xhi = ~(uint32_t)(okm >> 32);
+#pragma unroll
+            for (int b = 0; b < RADIX_BITS; ++b) {
+                const uint32_t sel = (uint32_t)((int32_t)(d << (31 - b)) >> 31);
+                const uint64_t bal = __ballot(sel != 0);
+                xlo |= (uint32_t)bal ^ sel;
+                xhi |= (uint32_t)(bal >> 32) ^ sel;
+            }
+            const uint32_t mlo = ~xlo, mhi = ~xhi;
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+            const uint32_t prior = my_hist[d];
+            if (ok && below == 0) my_hist[d] = prior + (uint32_t)(__popc(mlo) + __popc(mhi));
+            pos[j] = prior + below;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // ---- per-digit bookkeeping (thread d) ----
+        uint32_t tot = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int ww = 0; ww < NWAVES; ++ww) {
+                const uint32_t cnt = wave_hist[ww][tid];
+                wave_hist[ww][tid] = tot;
+                tot += cnt;
+            }
+        }
+        uint32_t tile_total;
+        const uint32_t dbase = block_excl_sum<THREADS>(tot, scan_lds, &tile_total);
+        uint32_t ng = 0, A = 0, o = 0, pending = 0, span = 0, left = 0, c1 = 0, w1 = 0;
+        if (tid < RADIX) {
+            const uint32_t c0 = cur[tid], w0 = wr[tid];
+            pending = c0 - w0;
+            c1 = c0 + tot;
+            const uint32_t fl = c1 & ~(uint32_t)(WC_GR - 1);
+            w1 = fl > w0 ? fl : w0;
+            span = w1 - w0;
+            A = w0 & ~(uint32_t)(WC_GR - 1);
+            o = w0 - A;
+            ng = span ? (w1 - A) / WC_GR : 0u;
+            left = c1 - w1;
+        }
+        uint32_t ngroups;
+        const uint32_t gb = block_excl_sum<THREADS>(ng, scan_lds, &ngroups);
+        if (tid < RADIX) {
+            drec[tid] = make_uint4(A, gb, o | (pending << 8) | (left << 16), dbase);
+            gstart[tid] = gb;
+            spanq[tid] = span;
+        }
+        if (tid == 0) gstart[RADIX] = ngroups;
+        __syncthreads();
+        // ---- keys and values into the stage in sorted order; granule -> digit table ----
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t d = digit_of(key[j], shift, dmask);
+            if (full || (e0 + j * WAVE) < valid) {
+                const uint32_t p = pos[j] + drec[d].w + my_hist[d];
+                stage_k[p] = key[j];
+                stage_v[p] = val[j];
+            }
+        }
+        // the registers are free again: fetch the next tile now, its latency hides behind the stores
+        if (PREFETCH && t + 1 < tiles_per_wg && base + TILE < n) load_tile(base + TILE);
+        for (uint32_t g = tid; g < ngroups; g += THREADS) {
+            // last digit whose first granule index is <= g (digits without granules share a start)
+            uint32_t lo = 0, hi = RADIX;
+#pragma unroll
+            for (int it = 0; it < RADIX_BITS; ++it) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (gstart[mid] <= g) lo = mid; else hi = mid;
+            }
+            group_digit[g] = (uint8_t)lo;
+        }
+        __syncthreads();
+        // ---- store whole granules: 16 consecutive lanes = one 128-B key line + one 64-B value block ----
+        for (uint32_t idx = tid; idx < ngroups * WC_GR; idx += THREADS) {
+            const uint32_t g = idx / WC_GR, k = idx % WC_GR;
+            const uint32_t d = group_digit[g];
+            const uint4 r = drec[d];
+            const uint32_t tt = (g - r.y) * WC_GR + k;
+            const uint32_t od = r.z & 255u, pd = (r.z >> 8) & 255u;
+            if (tt >= od) {
+                const uint32_t q = tt - od;                      // index in the digit's stream
+                if (q < spanq[d]) {
+                    const uint32_t gp = r.x + tt;
+                    if (q < pd) { keys_out[gp] = carry_k[d * WC_GR + q]; vals_out[gp] = carry_v[d * WC_GR + q]; }
+                    else { const uint32_t sidx = r.w + q - pd; keys_out[gp] = stage_k[sidx]; vals_out[gp] = stage_v[sidx]; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- new carry: the stream elements behind the stored span ----
+        for (int i = tid; i < RADIX * WC_GR; i += THREADS) {
+            const uint32_t d = (uint32_t)i / WC_GR, k = (uint32_t)i % WC_GR;
+            const uint4 r = drec[d];
+            const uint32_t pd = (r.z >> 8) & 255u, lf = (r.z >> 16) & 255u;
+            const uint32_t sp = spanq[d];
+            if (k < lf) {
+                const uint32_t q = sp ? sp + k : k;
+                if (q >= pd) { const uint32_t sidx = r.w + q - pd; carry_k[i] = stage_k[sidx]; carry_v[i] = stage_v[sidx]; }
+            }
+        }
+        if (tid < RADIX) { cur[tid] = c1; wr[tid] = w1; }
+        __syncthreads();
+    }
+    // ---- flush what is left in the carries (at most 15 elements per digit) ----
+    for (int i = tid; i < RADIX * WC_GR; i += THREADS) {
+        const uint32_t d = (uint32_t)i / WC_GR, k = (uint32_t)i % WC_GR;
+        const uint32_t w0 = wr[d], pend = cur[d] - w0;
+        if (k < pend) { keys_out[w0 + k] = carry_k[i]; vals_out[w0 + k] = carry_v[i]; }
     }
 }
 
@@ -520,12 +752,12 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict_
     if (threadIdx.x == 0) *out_total = tot;
 }
 
-template <bool FIRST, bool WRITE_SA>
+template <bool FIRST, bool WRITE_SA, bool SPARSE>
 __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ V, const uint32_t *__restrict__ U, int64_t m,
     const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_head, uint32_t *__restrict__ SA,
     uint32_t *__restrict__ ISA, uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo,
-    uint32_t n_text)
+    uint32_t n_text, uint32_t *__restrict__ has_isa)
 {
     __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
     const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
@@ -557,7 +789,10 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         if (i < m) {
             if ((f.head >> r) & 1u) run = slot[r] + 1u;
             if (WRITE_SA && slot[r] < n_text) SA[slot[r]] = v[r];
-            if (v[r] < n_text) ISA[v[r]] = run;
+            if (v[r] < n_text) {
+                ISA[v[r]] = run;
+                if (SPARSE) atomicOr(&has_isa[v[r] >> 5], 1u << (v[r] & 31u));   // this rank overrides the initial one
+            }
             if ((f.tied >> r) & 1u) { Uo[off] = slot[r]; Go[off] = run - 1u; Vo[off] = v[r]; ++off; }
         }
     }
@@ -582,6 +817,45 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_key2(const uint32_t *__re
         const uint32_t v = V[j];
         const int64_t p = (int64_t)v + h;
         const uint64_t key2 = (p < n) ? (uint64_t)n + (uint64_t)ISA[p] : (uint64_t)(n - 1 - (int64_t)v);
+        keys[j] = ((uint64_t)G[j] << key2_bits) | key2;
+    }
+}
+
+// Sparse variant (few tied suffixes after the initial sort, e.g. DNA: 2 of 2^30): no ISA is built.
+// A suffix that has been in the tied list has its current rank in ISA (has_isa bit set, written by
+// k_rr_apply); every other suffix still has the rank the initial sort gave it, which is recovered by
+// a binary search of its packed key in the sorted initial keys: rank = lower_bound + 1 = (slot of
+// its group head) + 1, the same value the dense scatter would have stored.
+__global__ __launch_bounds__(GK_THREADS) void k_gather_key2_sparse(
+    const uint32_t *__restrict__ V, const uint32_t *__restrict__ G, const uint32_t *__restrict__ ISA,
+    const uint32_t *__restrict__ has_isa, const uint64_t *__restrict__ sorted_keys, const uint8_t *__restrict__ T,
+    KeyParams P, int64_t m, int64_t n, int64_t h, int key2_bits, uint64_t *__restrict__ keys)
+{
+    __shared__ uint8_t lcode[256];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * GK_THREADS;
+    for (int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x; j < m; j += stride) {
+        const uint32_t v = V[j];
+        const int64_t p = (int64_t)v + h;
+        uint64_t key2;
+        if (p >= n) {
+            key2 = (uint64_t)(n - 1 - (int64_t)v);
+        } else if ((has_isa[p >> 5] >> (p & 31)) & 1u) {
+            key2 = (uint64_t)n + (uint64_t)ISA[p];
+        } else {
+            uint64_t kq = 0;
+            for (int i = 0; i < P.k; ++i) {
+                const int64_t pos = p + i;
+                kq = (kq << P.bits) | (uint64_t)(pos < n ? lcode[T[pos]] : (uint8_t)0);
+            }
+            int64_t lo = 0, hi = n;                      // first slot whose key is >= kq
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (sorted_keys[mid] < kq) lo = mid + 1; else hi = mid;
+            }
+            key2 = (uint64_t)n + (uint64_t)lo + 1u;
+        }
         keys[j] = ((uint64_t)G[j] << key2_bits) | key2;
     }
 }

@@ -154,6 +154,39 @@ def test_degenerate_large_runs(oracle):
         assert np.array_equal(build(s), oracle.sais(s))
 
 
+def _planted(n, seed, copies):
+    rng = np.random.default_rng(seed)
+    s = corpus.uniform(n, seed).copy()
+    for _ in range(copies):
+        ln = int(rng.integers(20, max(21, min(3000, n // (160 * copies)))))
+        src = int(rng.integers(0, n - ln)); dst = int(rng.integers(0, n - ln))
+        s[dst:dst + ln] = s[src:src + ln]
+    return s
+
+
+@pytest.mark.parametrize("n,copies", [(300_000, 1), (1 << 20, 5), (3_000_001, 40)])
+def test_sparse_refinement_mode(oracle, monkeypatch, n, copies):
+    """few tied suffixes after the initial sort: ranks come from a binary search in the sorted keys
+    (no ISA); must agree with the dense mode and the oracle"""
+    s = _planted(n, n, copies)
+    exp = oracle.sais(s)
+    assert np.array_equal(build(s), exp)
+    st = sa.last_stats()
+    assert st["sparse_mode"] == 1 and st["rounds"] >= 1 and 0 < st["unresolved_after_initial"] <= n // 64
+    monkeypatch.setenv("SA_AMD_FORCE_DENSE", "1")
+    assert np.array_equal(build(s), exp)
+    assert sa.last_stats()["sparse_mode"] == 0
+
+
+def test_sparse_mode_with_tail_and_runs(oracle):
+    # tied suffixes that run into the end of the text, and a long run inside otherwise random bytes
+    s = corpus.uniform(400_000, 9).copy()
+    s[-50:] = s[1000:1050]
+    s[200_000:200_700] = 7
+    assert np.array_equal(build(s), oracle.sais(s))
+    assert sa.last_stats()["sparse_mode"] == 1
+
+
 # ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------
 
 @pytest.mark.parametrize("name", ["c2_uniform_64m", "c3_english_256m"])
