@@ -103,21 +103,21 @@ static const SortVariant sort_variants[] = {
     { 512, 8, 4, k_radix_downsweep<512, 8, 8>, "512x8 <=64 vgpr" },
     { 256, 12, 4, k_radix_downsweep<256, 12, 4>, "256x12 <=128 vgpr" },
     { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 1>, "1024x8 ABLATION sequential stores (wrong results)" },
-    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 2>, "1024x8 ABLATION no ballot matching (wrong results)" },
-    { 1024, 16, 1, k_radix_downsweep<1024, 16, 4>, "1024x16 <=128 vgpr" },
-    { 1024, 12, 1, k_radix_downsweep<1024, 12, 4>, "1024x12 <=128 vgpr" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 33>, "1024x8 ABLATION no ranking + sequential stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 16>, "1024x8 ABLATION no stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 49>, "1024x8 ABLATION no ranking, no stores (wrong results)" },
     { 512, 16, 1, k_radix_downsweep<512, 16, 2, 1>, "512x16 ABLATION sequential stores" },
     { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 4>, "1024x8 nt loads" },
     { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 8>, "1024x8 nt stores" },
     { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 12>, "1024x8 nt loads+stores" },
     { 1024, 8, 1, k_radix_downsweep<1024, 8, 8, 0>, "1024x8, 256 workgroups" },
-    { 512, 12, 1, k_radix_downsweep_wc<512, 12, false>, "write-combined 512x12" },
-    { 512, 12, 1, k_radix_downsweep_wc<512, 12, true>, "write-combined 512x12 prefetch" },
-    { 512, 8, 1, k_radix_downsweep_wc<512, 8, true>, "write-combined 512x8 prefetch" },
-    { 1024, 4, 1, k_radix_downsweep_wc<1024, 4, true>, "write-combined 1024x4 prefetch" },
-    { 1024, 6, 1, k_radix_downsweep_wc<1024, 6, true>, "write-combined 1024x6 prefetch" },
+    { 512, 12, 1, k_radix_downsweep_wc<512, 12>, "write-combined 512x12" },
+    { 512, 16, 1, k_radix_downsweep_wc<512, 16>, "write-combined 512x16" },
+    { 512, 16, 1, k_radix_downsweep_wc<512, 16, 16>, "write-combined 512x16 ABLATION no stores" },
+    { 512, 8, 1, k_radix_downsweep_wc<512, 8>, "write-combined 512x8" },
+    { 256, 16, 1, k_radix_downsweep_wc<256, 16>, "write-combined 256x16" },
 };
-constexpr int SORT_DEFAULT_VARIANT = 0;
+constexpr int SORT_DEFAULT_VARIANT = 4;
 static const SortVariant &sort_variant()
 {
     static int v = -1;
@@ -201,8 +201,16 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
         const uint32_t dmask = (1u << nb) - 1u;
         const bool last = shift + RADIX_BITS >= end_bit;
         uint32_t *vdst = (last && final_vals) ? final_vals : vout;
-        PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.G), dim3(SORT_THREADS), 0, st, kin, spine,
-                                                       count, shift, dmask, g.tiles_per_wg * g.tile, g.G));
+        {
+            const int64_t chunk = g.tiles_per_wg * g.tile;
+            int split = 2048 / g.G;
+            if (split < 1) split = 1;
+            while (split > 1 && chunk / split < 4096) split /= 2;
+            const int64_t sub = (ceil_div(chunk, split) + 1) & ~(int64_t)1;
+            if (split > 1) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * g.G * 4, st));
+            PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.G * split), dim3(SORT_THREADS), 0, st, kin, spine,
+                                                           count, shift, dmask, chunk, g.G, split, sub));
+        }
         PROF(KC_SPINE, (int64_t)RADIX * g.G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st,
                                                                     spine, digit_tot, g.G));
         PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((sv.fn), dim3(g.G), dim3(sv.threads), 0, st,
@@ -290,6 +298,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     HIP_TRY(hipStreamSynchronize(st));
     int64_t m = m32;
     local.unresolved_after_initial = m;
+    if (getenv("SA_AMD_TIMING_ONLY_INITIAL_SORT")) m = 0;   // ablation builds produce wrong orders; stop here
     // few tied suffixes: do not build the ISA (n random writes); ranks of untouched suffixes are
     // looked up in the sorted initial keys instead (k_gather_key2_sparse)
     const bool sparse = m > 0 && m <= n / SPARSE_DIV && !getenv("SA_AMD_FORCE_DENSE");

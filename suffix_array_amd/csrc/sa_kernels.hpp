@@ -229,37 +229,53 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, uint32_t d
 __global__ __launch_bounds__(SORT_THREADS) void k_radix_upsweep(const uint64_t *__restrict__ keys,
                                                                  uint32_t *__restrict__ counts, int64_t n,
                                                                  int shift, uint32_t dmask,
-                                                                 int64_t chunk_elems, int G)
+                                                                 int64_t chunk_elems, int G, int split,
+                                                                 int64_t sub_elems)
 {
     __shared__ uint32_t h[SORT_WAVES][RADIX];
     for (int i = threadIdx.x; i < SORT_WAVES * RADIX; i += SORT_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
     uint32_t *mine = h[wave_id()];
-    const int64_t begin = (int64_t)blockIdx.x * chunk_elems;
-    int64_t end = begin + chunk_elems;
-    if (end > n) end = n;
-    // two keys (16 B) per lane per step; chunk_elems is a multiple of the tile size so the pairs are aligned
+    // `split` workgroups share one downsweep chunk (more waves in flight for the streaming read);
+    // sub_elems is even, so every part starts 16-byte aligned
+    const int g = (int)(blockIdx.x / split), part = (int)(blockIdx.x % split);
+    const int64_t cbegin = (int64_t)g * chunk_elems;
+    int64_t cend = cbegin + chunk_elems;
+    if (cend > n) cend = n;
+    int64_t begin = cbegin + (int64_t)part * sub_elems;
+    int64_t end = begin + sub_elems;
+    if (begin > cend) begin = cend;
+    if (end > cend || part == split - 1) end = cend;
+    // two keys (16 B) per lane per load, four loads in flight per lane; chunk_elems is a multiple of
+    // the tile size so the pairs are 16-byte aligned
     const int64_t npair = (end - begin) / 2;
     const ulonglong2 *K2 = (const ulonglong2 *)(keys + begin);
-    for (int64_t i = threadIdx.x; i < npair; i += SORT_THREADS) {
-        ulonglong2 q = K2[i];
+    auto count2 = [&](const ulonglong2 &q) {
         const uint32_t d0 = digit_of(q.x, shift, dmask), d1 = digit_of(q.y, shift, dmask);
         // constant digits (all-equal high bits) would serialise the LDS atomic 64 ways
         const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d0);
-        const uint32_t active = (uint32_t)__popcll(__ballot(1));   // evaluated by every active lane
+        const uint64_t act = __ballot(1);                          // evaluated by every active lane
         if (__all(d0 == f && d1 == f)) {
-            if (lane_id() == 0) atomicAdd(&mine[f], 2u * active);
+            // the lowest ACTIVE lane adds for the wave (lane 0 may have left the loop already)
+            if (lane_id() == __ffsll((unsigned long long)act) - 1) atomicAdd(&mine[f], 2u * (uint32_t)__popcll(act));
         } else {
             atomicAdd(&mine[d0], 1u);
             atomicAdd(&mine[d1], 1u);
         }
+    };
+    int64_t i = threadIdx.x;
+    for (; i + 3 * SORT_THREADS < npair; i += 4 * SORT_THREADS) {
+        const ulonglong2 q0 = K2[i], q1 = K2[i + SORT_THREADS], q2 = K2[i + 2 * SORT_THREADS], q3 = K2[i + 3 * SORT_THREADS];
+        count2(q0); count2(q1); count2(q2); count2(q3);
     }
+    for (; i < npair; i += SORT_THREADS) count2(K2[i]);
     if (((end - begin) & 1) && threadIdx.x == 0) atomicAdd(&mine[digit_of(keys[end - 1], shift, dmask)], 1u);
     __syncthreads();
     uint32_t s = 0;
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) s += h[w][threadIdx.x];
-    counts[(int64_t)threadIdx.x * G + blockIdx.x] = s;
+    if (split == 1) counts[(int64_t)threadIdx.x * G + g] = s;
+    else if (s) atomicAdd(&counts[(int64_t)threadIdx.x * G + g], s);     // counts zeroed by the host
 }
 
 // exclusive scan, in place, of `total` u32 counters by ONE workgroup (digit-major order)
@@ -331,12 +347,7 @@ __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ keys_in, 
     for (int j = 0; j < ITEMS; ++j) {
         const bool ok = FULL || (e0 + j * WAVE) < valid;
         const uint32_t d = digit_of(key[j], shift, dmask);
-        if (ABLATE == 2) {   // timing-only build: no ballot matching (every lane pretends to be alone)
-            const uint32_t prior = my_hist[d];
-            if (ok) my_hist[d] = prior + 1;
-            pos[j] = prior;
-            continue;
-        }
+        if (ABLATE & 32) { pos[j] = (uint32_t)(e0 + j * WAVE); continue; }   // timing-only: no ranking at all
         uint32_t xlo = 0, xhi = 0;
         if (!FULL) { const uint64_t okm = __ballot(ok); xlo = ~(uint32_t)okm; xhi = ~(uint32_t)(okm >> 32); }
 #pragma unroll
@@ -380,7 +391,7 @@ __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ keys_in, 
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint32_t d = digit_of(key[j], shift, dmask);
-        pos[j] += digit_base[d] + my_hist[d];
+        if (!(ABLATE & 32)) pos[j] += digit_base[d] + my_hist[d];
         if (FULL || (e0 + j * WAVE) < valid) lds_kv[pos[j]] = key[j];
     }
     __syncthreads();
@@ -393,7 +404,8 @@ __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ keys_in, 
             const uint64_t kx = lds_kv[idx];
             const uint32_t d = digit_of(kx, shift, dmask);
             dpack[j >> 2] |= d << (8 * (j & 3));
-            if (ABLATE == 1) keys_out[base + idx] = kx;   // timing-only build: sequential instead of scattered stores
+            if ((ABLATE & 16) && kx != 0x0123456789abcdefULL) continue;   // timing-only build: no stores
+            if (ABLATE & 1) keys_out[base + idx] = kx;   // timing-only build: sequential instead of scattered stores
             else if (ABLATE & 8) __builtin_nontemporal_store(kx, keys_out + (run_off[d] + ((uint32_t)idx - digit_base[d])));
             else keys_out[run_off[d] + ((uint32_t)idx - digit_base[d])] = kx;
         }
@@ -409,7 +421,8 @@ __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ keys_in, 
         const int idx = tid + j * THREADS;
         if (FULL || idx < valid) {
             const uint32_t d = (dpack[j >> 2] >> (8 * (j & 3))) & 255u;
-            if (ABLATE == 1) vals_out[base + idx] = lds_v[idx];
+            if ((ABLATE & 16) && lds_v[idx] != 0x01234567u) continue;
+            if (ABLATE & 1) vals_out[base + idx] = lds_v[idx];
             else if (ABLATE & 8) __builtin_nontemporal_store(lds_v[idx], vals_out + (run_off[d] + ((uint32_t)idx - digit_base[d])));
             else vals_out[run_off[d] + ((uint32_t)idx - digit_base[d])] = lds_v[idx];
         }
@@ -475,7 +488,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep(
 // ------------------------------------------------------------------------------------------
 constexpr int WC_GR = 16;   // granule, elements
 
-template <int THREADS, int ITEMS, bool PREFETCH>
+template <int THREADS, int ITEMS, int ABLATE = 0>
 __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
@@ -486,30 +499,26 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
     constexpr int WAVE_ELEMS = WAVE * ITEMS;
     constexpr int MAXGROUPS = TILE / WC_GR + RADIX;
     static_assert(THREADS >= RADIX, "one thread per digit is assumed");
+    static_assert(TILE < (1 << 14), "carry record packs a 14-bit stage index");
     __shared__ __attribute__((aligned(16))) uint64_t stage_k[TILE];
     __shared__ __attribute__((aligned(16))) uint64_t carry_k[RADIX * WC_GR];
     __shared__ __attribute__((aligned(16))) uint32_t stage_v[TILE];
     __shared__ __attribute__((aligned(16))) uint32_t carry_v[RADIX * WC_GR];
     __shared__ uint32_t wave_hist[NWAVES][RADIX];
-    __shared__ __attribute__((aligned(16))) uint4 drec[RADIX];     // per digit: {A, gbase, o | pending << 8 | left << 16, digit_base}
+    __shared__ __attribute__((aligned(16))) uint4 drec[RADIX];     // {A, first granule, o | pending << 8, digit_base}
+    __shared__ uint32_t crec[RADIX];                                // carry copy: src0 | dst0 << 14 | count << 18
     __shared__ uint32_t gstart[RADIX + 1];                          // exclusive scan of the granule counts
-    __shared__ uint32_t spanq[RADIX];                               // span (stream elements stored this tile)
-    __shared__ uint32_t cur[RADIX], wr[RADIX];
     __shared__ uint8_t group_digit[MAXGROUPS];
     __shared__ uint32_t scan_lds[NWAVES + 1];
 
     const int tid = threadIdx.x, l = lane_id(), w = wave_id();
+    uint32_t c0 = 0, w0 = 0;          // thread d: next global position of digit d / everything below is stored
     {
         uint32_t all;
         const uint32_t t = tid < RADIX ? digit_tot[tid] : 0u;
         const uint32_t gbase = block_excl_sum<THREADS>(t, scan_lds, &all);
-        if (tid < RADIX) {
-            const uint32_t s0 = gbase + spine[(int64_t)tid * G + blockIdx.x];
-            cur[tid] = s0;
-            wr[tid] = s0;
-        }
+        if (tid < RADIX) c0 = w0 = gbase + spine[(int64_t)tid * G + blockIdx.x];
     }
-    __syncthreads();
     uint32_t *my_hist = wave_hist[w];
     const int e0 = w * WAVE_ELEMS + l;
     const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
@@ -525,16 +534,21 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
             val[j] = in ? vals_in[tb + e] : 0u;
         }
     };
-    if (PREFETCH && tile0 * TILE < n) load_tile(tile0 * TILE);
+    if (tile0 * TILE < n) load_tile(tile0 * TILE);
     for (int64_t t = 0; t < tiles_per_wg; ++t) {
         const int64_t base = (tile0 + t) * TILE;
         if (base >= n) break;
         const int valid = (n - base) >= TILE ? TILE : (int)(n - base);
         const bool full = valid == TILE;
         uint32_t pos[ITEMS];
-        if (!PREFETCH) load_tile(base);
         for (int i = tid; i < NWAVES * RADIX; i += THREADS) (&wave_hist[0][0])[i] = 0;
         __syncthreads();
+        // Ranking.  For every item the lanes holding the same digit are found with 8 ballots (~x is the
+        // match mask).  The lowest matching lane adds the group size to the wave's LDS counter of that
+        // digit with ONE returning LDS atomic; a wave's LDS operations execute in issue order, so the
+        // counters see the items in tile order although all ITEMS atomics are in flight together.  The
+        // returned prior count is handed to the other lanes of the group by a shuffle afterwards.
+        uint32_t prior[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const bool ok = full || (e0 + j * WAVE) < valid;
@@ -550,10 +564,17 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
             }
             const uint32_t mlo = ~xlo, mhi = ~xhi;
             const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-            const uint32_t prior = my_hist[d];
-            if (ok && below == 0) my_hist[d] = prior + (uint32_t)(__popc(mlo) + __popc(mhi));
-            pos[j] = prior + below;
-            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t leader = mlo ? (uint32_t)__builtin_ctz(mlo) : 32u + (uint32_t)__builtin_ctz(mhi | 0x80000000u);
+            pos[j] = below | (leader << 8);
+            prior[j] = 0;
+            if (ok && below == 0)
+                prior[j] = __hip_atomic_fetch_add(&my_hist[d], (uint32_t)(__popc(mlo) + __popc(mhi)), __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t p = (uint32_t)__shfl((int)prior[j], (int)(pos[j] >> 8), WAVE);
+            pos[j] = p + (pos[j] & 255u);
         }
         __syncthreads();
         // ---- per-digit bookkeeping (thread d) ----
@@ -568,25 +589,28 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
         }
         uint32_t tile_total;
         const uint32_t dbase = block_excl_sum<THREADS>(tot, scan_lds, &tile_total);
-        uint32_t ng = 0, A = 0, o = 0, pending = 0, span = 0, left = 0, c1 = 0, w1 = 0;
+        uint32_t ng = 0, A = 0, o = 0, pending = 0, c1 = 0, w1 = 0, cr = 0;
         if (tid < RADIX) {
-            const uint32_t c0 = cur[tid], w0 = wr[tid];
             pending = c0 - w0;
             c1 = c0 + tot;
             const uint32_t fl = c1 & ~(uint32_t)(WC_GR - 1);
             w1 = fl > w0 ? fl : w0;
-            span = w1 - w0;
+            const uint32_t span = w1 - w0;
             A = w0 & ~(uint32_t)(WC_GR - 1);
             o = w0 - A;
             ng = span ? (w1 - A) / WC_GR : 0u;
-            left = c1 - w1;
+            // what stays behind: stage[src0 + k] -> carry[dst0 + k], k < count
+            if (span) cr = (dbase + span - pending) | (0u << 14) | ((c1 - w1) << 18);
+            else cr = dbase | (pending << 14) | (tot << 18);
         }
         uint32_t ngroups;
         const uint32_t gb = block_excl_sum<THREADS>(ng, scan_lds, &ngroups);
         if (tid < RADIX) {
-            drec[tid] = make_uint4(A, gb, o | (pending << 8) | (left << 16), dbase);
+            drec[tid] = make_uint4(A, gb, o | (pending << 8), dbase);
+            crec[tid] = cr;
             gstart[tid] = gb;
-            spanq[tid] = span;
+            c0 = c1;
+            w0 = w1;
         }
         if (tid == 0) gstart[RADIX] = ngroups;
         __syncthreads();
@@ -601,7 +625,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
             }
         }
         // the registers are free again: fetch the next tile now, its latency hides behind the stores
-        if (PREFETCH && t + 1 < tiles_per_wg && base + TILE < n) load_tile(base + TILE);
+        if (t + 1 < tiles_per_wg && base + TILE < n) load_tile(base + TILE);
         for (uint32_t g = tid; g < ngroups; g += THREADS) {
             // last digit whose first granule index is <= g (digits without granules share a start)
             uint32_t lo = 0, hi = RADIX;
@@ -614,41 +638,70 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
         }
         __syncthreads();
         // ---- store whole granules: 16 consecutive lanes = one 128-B key line + one 64-B value block ----
-        for (uint32_t idx = tid; idx < ngroups * WC_GR; idx += THREADS) {
-            const uint32_t g = idx / WC_GR, k = idx % WC_GR;
-            const uint32_t d = group_digit[g];
-            const uint4 r = drec[d];
-            const uint32_t tt = (g - r.y) * WC_GR + k;
-            const uint32_t od = r.z & 255u, pd = (r.z >> 8) & 255u;
-            if (tt >= od) {
-                const uint32_t q = tt - od;                      // index in the digit's stream
-                if (q < spanq[d]) {
-                    const uint32_t gp = r.x + tt;
-                    if (q < pd) { keys_out[gp] = carry_k[d * WC_GR + q]; vals_out[gp] = carry_v[d * WC_GR + q]; }
-                    else { const uint32_t sidx = r.w + q - pd; keys_out[gp] = stage_k[sidx]; vals_out[gp] = stage_v[sidx]; }
+        // (four output slots per thread and step so that the dependent LDS reads of the slots overlap)
+        {
+            const uint32_t total = ngroups * WC_GR;
+            for (uint32_t idx0 = tid; idx0 < total; idx0 += 4 * THREADS) {
+                uint32_t gp[4], sidx[4];
+                bool live[4], from_carry[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t idx = idx0 + u * THREADS;
+                    const bool in = idx < total;
+                    const uint32_t g = in ? idx / WC_GR : 0u, k = idx % WC_GR;
+                    const uint32_t d = group_digit[g];
+                    const uint4 r = drec[d];
+                    const uint32_t tt = (g - r.y) * WC_GR + k;
+                    const uint32_t od = r.z & 255u, pd = r.z >> 8;
+                    const uint32_t q = tt - od;                      // index in the digit's stream
+                    live[u] = in && tt >= od;
+                    from_carry[u] = q < pd;
+                    gp[u] = r.x + tt;
+                    sidx[u] = from_carry[u] ? d * WC_GR + q : r.w + q - pd;
+                    if (!live[u]) { sidx[u] = 0; from_carry[u] = false; }
+                }
+                uint64_t kx[4]; uint32_t vx[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    kx[u] = from_carry[u] ? carry_k[sidx[u]] : stage_k[sidx[u]];
+                    vx[u] = from_carry[u] ? carry_v[sidx[u]] : stage_v[sidx[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if ((ABLATE & 16) && gp[u] != 0x7fffffffu) continue;      // timing-only build: no stores
+                    if (live[u]) { keys_out[gp[u]] = kx[u]; vals_out[gp[u]] = vx[u]; }
                 }
             }
         }
         __syncthreads();
         // ---- new carry: the stream elements behind the stored span ----
-        for (int i = tid; i < RADIX * WC_GR; i += THREADS) {
-            const uint32_t d = (uint32_t)i / WC_GR, k = (uint32_t)i % WC_GR;
-            const uint4 r = drec[d];
-            const uint32_t pd = (r.z >> 8) & 255u, lf = (r.z >> 16) & 255u;
-            const uint32_t sp = spanq[d];
-            if (k < lf) {
-                const uint32_t q = sp ? sp + k : k;
-                if (q >= pd) { const uint32_t sidx = r.w + q - pd; carry_k[i] = stage_k[sidx]; carry_v[i] = stage_v[sidx]; }
+        {
+            constexpr int STEPS = RADIX * WC_GR / THREADS;
+            uint64_t ck[STEPS]; uint32_t cv[STEPS], dst[STEPS];
+            bool mv[STEPS];
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)u * THREADS;
+                const uint32_t d = i / WC_GR, k = i % WC_GR;
+                const uint32_t c = crec[d];
+                mv[u] = k < (c >> 18);
+                const uint32_t src = mv[u] ? (c & 0x3fffu) + k : 0u;
+                dst[u] = d * WC_GR + ((c >> 14) & 15u) + k;
+                ck[u] = stage_k[src];
+                cv[u] = stage_v[src];
             }
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u)
+                if (mv[u]) { carry_k[dst[u]] = ck[u]; carry_v[dst[u]] = cv[u]; }
         }
-        if (tid < RADIX) { cur[tid] = c1; wr[tid] = w1; }
         __syncthreads();
     }
     // ---- flush what is left in the carries (at most 15 elements per digit) ----
+    if (tid < RADIX) { drec[tid].x = w0; drec[tid].y = c0 - w0; }
+    __syncthreads();
     for (int i = tid; i < RADIX * WC_GR; i += THREADS) {
         const uint32_t d = (uint32_t)i / WC_GR, k = (uint32_t)i % WC_GR;
-        const uint32_t w0 = wr[d], pend = cur[d] - w0;
-        if (k < pend) { keys_out[w0 + k] = carry_k[i]; vals_out[w0 + k] = carry_v[i]; }
+        if (k < drec[d].y) { keys_out[drec[d].x + k] = carry_k[i]; vals_out[drec[d].x + k] = carry_v[i]; }
     }
 }
 
