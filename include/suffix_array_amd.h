@@ -66,7 +66,7 @@ int32_t sa_amd_saca_batch(const uint8_t *const *T, uint32_t *const *SA, const in
 
 typedef struct sa_amd_stats {
     int32_t sigma;            /* distinct byte values in T */
-    int32_t bits_per_symbol;  /* packed code width */
+    int32_t bits_per_symbol;  /* packed code width when sigma is a power of two, 0 = base-sigma packing */
     int32_t symbols_per_key;  /* symbols in the initial 64-bit key */
     int32_t rounds;           /* prefix-doubling refinement rounds after the initial sort */
     int32_t sort_passes;      /* 8-bit radix passes executed in total */

@@ -12,13 +12,30 @@ import numpy as np
 
 
 def alphabet(text: np.ndarray):
-    """code table (256 entries), bits per symbol, symbols per 64-bit key."""
+    """code table (256 entries), bits per symbol (0 = base-sigma packing), symbols per key, radix"""
     used = np.zeros(256, dtype=bool)
     used[text] = True
     sigma = int(used.sum())
     code = np.cumsum(used) - 1
-    bits = max(1, int(np.ceil(np.log2(max(sigma, 2)))))
-    return code.astype(np.uint64), bits, 64 // bits
+    se = max(sigma, 2)
+    if se & (se - 1) == 0:
+        bits = se.bit_length() - 1
+        return code.astype(np.uint64), bits, 64 // bits, se
+    k = 0
+    while se ** (k + 1) <= 2 ** 64:
+        k += 1
+    return code.astype(np.uint64), 0, k, se
+
+
+def pack_keys(text: np.ndarray):
+    """initial key of every suffix: k symbol codes, most significant first, zero codes past the end"""
+    n = text.size
+    code, bits, k, se = alphabet(text)
+    sym = np.concatenate([code[text], np.zeros(k, dtype=np.uint64)])
+    key = np.zeros(n, dtype=np.uint64)
+    for j in range(k):
+        key = ((key << np.uint64(bits)) | sym[j:j + n]) if bits else (key * np.uint64(se) + sym[j:j + n])
+    return key, bits, k
 
 
 def build(text_bytes: bytes, max_rounds: int = 64, stats: dict | None = None) -> np.ndarray:
@@ -28,12 +45,7 @@ def build(text_bytes: bytes, max_rounds: int = 64, stats: dict | None = None) ->
     out[0] = n
     if n == 0:
         return out
-    code, bits, k = alphabet(t)
-    # initial keys: k symbols, MSB first, zero padding past the end of the text
-    sym = np.concatenate([code[t], np.zeros(k, dtype=np.uint64)])
-    key = np.zeros(n, dtype=np.uint64)
-    for j in range(k):
-        key = (key << np.uint64(bits)) | sym[j:j + n] if bits < 64 else sym[j:j + n]
+    key, bits, k = pack_keys(t)
     sa = np.argsort(key, kind="stable").astype(np.int64)
     skey = key[sa]
     head = np.ones(n, dtype=bool)

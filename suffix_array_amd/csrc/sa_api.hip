@@ -44,10 +44,10 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
 enum KClass { KC_BYTE_HIST = 0, KC_BUILD_KEYS, KC_UPSWEEP, KC_SPINE, KC_DOWNSWEEP, KC_RR_COUNT, KC_RR_SCAN, KC_RR_APPLY,
-              KC_GATHER, KC_MISC, KC_COUNT };
+              KC_GATHER, KC_SCATTER, KC_MISC, KC_COUNT };
 static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys", "k_radix_upsweep", "k_spine_rows",
                                                     "k_radix_downsweep", "k_rr_count", "k_rr_scan", "k_rr_apply",
-                                                    "k_gather_key2", "misc" };
+                                                    "k_gather_key2", "k_scatter_pairs", "misc" };
 struct Profiler {
     bool on = false;
     struct Rec { int cls; hipEvent_t a, b; int64_t units; };
@@ -227,20 +227,61 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
     return SA_AMD_OK;
 }
 
-static void make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out)
+// symbol codes and key geometry from the sigma = 256 histogram; returns the number of key bits to sort
+static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out)
 {
     int sigma = 0;
     for (int c = 0; c < 256; ++c) {
         if (hist[c]) P->code[c] = (uint8_t)sigma++;
         else P->code[c] = 0;
     }
-    int bits = bit_length((uint64_t)(sigma > 1 ? sigma - 1 : 1));
-    if (bits < 1) bits = 1;
-    P->bits = bits;
-    P->k = 64 / bits;
-    const int used = P->k * bits;
-    P->mask = used >= 64 ? ~0ull : ((1ull << used) - 1ull);
     *sigma_out = sigma;
+    const uint64_t se = sigma > 2 ? (uint64_t)sigma : 2u;      // effective radix (a unary text still needs one bit)
+    P->sigma = se;
+    if ((se & (se - 1)) == 0) {                                // power of two: plain bit fields
+        const int bits = bit_length(se - 1);
+        P->bits = bits;
+        P->k = 64 / bits;
+        const int used = P->k * bits;
+        P->mask = used >= 64 ? ~0ull : ((1ull << used) - 1ull);
+        P->top = 0;
+        return used;
+    }
+    // otherwise pack as a base-sigma number: the largest k with sigma^k <= 2^64
+    unsigned __int128 pw = 1;
+    int k = 0;
+    while (pw * se <= ((unsigned __int128)1 << 64)) { pw *= se; ++k; }
+    P->bits = 0;
+    P->k = k;
+    P->mask = ~0ull;
+    uint64_t top = 1;
+    for (int i = 0; i + 1 < k; ++i) top *= se;
+    P->top = top;
+    const unsigned __int128 maxkey = pw - 1;                   // fits in 64 bits
+    return bit_length((uint64_t)maxkey);
+}
+
+// binned ISA update pays off once the ISA is far larger than the caches and there is enough to write
+static bool binned(int64_t n, int64_t count)
+{
+    if (getenv("SA_AMD_NO_BINNED_ISA")) return false;
+    if (getenv("SA_AMD_BINNED_ISA_ALWAYS")) return count > 0;      // tests: exercise the path at small sizes
+    return n >= ((int64_t)1 << 25) && count >= ((int64_t)1 << 22);
+}
+
+// (suffix, rank) pairs -> one radix pass on the top 8 bits of the suffix position -> windowed scatter
+static int scatter_binned(uint64_t *pk, uint32_t *pv, uint64_t *altk, uint32_t *altv, int64_t count, int64_t n,
+                          const Workspace &w, hipStream_t st, sa_amd_stats *local)
+{
+    const int nb = bit_length((uint64_t)(n - 1));
+    const int shift = nb > RADIX_BITS ? nb - RADIX_BITS : 0;
+    SortResult pr;
+    int rc = sort_pairs(pk, pv, altk, altv, count, shift, shift + RADIX_BITS, w.spine, w.digit_tot, nullptr, st, &pr);
+    if (rc) return rc;
+    local->sort_passes += pr.passes; local->sorted_elements += (int64_t)pr.passes * count;
+    PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_pairs), dim3((unsigned)ceil_div(count, 1024)), dim3(256), 0, st,
+                                                   (const uint64_t *)pr.keys, (const uint32_t *)pr.vals, w.isa, count, (uint32_t)n));
+    return SA_AMD_OK;
 }
 
 static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWork, int64_t work_bytes, hipStream_t st,
@@ -272,14 +313,14 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     HIP_TRY(hipStreamSynchronize(st));
     KeyParams P;
     int sigma;
-    make_key_params(hist, &P, &sigma);
+    const int key_bits = make_key_params(hist, &P, &sigma);
     local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
 
     // 2. packed keys, 3. initial sort
     PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P, w.keysA,
                        w.valsA));
     SortResult sr;
-    int rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, P.k * P.bits, w.spine, w.digit_tot, SA, st, &sr);
+    int rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr);
     if (rc) return rc;
     local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
     if (sr.vals != SA) {   // n == 1: no pass ran, the values are still in the input buffer
@@ -310,14 +351,24 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         rkA = other;
         rkB = other + (((size_t)n / 2 + 1) & ~(size_t)1);
         HIP_TRY(hipMemsetAsync(w.has_isa, 0, ((size_t)n + 31) / 32 * 4, st));
-        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                    SA, w.isa, Ucur, Gcur, Vcur, 0u, w.has_isa));
+                                                    SA, w.isa, Ucur, Gcur, Vcur, 0u, w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr));
     } else if (m > 0) {
         // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
-        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                    sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                    SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr));
+        if (binned(n, n)) {
+            uint64_t *pk = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1));
+            rc = scatter_binned(pk, w.U1, sr.keys, w.G1, n, n, w, st, &local);
+            if (rc) return rc;
+        } else {
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0,
+                                                        (uint64_t *)nullptr, (uint32_t *)nullptr));
+        }
     }
 
     // 5. prefix doubling on the tied suffixes only
@@ -344,14 +395,24 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, Ucur, m, w.tcnt,
                            w.thead));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-        if (sparse)
-            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+        if (sparse) {
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, w.has_isa));
-        else
-            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr));
+        } else if (binned(n, m)) {
+            // Gcur has been consumed by the gather, the other key buffer by nothing: they take the pairs
+            uint64_t *pk = (sr.keys == rkA) ? rkB : rkA;
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, (uint32_t *)nullptr));
+                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur));
+            rc = scatter_binned(pk, Gcur, sr.keys, sr.vals, m, n, w, st, &local);
+            if (rc) return rc;
+        } else {
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, (uint64_t *)nullptr,
+                                                        (uint32_t *)nullptr));
+        }
         HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         m = m32;

@@ -144,9 +144,11 @@ constexpr int KB_HALO = 64 + 8;                  // k <= 64 symbols, +8 so the h
 
 struct KeyParams {
     uint8_t code[256];
-    int32_t bits;
-    int32_t k;
-    uint64_t mask;
+    int32_t bits;      // > 0: sigma is a power of two, symbols are `bits`-wide fields (shift/or path)
+    int32_t k;         // symbols per key
+    uint64_t mask;     // shift path: the k * bits low bits
+    uint64_t sigma;    // multiply path (bits == 0): key = sum code_i * sigma^(k-1-i), an order-preserving
+    uint64_t top;      //   base-sigma number; top = sigma^(k-1).  sigma = 56 packs 11 symbols, not 10.
 };
 
 __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__restrict__ T, int64_t n,
@@ -180,15 +182,27 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
     __syncthreads();
     const int p0 = tid * KB_ITEMS;
     const int k = P.k, bits = P.bits;
-    const uint64_t mask = P.mask;
-    uint64_t key = 0;
-    for (int j = 0; j < k; ++j) key = (key << bits) | (uint64_t)c[p0 + j];
     uint64_t kk[KB_ITEMS];
-    kk[0] = key;
+    if (bits > 0) {
+        const uint64_t mask = P.mask;
+        uint64_t key = 0;
+        for (int j = 0; j < k; ++j) key = (key << bits) | (uint64_t)c[p0 + j];
+        kk[0] = key;
 #pragma unroll
-    for (int r = 1; r < KB_ITEMS; ++r) {
-        key = ((key << bits) | (uint64_t)c[p0 + k - 1 + r]) & mask;
-        kk[r] = key;
+        for (int r = 1; r < KB_ITEMS; ++r) {
+            key = ((key << bits) | (uint64_t)c[p0 + k - 1 + r]) & mask;
+            kk[r] = key;
+        }
+    } else {
+        const uint64_t sigma = P.sigma, top = P.top;
+        uint64_t key = 0;
+        for (int j = 0; j < k; ++j) key = key * sigma + (uint64_t)c[p0 + j];
+        kk[0] = key;
+#pragma unroll
+        for (int r = 1; r < KB_ITEMS; ++r) {
+            key = (key - (uint64_t)c[p0 + r - 1] * top) * sigma + (uint64_t)c[p0 + k - 1 + r];
+            kk[r] = key;
+        }
     }
     const int64_t g0 = base + p0;
     if (g0 + KB_ITEMS <= n) {
@@ -805,22 +819,32 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict_
     if (threadIdx.x == 0) *out_total = tot;
 }
 
-template <bool FIRST, bool WRITE_SA, bool SPARSE>
+// ISA_MODE: 0 = scatter ISA[suffix] = rank directly, 1 = the same plus the has_isa bitmap (sparse
+// refinement), 2 = write (suffix, rank) pairs in slot order; the host bins them by suffix position
+// with one radix pass and k_scatter_pairs then writes the ISA window by window (a random 4-byte
+// store costs a whole 64-byte memory transaction, a binned one is merged in the caches).
+template <bool FIRST, bool WRITE_SA, int ISA_MODE>
 __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ V, const uint32_t *__restrict__ U, int64_t m,
     const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_head, uint32_t *__restrict__ SA,
     uint32_t *__restrict__ ISA, uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo,
-    uint32_t n_text, uint32_t *__restrict__ has_isa)
+    uint32_t n_text, uint32_t *__restrict__ has_isa, int g_shift, uint64_t *__restrict__ pair_k,
+    uint32_t *__restrict__ pair_v)
 {
+    constexpr bool SPARSE = ISA_MODE == 1;
     __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
     const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
     const RRFlags f = rr_classify(keys, m, idx0);
-    uint32_t slot[RR_ITEMS], v[RR_ITEMS];
+    uint32_t slot[RR_ITEMS], v[RR_ITEMS], oldrank[RR_ITEMS];
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
         const int64_t i = idx0 + r;
-        if (i < m) { slot[r] = FIRST ? (uint32_t)i : U[i]; v[r] = V[i]; }
-        else { slot[r] = 0; v[r] = 0; }
+        if (i < m) {
+            slot[r] = FIRST ? (uint32_t)i : U[i];
+            v[r] = V[i];
+            // refinement rounds: the key's high part is the old group head, i.e. the rank already in ISA
+            oldrank[r] = (FIRST || SPARSE) ? 0u : (uint32_t)(keys[i] >> g_shift) + 1u;
+        } else { slot[r] = 0; v[r] = 0; oldrank[r] = 0; }
     }
     // group-head slot (+1): running max over (head ? slot + 1 : 0), seeded by the tiles before
     uint32_t lasthead = 0;
@@ -842,7 +866,10 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         if (i < m) {
             if ((f.head >> r) & 1u) run = slot[r] + 1u;
             if (WRITE_SA && slot[r] < n_text) SA[slot[r]] = v[r];
-            if (v[r] < n_text) {
+            if (ISA_MODE == 2) {
+                pair_k[i] = (uint64_t)v[r];
+                pair_v[i] = run;
+            } else if (v[r] < n_text && run != oldrank[r]) {     // the first subgroup of a split group keeps its rank
                 ISA[v[r]] = run;
                 if (SPARSE) atomicOr(&has_isa[v[r] >> 5], 1u << (v[r] & 31u));   // this rank overrides the initial one
             }
@@ -900,7 +927,8 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_key2_sparse(
             uint64_t kq = 0;
             for (int i = 0; i < P.k; ++i) {
                 const int64_t pos = p + i;
-                kq = (kq << P.bits) | (uint64_t)(pos < n ? lcode[T[pos]] : (uint8_t)0);
+                const uint64_t cs = (uint64_t)(pos < n ? lcode[T[pos]] : (uint8_t)0);
+                kq = P.bits > 0 ? ((kq << P.bits) | cs) : (kq * P.sigma + cs);
             }
             int64_t lo = 0, hi = n;                      // first slot whose key is >= kq
             while (lo < hi) {
@@ -910,6 +938,22 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_key2_sparse(
             key2 = (uint64_t)n + (uint64_t)lo + 1u;
         }
         keys[j] = ((uint64_t)G[j] << key2_bits) | key2;
+    }
+}
+
+// ISA[suffix] = rank for pairs that one radix pass has binned by suffix position: consecutive
+// pairs fall into the same few-MiB window of the ISA, so the stores merge in L2 / Infinity Cache.
+__global__ __launch_bounds__(256) void k_scatter_pairs(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pv,
+                                                        uint32_t *__restrict__ ISA, int64_t count, uint32_t n_text)
+{
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + r;
+        if (i < count) {
+            const uint32_t v = (uint32_t)pk[i];
+            if (v < n_text) ISA[v] = pv[i];
+        }
     }
 }
 

@@ -63,12 +63,8 @@ def test_build_keys(gen, n):
     keys = np.zeros(n, dtype=np.uint64)
     bits, k = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
     assert sa.lib().sa_amd_test_build_keys(text.ctypes.data, n, keys.ctypes.data, bits.ctypes.data, k.ctypes.data) == 0
-    code, ebits, ek = pd_model.alphabet(text)
+    exp, ebits, ek = pd_model.pack_keys(text)
     assert (int(bits[0]), int(k[0])) == (ebits, ek)
-    sym = np.concatenate([code[text], np.zeros(ek, dtype=np.uint64)])
-    exp = np.zeros(n, dtype=np.uint64)
-    for j in range(ek):
-        exp = (exp << np.uint64(ebits)) | sym[j:j + n]
     assert np.array_equal(keys, exp)
 
 
@@ -185,6 +181,21 @@ def test_sparse_mode_with_tail_and_runs(oracle):
     s[200_000:200_700] = 7
     assert np.array_equal(build(s), oracle.sais(s))
     assert sa.last_stats()["sparse_mode"] == 1
+
+
+@pytest.mark.parametrize("gen,n,seed", [("english", 300_000, 3), ("dna_repeats", 1 << 20, 5), ("periodic", 200_001, 1)])
+def test_binned_isa_update_path(oracle, monkeypatch, gen, n, seed):
+    """the (suffix, rank) pairs + one radix pass + windowed scatter form of the ISA update (used for
+    large texts) forced on at small sizes; must give the same array as the direct scatter"""
+    text = np.resize(np.frombuffer(b"abcab", dtype=np.uint8), n) if gen == "periodic" else getattr(corpus, gen)(n, seed)
+    exp = oracle.sais(text)
+    monkeypatch.setenv("SA_AMD_BINNED_ISA_ALWAYS", "1")
+    monkeypatch.setenv("SA_AMD_FORCE_DENSE", "1")
+    assert np.array_equal(build(text), exp)
+    assert sa.last_stats()["rounds"] >= 1
+    monkeypatch.delenv("SA_AMD_BINNED_ISA_ALWAYS")
+    monkeypatch.setenv("SA_AMD_NO_BINNED_ISA", "1")
+    assert np.array_equal(build(text), exp)
 
 
 # ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------
