@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DOMINANT = "k_radix_downsweep"
 # algorithmic bytes per unit (element) of each kernel class, DESIGN.md section 3
 ALGO_BYTES = {"k_byte_hist": 1, "k_build_keys": 13, "k_radix_upsweep": 8, "k_radix_downsweep": 24,
-              "k_rr_count": 8, "k_rr_apply": 24, "k_gather_key2": 20}
+              "k_rr_count": 8, "k_rr_apply": 24, "k_gather_key2": 20, "k_scatter_pairs": 16}
 
 
 def parse():
@@ -155,6 +155,13 @@ def main():
                                if L.sa_amd_profile_kernel_name(i).decode() == dom][0]
     avg_ms = d_ms / max(d_launch, 1)
     achieved = (ALGO_BYTES[dom] * d_units) / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
+    # HBM traffic of the dominant kernel from the committed PMC passes of this same command (if any)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("workload") == args.workload and tj.get("n_bytes") == n and dom in tj.get("kernels", {}):
+            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
     per_step = dt / args.steps
     device_ms = sum(ms[i] for i in range(ncls)) / args.steps
     job_gbs = (5 * n + 4) / per_step / 1e9
@@ -176,7 +183,8 @@ def main():
                    "symbols_per_key": stats.symbols_per_key, "doubling_rounds": stats.rounds,
                    "radix_passes": stats.sort_passes, "unresolved_after_initial_sort": stats.unresolved_after_initial},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": round(ALGO_BYTES[dom] * d_units / max(d_launch, 1)),
                      "algorithmic_bytes_per_element": ALGO_BYTES[dom], "avg_launch_ms": round(avg_ms, 4),
                      "launches_per_step": d_launch / args.steps,
                      "whole_job": {"algorithmic_bytes": 5 * n + 4, "achieved": round(job_gbs, 3),
