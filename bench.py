@@ -87,12 +87,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal on a one-GPU box: SA_BENCH_SHARE_GPU=1 puts every rank on device 0 and uses gloo for the
+    # control plane (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank + nccl
+    share = os.environ.get("SA_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
+    ctl_dev = dev
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+            ctl_dev = torch.device("cpu")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     # ---- synthetic input, resident in HBM before the timed region ----
     text_h = corpus.workload(args.workload, rank=rank, n_override=args.n)
@@ -129,7 +138,7 @@ def main():
     units = (ctypes.c_int64 * cap)()
     ncls = L.sa_amd_profile_end(ms, launches, units, cap)
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -193,7 +202,7 @@ def main():
         "device_ms_per_step": round(device_ms, 3),
         "verified": verified,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(text_h, min(args.cpu_sample, n))
     else:
         result["cpu_baseline"] = None

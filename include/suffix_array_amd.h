@@ -31,6 +31,7 @@ extern "C" {
 #define SA_AMD_EHIP       (-3)   /* HIP runtime error (launch, copy, sync) */
 #define SA_AMD_ENODEVICE  (-4)   /* no HIP device visible */
 #define SA_AMD_EINTERNAL  (-5)   /* refinement did not converge (cannot happen for valid input) */
+#define SA_AMD_ERANGE     (-6)   /* check_integrity: an entry exceeds n (the reference panics, src/sa.rs:77-78) */
 
 /* reference src/saca.rs:6  `pub const MAX_LENGTH: usize = std::i32::MAX as usize;` */
 #define SA_AMD_MAX_LENGTH 2147483647
@@ -95,6 +96,30 @@ int32_t sa_amd_device_count(void);
 
 const char *sa_amd_strerror(int32_t code);
 const char *sa_amd_version(void);
+
+/* ---- next rows, on either side of the construction path ----
+ *
+ * Bucket table of `enable_buckets` (reference src/sa.rs:89-119): 256 * 257 + 1 = 65 793 entries in the
+ * layout of src/sa.rs:94; bkt[i] = exclusive right edge of bucket i inside the SA (what the reference
+ * gets by counting bigrams, src/sa.rs:100-108, and prefix-summing, src/sa.rs:112-116).  Here it is
+ * read off the finished suffix array with one binary search per bucket.
+ */
+#define SA_AMD_BUCKET_TABLE_LEN 65793
+/* T: n bytes, SA: n + 1 entries (a valid suffix array of T), bkt: 65 793 entries; host buffers */
+int32_t sa_amd_bucket_table(const uint8_t *T, int32_t n, const uint32_t *SA, uint32_t *bkt);
+/* SuffixArray::new followed by enable_buckets in one device round trip (text and SA stay in HBM) */
+int32_t sa_amd_saca_u8_buckets(const uint8_t *T, uint32_t *SA, int32_t n, uint32_t *bkt);
+int32_t sa_amd_bucket_table_device(const uint8_t *dT, const uint32_t *dSA, int32_t n, uint32_t *dBkt, void *stream);
+
+/*
+ * `check_integrity` (reference src/sa.rs:72-84), the validation behind `from_parts` and every
+ * `load*` (src/sa.rs:57-64, :293-361), in linear time: returns 1 (true), 0 (false; also when
+ * sa_len != n + 1, src/sa.rs:73-75), SA_AMD_ERANGE when an entry exceeds n (the reference panics
+ * on the slice index there), or another negative status.  dWork: 4 * (n + 1) + 256 bytes.
+ */
+int32_t sa_amd_check_integrity(const uint8_t *T, int32_t n, const uint32_t *SA, int64_t sa_len);
+int32_t sa_amd_check_integrity_device(const uint8_t *dT, int32_t n, const uint32_t *dSA, void *dWork,
+                                      int64_t work_bytes, void *stream);
 
 /* ---- per-kernel timing (HIP events on the launch stream), per calling thread ----
  * begin() zeroes and enables the counters for builds issued by this thread; end() disables them and

@@ -20,7 +20,7 @@ from typing import Optional
 import numpy as np
 
 __all__ = ["MAX_LENGTH", "saca", "SuffixArray", "SuffixArrayError", "lib", "library_path", "Stats",
-           "saca_batch", "workspace_bytes", "saca_device_ptr"]
+           "saca_batch", "workspace_bytes", "saca_device_ptr", "bucket_table", "check_integrity", "last_stats"]
 
 #: reference src/saca.rs:6
 MAX_LENGTH = 2**31 - 1
@@ -76,6 +76,12 @@ def lib() -> ctypes.CDLL:
         L.sa_amd_saca_device.restype = ctypes.c_int32
         L.sa_amd_device_count.restype = ctypes.c_int32
         L.sa_amd_last_stats.argtypes = [c_vp]
+        L.sa_amd_bucket_table.argtypes = [c_vp, ctypes.c_int32, c_vp, c_vp]
+        L.sa_amd_bucket_table.restype = ctypes.c_int32
+        L.sa_amd_saca_u8_buckets.argtypes = [c_vp, c_vp, ctypes.c_int32, c_vp]
+        L.sa_amd_saca_u8_buckets.restype = ctypes.c_int32
+        L.sa_amd_check_integrity.argtypes = [c_vp, ctypes.c_int32, c_vp, ctypes.c_int64]
+        L.sa_amd_check_integrity.restype = ctypes.c_int32
         L.sa_amd_last_stats.restype = None
         L.sa_amd_strerror.argtypes = [ctypes.c_int32]
         L.sa_amd_strerror.restype = ctypes.c_char_p
@@ -150,6 +156,33 @@ def last_stats() -> dict:
     return st.as_dict()
 
 
+BUCKET_TABLE_LEN = 256 * 257 + 1        # reference src/sa.rs:95
+
+
+def bucket_table(s, sa: np.ndarray) -> np.ndarray:
+    """the table `enable_buckets` builds (reference src/sa.rs:89-119), computed on the GPU from the
+    text and its suffix array"""
+    t = _as_u8(s)
+    a = np.ascontiguousarray(sa, dtype=np.uint32)
+    assert a.size == t.size + 1
+    bkt = np.empty(BUCKET_TABLE_LEN, dtype=np.uint32)
+    _check(lib().sa_amd_bucket_table(t.ctypes.data, t.size, a.ctypes.data, bkt.ctypes.data))
+    return bkt
+
+
+def check_integrity(s, sa: np.ndarray) -> bool:
+    """`check_integrity` (reference src/sa.rs:72-84) on the GPU; raises IndexError where the
+    reference panics (an entry beyond the text)"""
+    t = _as_u8(s)
+    a = np.ascontiguousarray(sa, dtype=np.uint32)
+    rc = lib().sa_amd_check_integrity(t.ctypes.data, t.size, a.ctypes.data, a.size)
+    if rc == -6:
+        raise IndexError("suffix offset out of range (the reference panics here, src/sa.rs:77-78)")
+    if rc < 0:
+        _check(rc)
+    return rc == 1
+
+
 def workspace_bytes(n: int) -> int:
     return int(lib().sa_amd_workspace_bytes(n))
 
@@ -220,7 +253,11 @@ class SuffixArray:
     def from_parts(cls, s, sa) -> Optional["SuffixArray"]:
         """reference src/sa.rs:57-64: compose and check integrity; None when the check fails."""
         obj = cls.unchecked_from_parts(s, sa)
-        return obj if _check_integrity(obj._s, obj._sa) else None
+        if lib().sa_amd_device_count() > 0:
+            ok = check_integrity(obj._s, obj._sa)             # HIP kernels k_ci_scatter / k_ci_check
+        else:
+            ok = _check_integrity(obj._s, obj._sa)            # host glue when no device is visible
+        return obj if ok else None
 
     @classmethod
     def unchecked_from_parts(cls, s, sa) -> "SuffixArray":   # src/sa.rs:68-70
@@ -229,6 +266,14 @@ class SuffixArray:
         obj._sa = np.ascontiguousarray(sa, dtype=np.uint32)
         obj._bkt = None
         return obj
+
+    def enable_buckets(self) -> None:
+        """reference src/sa.rs:89-119; a no-op when the table exists (src/sa.rs:90-92)"""
+        if self._bkt is None:
+            self._bkt = bucket_table(self._s, self._sa)
+
+    def buckets(self) -> Optional[np.ndarray]:
+        return self._bkt
 
     def __array__(self, dtype=None):                   # From<SuffixArray> for Vec<u32>, src/sa.rs:364-368
         return self._sa if dtype is None else self._sa.astype(dtype)

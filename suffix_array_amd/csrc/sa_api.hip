@@ -5,6 +5,7 @@
 // There is deliberately no CPU fallback in this file: every entry point runs the HIP
 // kernels of sa_kernels.hpp or returns an error code.
 #include "sa_kernels.hpp"
+#include "sa_extras.hpp"
 #include "../../include/suffix_array_amd.h"
 
 #include <cstdio>
@@ -528,6 +529,90 @@ SA_EXPORT int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n
     return sa::build_device(dT, dSA, n, dWork, work_bytes, (hipStream_t)stream, stats);
 }
 
+// ---- next rows: bucket table and integrity check on the device-resident arrays ----
+
+SA_EXPORT int32_t sa_amd_bucket_table_device(const uint8_t *dT, const uint32_t *dSA, int32_t n, uint32_t *dBkt, void *stream)
+{
+    if (n < 0 || !dSA || !dBkt || (n > 0 && !dT)) return SA_AMD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sa::k_bucket_table, dim3((sa::BKT_LEN + 255) / 256), dim3(256), 0, st, dT, dSA, (int64_t)n, dBkt);
+    if (hipGetLastError() != hipSuccess) return SA_AMD_EHIP;
+    return hipStreamSynchronize(st) == hipSuccess ? SA_AMD_OK : SA_AMD_EHIP;
+}
+
+SA_EXPORT int32_t sa_amd_check_integrity_device(const uint8_t *dT, int32_t n, const uint32_t *dSA, void *dWork,
+                                                int64_t work_bytes, void *stream)
+{
+    if (n < 0 || !dSA || !dWork || (n > 0 && !dT)) return SA_AMD_EINVAL;
+    if (work_bytes < ((int64_t)n + 1) * 4 + 256) return SA_AMD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *flags = (uint32_t *)dWork;
+    uint32_t *rank = (uint32_t *)((char *)dWork + 256);
+    if (hipMemsetAsync(flags, 0, 4, st) != hipSuccess) return SA_AMD_EHIP;
+    int64_t blocks = ((int64_t)n + 1 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(sa::k_ci_scatter, dim3((unsigned)blocks), dim3(256), 0, st, dSA, (int64_t)n, rank, flags);
+    hipLaunchKernelGGL(sa::k_ci_check, dim3((unsigned)blocks), dim3(256), 0, st, dT, dSA, (int64_t)n, (const uint32_t *)rank, flags);
+    if (hipGetLastError() != hipSuccess) return SA_AMD_EHIP;
+    uint32_t f = 0;
+    if (hipMemcpyAsync(&f, flags, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return SA_AMD_EHIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return SA_AMD_EHIP;
+    if (f & 1u) return SA_AMD_ERANGE;
+    return (f & 2u) ? 0 : 1;
+}
+
+// host buffers; which = 1: bucket table, 2: integrity check, 3: build SA (into SA, n + 1 entries) then bucket table
+static int32_t extras_host(const uint8_t *T, int32_t n, uint32_t *SA, int64_t sa_len, uint32_t *bkt, int which)
+{
+    using namespace sa;
+    if (n < 0 || !SA || (n > 0 && !T)) return SA_AMD_EINVAL;
+    if (sa_amd_device_count() <= 0) return SA_AMD_ENODEVICE;
+    if (which == 2 && sa_len != (int64_t)n + 1) return 0;          // reference src/sa.rs:73-75: false
+    uint8_t *dT = nullptr; uint32_t *dSA = nullptr, *dB = nullptr; void *dW = nullptr;
+    int32_t rc = SA_AMD_OK;
+    const size_t N = (size_t)n;
+    auto cleanup = [&]() { if (dT) (void)hipFree(dT); if (dSA) (void)hipFree(dSA); if (dB) (void)hipFree(dB); if (dW) (void)hipFree(dW); };
+    auto hrc = [&](hipError_t e) { return e == hipSuccess ? SA_AMD_OK : (e == hipErrorOutOfMemory ? SA_AMD_ENOMEM : SA_AMD_EHIP); };
+    if ((rc = hrc(hipMalloc((void **)&dT, N ? N : 1)))) { cleanup(); return rc; }
+    if ((rc = hrc(hipMalloc((void **)&dSA, (N + 1) * 4)))) { cleanup(); return rc; }
+    if (N && (rc = hrc(hipMemcpy(dT, T, N, hipMemcpyHostToDevice)))) { cleanup(); return rc; }
+    if (which == 3) {
+        const int64_t wb = sa_amd_workspace_bytes(n);
+        if ((rc = hrc(hipMalloc(&dW, (size_t)wb)))) { cleanup(); return rc; }
+        rc = build_device(dT, dSA, n, dW, wb, nullptr, nullptr);
+        if (rc == SA_AMD_OK) rc = hrc(hipMemcpy(SA, dSA, (N + 1) * 4, hipMemcpyDeviceToHost));
+        if (rc) { cleanup(); return rc; }
+    } else if ((rc = hrc(hipMemcpy(dSA, SA, (N + 1) * 4, hipMemcpyHostToDevice)))) { cleanup(); return rc; }
+    if (which == 1 || which == 3) {
+        if ((rc = hrc(hipMalloc((void **)&dB, (size_t)BKT_LEN * 4)))) { cleanup(); return rc; }
+        rc = sa_amd_bucket_table_device(dT, dSA, n, dB, nullptr);
+        if (rc == SA_AMD_OK) rc = hrc(hipMemcpy(bkt, dB, (size_t)BKT_LEN * 4, hipMemcpyDeviceToHost));
+    } else {
+        const int64_t wb = ((int64_t)n + 1) * 4 + 256;
+        if ((rc = hrc(hipMalloc(&dW, (size_t)wb)))) { cleanup(); return rc; }
+        rc = sa_amd_check_integrity_device(dT, n, dSA, dW, wb, nullptr);
+    }
+    cleanup();
+    return rc;
+}
+
+SA_EXPORT int32_t sa_amd_bucket_table(const uint8_t *T, int32_t n, const uint32_t *SA, uint32_t *bkt)
+{
+    if (!bkt) return SA_AMD_EINVAL;
+    return extras_host(T, n, (uint32_t *)SA, (int64_t)n + 1, bkt, 1);
+}
+
+SA_EXPORT int32_t sa_amd_saca_u8_buckets(const uint8_t *T, uint32_t *SA, int32_t n, uint32_t *bkt)
+{
+    if (!bkt) return SA_AMD_EINVAL;
+    return extras_host(T, n, SA, (int64_t)n + 1, bkt, 3);
+}
+
+SA_EXPORT int32_t sa_amd_check_integrity(const uint8_t *T, int32_t n, const uint32_t *SA, int64_t sa_len)
+{
+    return extras_host(T, n, (uint32_t *)SA, sa_len, nullptr, 2);
+}
+
 SA_EXPORT void sa_amd_last_stats(sa_amd_stats *out)
 {
     if (out) *out = sa::g_last_stats;
@@ -549,6 +634,7 @@ SA_EXPORT const char *sa_amd_strerror(int32_t code)
     case SA_AMD_EHIP: return "HIP runtime error";
     case SA_AMD_ENODEVICE: return "no HIP device";
     case SA_AMD_EINTERNAL: return "internal error: refinement did not converge";
+    case SA_AMD_ERANGE: return "suffix offset out of range";
     default: return "unknown error";
     }
 }

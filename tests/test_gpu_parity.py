@@ -208,3 +208,72 @@ def test_full_size_configs(oracle, name):
     assert oracle.verify(text, arr) == 1          # linear-time form of reference src/sa.rs:72-84
     if text.size <= (64 << 20):
         assert np.array_equal(arr, oracle.sais(text))
+
+
+# ---- next rows: bucket table and integrity check --------------------------------
+
+def _texts_for_extras():
+    cases = {k: v for k, v in adversarial_cases().items() if len(v) < 3000}
+    cases["english_200k"] = corpus.english(200_000, 3).tobytes()
+    cases["uniform_300k"] = corpus.uniform(300_001, 2).tobytes()
+    cases["dna_100k"] = corpus.dna(100_000, 4).tobytes()
+    return cases
+
+
+def test_bucket_table_matches_reference_restatement(oracle):
+    """reference src/sa.rs:89-119 restated in oracle_bucket_table (bigram counts + prefix sum)"""
+    for name, s in _texts_for_extras().items():
+        arr = oracle.sais(s)
+        got = sa.bucket_table(s, arr)
+        assert got.size == 256 * 257 + 1
+        assert np.array_equal(got, oracle.bucket_table(s)), name
+
+
+def test_enable_buckets_on_constructed_array(oracle):
+    s = b"splendid splendor"
+    obj = sa.SuffixArray(s)
+    assert obj.buckets() is None
+    obj.enable_buckets()
+    bkt = obj.buckets()
+    idx = ord("s") * 257 + (ord("p") + 1) + 1                       # sub-bucket (c0, c1), reference src/sa.rs:130
+    arr = obj.into_parts()[1]
+    assert sorted(int(p) for p in arr[bkt[idx - 1]:bkt[idx]]) == [0, 9]   # doc-test of reference src/lib.rs:28-29
+    assert np.array_equal(bkt, oracle.bucket_table(s))
+
+
+def test_saca_with_buckets_single_round_trip(oracle):
+    t = corpus.english(150_000, 8)
+    arr = np.zeros(t.size + 1, dtype=np.uint32)
+    bkt = np.zeros(256 * 257 + 1, dtype=np.uint32)
+    assert sa.lib().sa_amd_saca_u8_buckets(t.ctypes.data, arr.ctypes.data, t.size, bkt.ctypes.data) == 0
+    assert np.array_equal(arr, oracle.sais(t)) and np.array_equal(bkt, oracle.bucket_table(t))
+
+
+def test_check_integrity_matches_reference_restatement(oracle):
+    """reference src/sa.rs:72-84 restated literally in oracle_check_integrity"""
+    rng = np.random.default_rng(5)
+    for name, s in _texts_for_extras().items():
+        good = oracle.sais(s)
+        assert sa.check_integrity(s, good) is True, name
+        n = len(s)
+        if n >= 2:
+            for _ in range(4):
+                bad = good.copy()
+                i, j = rng.integers(0, n + 1, 2)
+                bad[i], bad[j] = bad[j], bad[i]
+                assert sa.check_integrity(s, bad) == (oracle.check_integrity(s, bad) == 1), name
+            dup = good.copy(); dup[n // 2] = dup[n // 2 + 1]
+            assert sa.check_integrity(s, dup) is False
+            assert sa.check_integrity(s, good[:-1]) is False               # src/sa.rs:73-75
+            oob = good.copy(); oob[1] = n + 7
+            assert oracle.check_integrity(s, oob) == -1
+            with pytest.raises(IndexError):
+                sa.check_integrity(s, oob)
+
+
+def test_from_parts_uses_gpu_check(oracle):
+    s = corpus.english(50_000, 4)
+    good = oracle.sais(s)
+    assert sa.SuffixArray.from_parts(s, good) is not None
+    bad = good.copy(); bad[100], bad[101] = bad[101], bad[100]
+    assert sa.SuffixArray.from_parts(s, bad) is None
