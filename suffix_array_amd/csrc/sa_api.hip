@@ -117,8 +117,12 @@ static const SortVariant sort_variants[] = {
     { 512, 16, 1, k_radix_downsweep_wc<512, 16, 16>, "write-combined 512x16 ABLATION no stores" },
     { 512, 8, 1, k_radix_downsweep_wc<512, 8>, "write-combined 512x8" },
     { 256, 16, 1, k_radix_downsweep_wc<256, 16>, "write-combined 256x16" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8" },
+    { 512, 16, 1, k_radix_downsweep_wcl<512, 16>, "carry-completed lines 512x16" },
+    { 1024, 8, 1, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8, 256 workgroups" },
+    { 1024, 8, 4, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8, 1024 workgroups" },
 };
-constexpr int SORT_DEFAULT_VARIANT = 4;
+constexpr int SORT_DEFAULT_VARIANT = 22;
 static const SortVariant &sort_variant()
 {
     static int v = -1;

@@ -720,6 +720,183 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
 }
 
 // ------------------------------------------------------------------------------------------
+// k_radix_downsweep_wcl: the plain tile scatter of k_radix_downsweep plus a per-digit LDS carry, so
+// that every 128-byte line a tile touches is completed by that same tile (within microseconds,
+// from one CU) instead of by the workgroup's next tile (tens of microseconds later, after the
+// 4 MiB L2 of the XCD has been swept several times).  Per digit d the workgroup keeps
+//   c0[d]  next global position,  w0[d]  everything below is stored (16-aligned after the first
+//   tile);  carry[d][0 .. c0-w0)  the elements in between (< 16).
+// Tile: new elements of digit d would go to [c0, c0+cnt).  Only positions below
+// w1 = max(w0, (c0+cnt) & ~15) are stored now -- first the old carry ([w0, c0), loop A), then the
+// tile's own elements -- and the rest lands in the carry at index (position - w1).
+// ------------------------------------------------------------------------------------------
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
+    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
+    int64_t n, int shift, uint32_t dmask, int64_t tiles_per_wg, int G)
+{
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int NWAVES = THREADS / WAVE;
+    constexpr int WAVE_ELEMS = WAVE * ITEMS;
+    constexpr int CSTEPS = RADIX * WC_GR / THREADS;
+    static_assert(THREADS >= RADIX && (RADIX * WC_GR) % THREADS == 0, "thread / digit mapping");
+    static_assert(ITEMS % 4 == 0, "digits are packed four to a register");
+    __shared__ __attribute__((aligned(16))) uint64_t lds_kv[TILE];
+    __shared__ __attribute__((aligned(16))) uint64_t carry_k[RADIX * WC_GR];
+    __shared__ __attribute__((aligned(16))) uint32_t carry_v[RADIX * WC_GR];
+    __shared__ uint32_t wave_hist[NWAVES][RADIX];
+    __shared__ uint32_t digit_base[RADIX];     // first stage slot of digit d
+    __shared__ uint32_t goff[RADIX];           // c0 - digit_base: global position = goff + stage slot
+    __shared__ uint32_t wlim[RADIX];           // w1: positions below are stored by this tile
+    __shared__ uint32_t aold[RADIX];           // w0 | pending << 28 is too narrow -> w0 only; pending in apnd
+    __shared__ uint32_t apnd[RADIX];           // old carry elements to flush this tile (0 when nothing is stored)
+    __shared__ uint32_t scan_lds[NWAVES + 1];
+
+    const int tid = threadIdx.x, l = lane_id(), w = wave_id();
+    uint32_t c0 = 0, w0 = 0;
+    {
+        uint32_t all;
+        const uint32_t t = tid < RADIX ? digit_tot[tid] : 0u;
+        const uint32_t gbase = block_excl_sum<THREADS>(t, scan_lds, &all);
+        if (tid < RADIX) c0 = w0 = gbase + spine[(int64_t)tid * G + blockIdx.x];
+    }
+    uint32_t *my_hist = wave_hist[w];
+    uint32_t *lds_v = (uint32_t *)lds_kv;
+    const int e0 = w * WAVE_ELEMS + l;
+    const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
+    for (int64_t t = 0; t < tiles_per_wg; ++t) {
+        const int64_t base = (tile0 + t) * TILE;
+        if (base >= n) break;
+        const int valid = (n - base) >= TILE ? TILE : (int)(n - base);
+        const bool full = valid == TILE;
+        uint64_t key[ITEMS];
+        uint32_t pos[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int e = e0 + j * WAVE;
+            key[j] = (full || e < valid) ? keys_in[base + e] : ~0ull;
+        }
+        for (int i = tid; i < NWAVES * RADIX; i += THREADS) (&wave_hist[0][0])[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool ok = full || (e0 + j * WAVE) < valid;
+            const uint32_t d = digit_of(key[j], shift, dmask);
+            const uint64_t okm = __ballot(ok);
+            uint32_t xlo = ~(uint32_t)okm, xhi = ~(uint32_t)(okm >> 32);
+#pragma unroll
+            for (int b = 0; b < RADIX_BITS; ++b) {
+                const uint32_t sel = (uint32_t)((int32_t)(d << (31 - b)) >> 31);
+                const uint64_t bal = __ballot(sel != 0);
+                xlo |= (uint32_t)bal ^ sel;
+                xhi |= (uint32_t)(bal >> 32) ^ sel;
+            }
+            const uint32_t mlo = ~xlo, mhi = ~xhi;
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+            const uint32_t prior = my_hist[d];
+            if (ok && below == 0) my_hist[d] = prior + (uint32_t)(__popc(mlo) + __popc(mhi));
+            pos[j] = prior + below;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t val[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int e = e0 + j * WAVE;
+            val[j] = (full || e < valid) ? vals_in[base + e] : 0u;
+        }
+        __syncthreads();
+        // ---- thread d: per-wave offsets, digit totals, carry bookkeeping ----
+        uint32_t tot = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int ww = 0; ww < NWAVES; ++ww) {
+                const uint32_t cnt = wave_hist[ww][tid];
+                wave_hist[ww][tid] = tot;
+                tot += cnt;
+            }
+        }
+        uint32_t tile_total;
+        const uint32_t dbase = block_excl_sum<THREADS>(tot, scan_lds, &tile_total);
+        if (tid < RADIX) {
+            const uint32_t c1 = c0 + tot;
+            const uint32_t fl = c1 & ~(uint32_t)(WC_GR - 1);
+            const uint32_t w1 = fl > w0 ? fl : w0;
+            digit_base[tid] = dbase;
+            goff[tid] = c0 - dbase;
+            wlim[tid] = w1;
+            aold[tid] = w0;
+            apnd[tid] = w1 > w0 ? c0 - w0 : 0u;      // flush the old carry only when this tile stores something
+            c0 = c1;
+            w0 = w1;
+        }
+        __syncthreads();
+        // ---- keys: stage in sorted order ----
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t d = digit_of(key[j], shift, dmask);
+            pos[j] += digit_base[d] + my_hist[d];
+            if (full || (e0 + j * WAVE) < valid) lds_kv[pos[j]] = key[j];
+        }
+        // loop A (keys): the old carry of every digit that stores something goes out first
+#pragma unroll
+        for (int u = 0; u < CSTEPS; ++u) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)u * THREADS;
+            const uint32_t d = i / WC_GR, k = i % WC_GR;
+            if (k < apnd[d]) keys_out[aold[d] + k] = carry_k[i];
+        }
+        __syncthreads();
+        uint32_t dpack[ITEMS / 4];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int idx = tid + j * THREADS;
+            if ((j & 3) == 0) dpack[j >> 2] = 0;
+            if (full || idx < valid) {
+                const uint64_t kx = lds_kv[idx];
+                const uint32_t d = digit_of(kx, shift, dmask);
+                dpack[j >> 2] |= d << (8 * (j & 3));
+                const uint32_t gp = goff[d] + (uint32_t)idx, lim = wlim[d];
+                if (gp < lim) keys_out[gp] = kx;
+                else carry_k[d * WC_GR + (gp - lim)] = kx;
+            }
+        }
+        __syncthreads();
+        // ---- values: the same through the same stage ----
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (full || (e0 + j * WAVE) < valid) lds_v[pos[j]] = val[j];
+#pragma unroll
+        for (int u = 0; u < CSTEPS; ++u) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)u * THREADS;
+            const uint32_t d = i / WC_GR, k = i % WC_GR;
+            if (k < apnd[d]) vals_out[aold[d] + k] = carry_v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int idx = tid + j * THREADS;
+            if (full || idx < valid) {
+                const uint32_t d = (dpack[j >> 2] >> (8 * (j & 3))) & 255u;
+                const uint32_t gp = goff[d] + (uint32_t)idx, lim = wlim[d];
+                const uint32_t vx = lds_v[idx];
+                if (gp < lim) vals_out[gp] = vx;
+                else carry_v[d * WC_GR + (gp - lim)] = vx;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- flush what is left in the carries (at most 15 elements per digit) ----
+    if (tid < RADIX) { aold[tid] = w0; apnd[tid] = c0 - w0; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < CSTEPS; ++u) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)u * THREADS;
+        const uint32_t d = i / WC_GR, k = i % WC_GR;
+        if (k < apnd[d]) { keys_out[aold[d] + k] = carry_k[i]; vals_out[aold[d] + k] = carry_v[i]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Re-rank: m sorted (key, suffix) pairs sitting in slots U[0..m) of SA (FIRST: U[j] = j).
 // A group = maximal run of equal keys; its rank is (slot of its first element) + 1.
 //   k_rr_count : per tile, how many elements stay tied with a neighbour, and the last group
