@@ -358,21 +358,21 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         HIP_TRY(hipMemsetAsync(w.has_isa, 0, ((size_t)n + 31) / 32 * 4, st));
         PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                    SA, w.isa, Ucur, Gcur, Vcur, 0u, w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr));
+                                                    SA, w.isa, Ucur, Gcur, Vcur, 0u, w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total));
     } else if (m > 0) {
         // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
         if (binned(n, n)) {
             uint64_t *pk = (sr.keys == w.keysA) ? w.keysB : w.keysA;
             PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1));
+                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total));
             rc = scatter_binned(pk, w.U1, sr.keys, w.G1, n, n, w, st, &local);
             if (rc) return rc;
         } else {
             PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
                                                         SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0,
-                                                        (uint64_t *)nullptr, (uint32_t *)nullptr));
+                                                        (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total));
         }
     }
 
@@ -403,20 +403,20 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         if (sparse) {
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr));
+                                                        (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total));
         } else if (binned(n, m)) {
             // Gcur has been consumed by the gather, the other key buffer by nothing: they take the pairs
             uint64_t *pk = (sr.keys == rkA) ? rkB : rkA;
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur));
+                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total));
             rc = scatter_binned(pk, Gcur, sr.keys, sr.vals, m, n, w, st, &local);
             if (rc) return rc;
         } else {
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
                                                         (uint32_t)n, (uint32_t *)nullptr, key2_bits, (uint64_t *)nullptr,
-                                                        (uint32_t *)nullptr));
+                                                        (uint32_t *)nullptr, (const uint32_t *)w.total));
         }
         HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

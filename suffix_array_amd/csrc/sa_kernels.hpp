@@ -907,9 +907,9 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
 // Algorithmic traffic per element: 12 B read twice (keys + vals [+ 4 B slot]), 4 B SA write,
 // 4 B ISA scatter, 12 B per surviving element.
 // ------------------------------------------------------------------------------------------
-constexpr int RR_THREADS = 256;
+constexpr int RR_THREADS = 1024;
 constexpr int RR_ITEMS = 8;
-constexpr int RR_TILE = RR_THREADS * RR_ITEMS;   // 2048
+constexpr int RR_TILE = RR_THREADS * RR_ITEMS;   // 8192
 
 struct RRFlags {
     uint32_t head;   // bit r: element r starts a group
@@ -1006,10 +1006,16 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_head, uint32_t *__restrict__ SA,
     uint32_t *__restrict__ ISA, uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo,
     uint32_t n_text, uint32_t *__restrict__ has_isa, int g_shift, uint64_t *__restrict__ pair_k,
-    uint32_t *__restrict__ pair_v)
+    uint32_t *__restrict__ pair_v, const uint32_t *__restrict__ tile_total)
 {
     constexpr bool SPARSE = ISA_MODE == 1;
     __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
+    if (FIRST && !WRITE_SA && SPARSE) {
+        // compaction-only pass (no SA, no ISA write): a tile without tied suffixes has nothing to do
+        const uint32_t here = tile_cnt[blockIdx.x];
+        const uint32_t next = (blockIdx.x + 1 < gridDim.x) ? tile_cnt[blockIdx.x + 1] : *tile_total;
+        if (next == here) return;
+    }
     const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
     const RRFlags f = rr_classify(keys, m, idx0);
     uint32_t slot[RR_ITEMS], v[RR_ITEMS], oldrank[RR_ITEMS];
