@@ -121,6 +121,8 @@ static const SortVariant sort_variants[] = {
     { 512, 16, 1, k_radix_downsweep_wcl<512, 16>, "carry-completed lines 512x16" },
     { 1024, 8, 1, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8, 256 workgroups" },
     { 1024, 8, 4, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8, 1024 workgroups" },
+    { 1024, 12, 1, k_radix_downsweep_wcl<1024, 12>, "carry-completed lines 1024x12" },
+    { 512, 20, 1, k_radix_downsweep_wcl<512, 20>, "carry-completed lines 512x20" },
 };
 constexpr int SORT_DEFAULT_VARIANT = 22;
 static const SortVariant &sort_variant()

@@ -742,10 +742,11 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
     constexpr int CSTEPS = RADIX * WC_GR / THREADS;
     static_assert(THREADS >= RADIX && (RADIX * WC_GR) % THREADS == 0, "thread / digit mapping");
     static_assert(ITEMS % 4 == 0, "digits are packed four to a register");
+    static_assert(TILE < 65536, "16-bit tile-local counters");
     __shared__ __attribute__((aligned(16))) uint64_t lds_kv[TILE];
     __shared__ __attribute__((aligned(16))) uint64_t carry_k[RADIX * WC_GR];
     __shared__ __attribute__((aligned(16))) uint32_t carry_v[RADIX * WC_GR];
-    __shared__ uint32_t wave_hist[NWAVES][RADIX];
+    __shared__ uint16_t wave_hist[NWAVES][RADIX];   // a wave holds 64 * ITEMS <= 65535 elements, a tile < 65536
     __shared__ uint32_t digit_base[RADIX];     // first stage slot of digit d
     __shared__ uint32_t goff[RADIX];           // c0 - digit_base: global position = goff + stage slot
     __shared__ uint32_t wlim[RADIX];           // w1: positions below are stored by this tile
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
         const uint32_t gbase = block_excl_sum<THREADS>(t, scan_lds, &all);
         if (tid < RADIX) c0 = w0 = gbase + spine[(int64_t)tid * G + blockIdx.x];
     }
-    uint32_t *my_hist = wave_hist[w];
+    uint16_t *my_hist = wave_hist[w];
     uint32_t *lds_v = (uint32_t *)lds_kv;
     const int e0 = w * WAVE_ELEMS + l;
     const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
             const int e = e0 + j * WAVE;
             key[j] = (full || e < valid) ? keys_in[base + e] : ~0ull;
         }
-        for (int i = tid; i < NWAVES * RADIX; i += THREADS) (&wave_hist[0][0])[i] = 0;
+        for (int i = tid; i < NWAVES * RADIX / 2; i += THREADS) ((uint32_t *)&wave_hist[0][0])[i] = 0;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
             const uint32_t mlo = ~xlo, mhi = ~xhi;
             const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
             const uint32_t prior = my_hist[d];
-            if (ok && below == 0) my_hist[d] = prior + (uint32_t)(__popc(mlo) + __popc(mhi));
+            if (ok && below == 0) my_hist[d] = (uint16_t)(prior + (uint32_t)(__popc(mlo) + __popc(mhi)));
             pos[j] = prior + below;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
 #pragma unroll
             for (int ww = 0; ww < NWAVES; ++ww) {
                 const uint32_t cnt = wave_hist[ww][tid];
-                wave_hist[ww][tid] = tot;
+                wave_hist[ww][tid] = (uint16_t)tot;
                 tot += cnt;
             }
         }
