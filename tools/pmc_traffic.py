@@ -23,6 +23,8 @@ def load(counter_dir):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sa::", "")
             k = k.split("<")[0]
+            if k.startswith("k_radix_downsweep"):
+                k = "k_radix_downsweep"          # all tile-scatter variants are one kernel class in bench.py
             agg[k][0] += 1
             agg[k][1] += float(r["Counter_Value"])
     return agg
