@@ -88,6 +88,11 @@ int64_t sa_amd_workspace_bytes(int32_t n);
 int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n, void *dWork,
                            int64_t work_bytes, void *stream, sa_amd_stats *stats);
 
+/* The host-pointer entry points keep one grow-only device block and one stream per calling thread
+ * (at most SA_AMD_CACHE_MAX_BYTES, default 1 GiB; larger requests are allocated per call).
+ * This frees the calling thread's block now; it is also freed when the thread exits. */
+void sa_amd_release_cache(void);
+
 /* statistics of the most recent build issued by the calling thread (any entry point) */
 void sa_amd_last_stats(sa_amd_stats *out);
 

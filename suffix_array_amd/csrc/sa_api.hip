@@ -445,7 +445,33 @@ static int pick_device()
     return e ? atoi(e) : -1;   // -1: keep the calling thread's current device
 }
 
-// host buffers in, host buffers out; out_off = 1 writes SA[0] = n too (saca layout)
+// Per-thread device buffers of the host-pointer entry points.  Small and medium texts (the
+// reference's own tests build thousands of arrays of < 4096 bytes, reference src/tests.rs:14) would
+// otherwise pay three hipMalloc/hipFree pairs and a stream per call.  One grow-only block per
+// (thread, device), kept while it is at most SA_AMD_CACHE_MAX_BYTES (default 1 GiB); larger
+// requests are allocated and freed per call.  Thread-local, so the entry points stay re-entrant.
+struct HostCache {
+    int device = -1;
+    void *block = nullptr;
+    size_t bytes = 0;
+    hipStream_t stream = nullptr;
+    ~HostCache() { release(); }
+    void release()
+    {
+        if (block) (void)hipFree(block);
+        if (stream) (void)hipStreamDestroy(stream);
+        block = nullptr; bytes = 0; stream = nullptr; device = -1;
+    }
+};
+static thread_local HostCache g_cache;
+
+static size_t cache_limit()
+{
+    const char *e = getenv("SA_AMD_CACHE_MAX_BYTES");
+    return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 30);
+}
+
+// host buffers in, host buffers out; with_sentinel writes SA[0] = n too (saca layout)
 static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_sentinel, int device)
 {
     if (n < 0 || (n > 0 && (!T || !SA_host)) || (with_sentinel && !SA_host)) return SA_AMD_EINVAL;
@@ -454,24 +480,44 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     if (device >= ndev) return SA_AMD_EINVAL;
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     if (n == 0) { if (with_sentinel) SA_host[0] = 0; return SA_AMD_OK; }
-    uint8_t *dT = nullptr; uint32_t *dSA = nullptr; void *dW = nullptr;
-    const int64_t wb = sa_amd_workspace_bytes(n);
-    int rc = SA_AMD_OK;
-    hipStream_t st = nullptr;
-    auto cleanup = [&]() { if (dT) (void)hipFree(dT); if (dSA) (void)hipFree(dSA); if (dW) (void)hipFree(dW); if (st) (void)hipStreamDestroy(st); };
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    const size_t wb = (size_t)sa_amd_workspace_bytes(n);
+    const size_t tb = align_up((size_t)n, 256), sb = align_up(((size_t)n + 1) * 4, 256);
+    const size_t need = tb + sb + wb;
     auto hip_rc = [&](hipError_t e) { return e == hipSuccess ? SA_AMD_OK : (e == hipErrorOutOfMemory ? SA_AMD_ENOMEM : SA_AMD_EHIP); };
-    if ((rc = hip_rc(hipStreamCreate(&st)))) { cleanup(); return rc; }
-    if ((rc = hip_rc(hipMalloc((void **)&dT, (size_t)n)))) { cleanup(); return rc; }
-    if ((rc = hip_rc(hipMalloc((void **)&dSA, ((size_t)n + 1) * 4)))) { cleanup(); return rc; }
-    if ((rc = hip_rc(hipMalloc(&dW, (size_t)wb)))) { cleanup(); return rc; }
-    if ((rc = hip_rc(hipMemcpyAsync(dT, T, (size_t)n, hipMemcpyHostToDevice, st)))) { cleanup(); return rc; }
-    rc = build_device(dT, dSA, n, dW, wb, st, nullptr);
+    int rc = SA_AMD_OK;
+    void *block = nullptr;
+    hipStream_t st = nullptr;
+    const bool cached = need <= cache_limit();
+    if (cached) {
+        if (g_cache.device != cur) g_cache.release();
+        if (!g_cache.stream) { if ((rc = hip_rc(hipStreamCreate(&g_cache.stream)))) return rc; g_cache.device = cur; }
+        if (g_cache.bytes < need) {
+            if (g_cache.block) { (void)hipFree(g_cache.block); g_cache.block = nullptr; g_cache.bytes = 0; }
+            size_t want = need + need / 4;                      // some slack so a growing series does not reallocate every call
+            if (want > cache_limit()) want = need;
+            if ((rc = hip_rc(hipMalloc(&g_cache.block, want)))) return rc;
+            g_cache.bytes = want;
+        }
+        block = g_cache.block;
+        st = g_cache.stream;
+    } else {
+        if ((rc = hip_rc(hipStreamCreate(&st)))) return rc;
+        if ((rc = hip_rc(hipMalloc(&block, need)))) { (void)hipStreamDestroy(st); return rc; }
+    }
+    uint8_t *dT = (uint8_t *)block;
+    uint32_t *dSA = (uint32_t *)((char *)block + tb);
+    void *dW = (char *)block + tb + sb;
+    rc = hip_rc(hipMemcpyAsync(dT, T, (size_t)n, hipMemcpyHostToDevice, st));
+    if (rc == SA_AMD_OK) rc = build_device(dT, dSA, n, dW, (int64_t)wb, st, nullptr);
     if (rc == SA_AMD_OK) {
         if (with_sentinel) rc = hip_rc(hipMemcpyAsync(SA_host, dSA, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
         else rc = hip_rc(hipMemcpyAsync(SA_host, dSA + 1, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-        if (rc == SA_AMD_OK) rc = hip_rc(hipStreamSynchronize(st));
     }
-    cleanup();
+    const int rs = hip_rc(hipStreamSynchronize(st));       // also drains the stream after a failure
+    if (rc == SA_AMD_OK) rc = rs;
+    if (!cached) { (void)hipFree(block); (void)hipStreamDestroy(st); }
     return rc;
 }
 
@@ -618,6 +664,8 @@ SA_EXPORT int32_t sa_amd_check_integrity(const uint8_t *T, int32_t n, const uint
 {
     return extras_host(T, n, (uint32_t *)SA, sa_len, nullptr, 2);
 }
+
+SA_EXPORT void sa_amd_release_cache(void) { sa::g_cache.release(); }
 
 SA_EXPORT void sa_amd_last_stats(sa_amd_stats *out)
 {
