@@ -42,6 +42,7 @@ def parse():
                     help="c2_uniform_64m | c3_english_256m | c4_dna_1g | c5_uniform_512m")
     ap.add_argument("--n", type=int, default=None, help="override the text length (bytes)")
     ap.add_argument("--verify", action="store_true", help="check the last SA with the oracle's linear verifier")
+    ap.add_argument("--verify-gpu", action="store_true", help="check the last SA with the HIP integrity check (any n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload timed on the CPU")
     return ap.parse_args()
@@ -147,6 +148,15 @@ def main():
         orc = load_oracle()
         got = out.cpu().numpy().view(np.uint32)
         verified = bool(orc.oracle_verify_sa(text_h.ctypes.data, n, got.ctypes.data, n + 1) == 1)
+
+    if args.verify_gpu:
+        ci_bytes = 4 * (n + 1) + 256
+        ci_work = torch.empty(ci_bytes, dtype=torch.uint8, device=dev)
+        L.sa_amd_check_integrity_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_int64, ctypes.c_void_p]
+        L.sa_amd_check_integrity_device.restype = ctypes.c_int32
+        rc = L.sa_amd_check_integrity_device(text.data_ptr(), n, out.data_ptr(), ci_work.data_ptr(), ci_bytes, stream)
+        verified = bool(rc == 1) if verified is None else (verified and rc == 1)
 
     if rank != 0:
         if dist is not None:

@@ -123,6 +123,10 @@ static const SortVariant sort_variants[] = {
     { 1024, 8, 4, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8, 1024 workgroups" },
     { 1024, 12, 1, k_radix_downsweep_wcl<1024, 12>, "carry-completed lines 1024x12" },
     { 512, 20, 1, k_radix_downsweep_wcl<512, 20>, "carry-completed lines 512x20" },
+    { 512, 8, 2, k_radix_downsweep_wcl<512, 8, 8>, "carry 512x8, granule 8, 2 workgroups per CU" },
+    { 256, 16, 2, k_radix_downsweep_wcl<256, 16, 8>, "carry 256x16, granule 8, 2 workgroups per CU" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 8>, "carry 1024x8, granule 8" },
+    { 512, 8, 4, k_radix_downsweep_wcl<512, 8, 4>, "carry 512x8, granule 4, 2-3 workgroups per CU" },
 };
 constexpr int SORT_DEFAULT_VARIANT = 22;
 static const SortVariant &sort_variant()

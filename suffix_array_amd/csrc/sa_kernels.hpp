@@ -730,7 +730,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
 // w1 = max(w0, (c0+cnt) & ~15) are stored now -- first the old carry ([w0, c0), loop A), then the
 // tile's own elements -- and the rest lands in the carry at index (position - w1).
 // ------------------------------------------------------------------------------------------
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, int GR = 16>
 __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
@@ -739,13 +739,13 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
     constexpr int TILE = THREADS * ITEMS;
     constexpr int NWAVES = THREADS / WAVE;
     constexpr int WAVE_ELEMS = WAVE * ITEMS;
-    constexpr int CSTEPS = RADIX * WC_GR / THREADS;
-    static_assert(THREADS >= RADIX && (RADIX * WC_GR) % THREADS == 0, "thread / digit mapping");
+    constexpr int CSTEPS = (RADIX * GR + THREADS - 1) / THREADS;
+    static_assert(THREADS >= RADIX, "thread / digit mapping");
     static_assert(ITEMS % 4 == 0, "digits are packed four to a register");
     static_assert(TILE < 65536, "16-bit tile-local counters");
     __shared__ __attribute__((aligned(16))) uint64_t lds_kv[TILE];
-    __shared__ __attribute__((aligned(16))) uint64_t carry_k[RADIX * WC_GR];
-    __shared__ __attribute__((aligned(16))) uint32_t carry_v[RADIX * WC_GR];
+    __shared__ __attribute__((aligned(16))) uint64_t carry_k[RADIX * GR];
+    __shared__ __attribute__((aligned(16))) uint32_t carry_v[RADIX * GR];
     __shared__ uint16_t wave_hist[NWAVES][RADIX];   // a wave holds 64 * ITEMS <= 65535 elements, a tile < 65536
     __shared__ uint32_t digit_base[RADIX];     // first stage slot of digit d
     __shared__ uint32_t goff[RADIX];           // c0 - digit_base: global position = goff + stage slot
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
         const uint32_t dbase = block_excl_sum<THREADS>(tot, scan_lds, &tile_total);
         if (tid < RADIX) {
             const uint32_t c1 = c0 + tot;
-            const uint32_t fl = c1 & ~(uint32_t)(WC_GR - 1);
+            const uint32_t fl = c1 & ~(uint32_t)(GR - 1);
             const uint32_t w1 = fl > w0 ? fl : w0;
             digit_base[tid] = dbase;
             goff[tid] = c0 - dbase;
@@ -843,8 +843,8 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
 #pragma unroll
         for (int u = 0; u < CSTEPS; ++u) {
             const uint32_t i = (uint32_t)tid + (uint32_t)u * THREADS;
-            const uint32_t d = i / WC_GR, k = i % WC_GR;
-            if (k < apnd[d]) keys_out[aold[d] + k] = carry_k[i];
+            const uint32_t d = i / GR, k = i % GR;
+            if (i < (uint32_t)(RADIX * GR) && k < apnd[d]) keys_out[aold[d] + k] = carry_k[i];
         }
         __syncthreads();
         uint32_t dpack[ITEMS / 4];
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
                 dpack[j >> 2] |= d << (8 * (j & 3));
                 const uint32_t gp = goff[d] + (uint32_t)idx, lim = wlim[d];
                 if (gp < lim) keys_out[gp] = kx;
-                else carry_k[d * WC_GR + (gp - lim)] = kx;
+                else carry_k[d * GR + (gp - lim)] = kx;
             }
         }
         __syncthreads();
@@ -869,8 +869,8 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
 #pragma unroll
         for (int u = 0; u < CSTEPS; ++u) {
             const uint32_t i = (uint32_t)tid + (uint32_t)u * THREADS;
-            const uint32_t d = i / WC_GR, k = i % WC_GR;
-            if (k < apnd[d]) vals_out[aold[d] + k] = carry_v[i];
+            const uint32_t d = i / GR, k = i % GR;
+            if (i < (uint32_t)(RADIX * GR) && k < apnd[d]) vals_out[aold[d] + k] = carry_v[i];
         }
         __syncthreads();
 #pragma unroll
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
                 const uint32_t gp = goff[d] + (uint32_t)idx, lim = wlim[d];
                 const uint32_t vx = lds_v[idx];
                 if (gp < lim) vals_out[gp] = vx;
-                else carry_v[d * WC_GR + (gp - lim)] = vx;
+                else carry_v[d * GR + (gp - lim)] = vx;
             }
         }
         __syncthreads();
@@ -892,8 +892,8 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
 #pragma unroll
     for (int u = 0; u < CSTEPS; ++u) {
         const uint32_t i = (uint32_t)tid + (uint32_t)u * THREADS;
-        const uint32_t d = i / WC_GR, k = i % WC_GR;
-        if (k < apnd[d]) { keys_out[aold[d] + k] = carry_k[i]; vals_out[aold[d] + k] = carry_v[i]; }
+        const uint32_t d = i / GR, k = i % GR;
+        if (i < (uint32_t)(RADIX * GR) && k < apnd[d]) { keys_out[aold[d] + k] = carry_k[i]; vals_out[aold[d] + k] = carry_v[i]; }
     }
 }
 

@@ -198,6 +198,43 @@ def test_binned_isa_update_path(oracle, monkeypatch, gen, n, seed):
     assert np.array_equal(build(text), exp)
 
 
+def test_concurrent_callers(oracle):
+    """SuffixArray is Send + Sync in the reference (src/sa.rs:15-19): arrays may be built from many
+    threads at once; every thread owns its stream and device block here"""
+    import threading
+    texts = [corpus.english(200_000 + 1111 * i, 30 + i) for i in range(6)]
+    outs = [None] * len(texts)
+
+    def work(i):
+        for _ in range(3):
+            outs[i] = build(texts[i])
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(texts))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for t_, o in zip(texts, outs):
+        assert np.array_equal(o, oracle.sais(t_))
+
+
+def test_max_length_text():
+    """n = MAX_LENGTH = i32::MAX (reference src/saca.rs:6,10): index arithmetic at the top of the range.
+    Checked with the HIP integrity check (reference src/sa.rs:72-84) and direct comparisons of
+    sampled neighbours."""
+    n = sa.MAX_LENGTH
+    text = corpus.uniform(n, 77)
+    arr = np.empty(n + 1, dtype=np.uint32)
+    sa.saca(text, arr)
+    assert arr[0] == n
+    assert sa.check_integrity(text, arr) is True
+    rng = np.random.default_rng(1)
+    for i in rng.integers(1, n, 2000):
+        a, b = int(arr[i]), int(arr[i + 1])
+        assert text[a:a + 64].tobytes() < text[b:b + 64].tobytes() or text[a:a + 64].tobytes() == text[b:b + 64].tobytes()
+    sa.lib().sa_amd_release_cache()
+
+
 # ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------
 
 @pytest.mark.parametrize("name", ["c2_uniform_64m", "c3_english_256m"])
