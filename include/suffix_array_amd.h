@@ -126,6 +126,27 @@ int32_t sa_amd_check_integrity(const uint8_t *T, int32_t n, const uint32_t *SA, 
 int32_t sa_amd_check_integrity_device(const uint8_t *dT, int32_t n, const uint32_t *dSA, void *dWork,
                                       int64_t work_bytes, void *stream);
 
+/*
+ * Device-resident index: the text and its suffix array stay in HBM (SA == NULL: the array is built
+ * there, i.e. SuffixArray::new without the 4(n+1)-byte download), then serve the bucket table, the
+ * integrity check and BATCHED search -- `contains` / `search_all` / `search_lcp` of reference
+ * src/sa.rs:164-253 (no-bucket paths) for `count` patterns per call, one wavefront per pattern.
+ * Patterns are concatenated in pat_data; pattern q is pat_data[pat_off[q] .. pat_off[q+1]).
+ * Outputs (any may be NULL), per pattern:
+ *   contains[q]            1 iff the pattern occurs                            (src/sa.rs:164-170)
+ *   range_lo/hi[q]         search_all(pat) == &sa[lo..hi]                      (src/sa.rs:173-204)
+ *   lcp_start/len[q]       search_lcp(pat) == start..start+len                 (src/sa.rs:207-253)
+ */
+typedef struct sa_amd_index sa_amd_index;
+int32_t sa_amd_index_create(const uint8_t *T, int32_t n, const uint32_t *SA, sa_amd_index **out);
+void sa_amd_index_destroy(sa_amd_index *ix);
+int32_t sa_amd_index_sa(const sa_amd_index *ix, uint32_t *SA_out);               /* n + 1 entries */
+int32_t sa_amd_index_buckets(const sa_amd_index *ix, uint32_t *bkt);             /* 65 793 entries */
+int32_t sa_amd_index_check_integrity(const sa_amd_index *ix);                    /* as sa_amd_check_integrity */
+int32_t sa_amd_index_search(const sa_amd_index *ix, const uint8_t *pat_data, const int64_t *pat_off, int32_t count,
+                            uint8_t *contains, uint32_t *range_lo, uint32_t *range_hi, uint32_t *lcp_start,
+                            uint32_t *lcp_len);
+
 /* ---- per-kernel timing (HIP events on the launch stream), per calling thread ----
  * begin() zeroes and enables the counters for builds issued by this thread; end() disables them and
  * copies up to `capacity` classes out (ms = summed event time, launches, units = elements or bytes

@@ -20,7 +20,7 @@ from typing import Optional
 import numpy as np
 
 __all__ = ["MAX_LENGTH", "saca", "SuffixArray", "SuffixArrayError", "lib", "library_path", "Stats",
-           "saca_batch", "workspace_bytes", "saca_device_ptr", "bucket_table", "check_integrity", "last_stats"]
+           "saca_batch", "workspace_bytes", "saca_device_ptr", "bucket_table", "check_integrity", "last_stats", "DeviceIndex"]
 
 #: reference src/saca.rs:6
 MAX_LENGTH = 2**31 - 1
@@ -76,6 +76,17 @@ def lib() -> ctypes.CDLL:
         L.sa_amd_saca_device.restype = ctypes.c_int32
         L.sa_amd_device_count.restype = ctypes.c_int32
         L.sa_amd_last_stats.argtypes = [c_vp]
+        L.sa_amd_index_create.argtypes = [c_vp, ctypes.c_int32, c_vp, ctypes.POINTER(ctypes.c_void_p)]
+        L.sa_amd_index_create.restype = ctypes.c_int32
+        L.sa_amd_index_destroy.argtypes = [c_vp]
+        L.sa_amd_index_destroy.restype = None
+        for fn in ("sa_amd_index_sa", "sa_amd_index_buckets"):
+            getattr(L, fn).argtypes = [c_vp, c_vp]
+            getattr(L, fn).restype = ctypes.c_int32
+        L.sa_amd_index_check_integrity.argtypes = [c_vp]
+        L.sa_amd_index_check_integrity.restype = ctypes.c_int32
+        L.sa_amd_index_search.argtypes = [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp]
+        L.sa_amd_index_search.restype = ctypes.c_int32
         L.sa_amd_bucket_table.argtypes = [c_vp, ctypes.c_int32, c_vp, c_vp]
         L.sa_amd_bucket_table.restype = ctypes.c_int32
         L.sa_amd_saca_u8_buckets.argtypes = [c_vp, c_vp, ctypes.c_int32, c_vp]
@@ -183,6 +194,59 @@ def check_integrity(s, sa: np.ndarray) -> bool:
     return rc == 1
 
 
+class DeviceIndex:
+    """Text + suffix array resident in HBM (sa_amd_index of include/suffix_array_amd.h): batched
+    `contains` / `search_all` / `search_lcp` (reference src/sa.rs:164-253), bucket table, integrity check.
+    `sa=None` builds the array on the device (SuffixArray::new without downloading it)."""
+
+    def __init__(self, s, sa: Optional[np.ndarray] = None):
+        self._s = _as_u8(s)
+        h = ctypes.c_void_p()
+        a = None if sa is None else np.ascontiguousarray(sa, dtype=np.uint32)
+        if a is not None:
+            assert a.size == self._s.size + 1
+        _check(lib().sa_amd_index_create(self._s.ctypes.data, self._s.size, None if a is None else a.ctypes.data,
+                                         ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sa_amd_index_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def suffix_array(self) -> np.ndarray:
+        out = np.empty(self._s.size + 1, dtype=np.uint32)
+        _check(lib().sa_amd_index_sa(self._h, out.ctypes.data))
+        return out
+
+    def buckets(self) -> np.ndarray:
+        bkt = np.empty(BUCKET_TABLE_LEN, dtype=np.uint32)
+        _check(lib().sa_amd_index_buckets(self._h, bkt.ctypes.data))
+        return bkt
+
+    def check_integrity(self) -> bool:
+        rc = lib().sa_amd_index_check_integrity(self._h)
+        if rc < 0 and rc != -6:
+            _check(rc)
+        return rc == 1
+
+    def search(self, patterns):
+        """-> dict of arrays over the patterns: contains (bool), lo/hi (search_all == sa[lo:hi]),
+        lcp_start/lcp_len (search_lcp == start..start+len)"""
+        pats = [bytes(p) for p in patterns]
+        cnt = len(pats)
+        off = np.zeros(cnt + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(p) for p in pats])
+        data = np.frombuffer(b"".join(pats), dtype=np.uint8) if off[-1] else np.zeros(1, dtype=np.uint8)
+        c = np.zeros(cnt, dtype=np.uint8)
+        lo, hi, ls, ll = (np.zeros(cnt, dtype=np.uint32) for _ in range(4))
+        _check(lib().sa_amd_index_search(self._h, data.ctypes.data, off.ctypes.data, cnt, c.ctypes.data, lo.ctypes.data,
+                                         hi.ctypes.data, ls.ctypes.data, ll.ctypes.data))
+        return {"contains": c.astype(bool), "lo": lo, "hi": hi, "lcp_start": ls, "lcp_len": ll}
+
+
 def workspace_bytes(n: int) -> int:
     return int(lib().sa_amd_workspace_bytes(n))
 
@@ -228,6 +292,7 @@ class SuffixArray:
         self._sa = np.zeros(self._s.size + 1, dtype=np.uint32)     # vec![0; s.len() + 1]
         saca(self._s, self._sa)
         self._bkt = None
+        self._ix = None
 
     @classmethod
     def new(cls, s) -> "SuffixArray":
@@ -265,6 +330,7 @@ class SuffixArray:
         obj._s = _as_u8(s)
         obj._sa = np.ascontiguousarray(sa, dtype=np.uint32)
         obj._bkt = None
+        obj._ix = None
         return obj
 
     def enable_buckets(self) -> None:
@@ -274,6 +340,24 @@ class SuffixArray:
 
     def buckets(self) -> Optional[np.ndarray]:
         return self._bkt
+
+    # search: reference src/sa.rs:164-253, one pattern per call as in the reference (a batch of one on
+    # the device-resident index; use DeviceIndex.search for many patterns)
+    def _index(self) -> "DeviceIndex":
+        if getattr(self, "_ix", None) is None:
+            self._ix = DeviceIndex(self._s, self._sa)
+        return self._ix
+
+    def contains(self, pat) -> bool:
+        return bool(self._index().search([pat])["contains"][0])
+
+    def search_all(self, pat) -> np.ndarray:
+        r = self._index().search([pat])
+        return self._sa[int(r["lo"][0]):int(r["hi"][0])]
+
+    def search_lcp(self, pat) -> range:
+        r = self._index().search([pat])
+        return range(int(r["lcp_start"][0]), int(r["lcp_start"][0]) + int(r["lcp_len"][0]))
 
     def __array__(self, dtype=None):                   # From<SuffixArray> for Vec<u32>, src/sa.rs:364-368
         return self._sa if dtype is None else self._sa.astype(dtype)

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -667,6 +668,120 @@ SA_EXPORT int32_t sa_amd_saca_u8_buckets(const uint8_t *T, uint32_t *SA, int32_t
 SA_EXPORT int32_t sa_amd_check_integrity(const uint8_t *T, int32_t n, const uint32_t *SA, int64_t sa_len)
 {
     return extras_host(T, n, (uint32_t *)SA, sa_len, nullptr, 2);
+}
+
+// ---- device-resident index: text + suffix array kept in HBM for bucket table, integrity check and batched search ----
+
+struct sa_amd_index {
+    int device;
+    int32_t n;
+    uint8_t *dT;
+    uint32_t *dSA;
+};
+
+SA_EXPORT int32_t sa_amd_index_create(const uint8_t *T, int32_t n, const uint32_t *SA, sa_amd_index **out)
+{
+    using namespace sa;
+    if (!out || n < 0 || (n > 0 && !T)) return SA_AMD_EINVAL;
+    *out = nullptr;
+    if (sa_amd_device_count() <= 0) return SA_AMD_ENODEVICE;
+    auto hrc = [&](hipError_t e) { return e == hipSuccess ? SA_AMD_OK : (e == hipErrorOutOfMemory ? SA_AMD_ENOMEM : SA_AMD_EHIP); };
+    sa_amd_index *ix = new (std::nothrow) sa_amd_index();
+    if (!ix) return SA_AMD_ENOMEM;
+    ix->n = n; ix->dT = nullptr; ix->dSA = nullptr; ix->device = 0;
+    (void)hipGetDevice(&ix->device);
+    const size_t N = (size_t)n;
+    int32_t rc = hrc(hipMalloc((void **)&ix->dT, N ? N : 1));
+    if (rc == SA_AMD_OK) rc = hrc(hipMalloc((void **)&ix->dSA, (N + 1) * 4));
+    if (rc == SA_AMD_OK && N) rc = hrc(hipMemcpy(ix->dT, T, N, hipMemcpyHostToDevice));
+    if (rc == SA_AMD_OK) {
+        if (SA) rc = hrc(hipMemcpy(ix->dSA, SA, (N + 1) * 4, hipMemcpyHostToDevice));
+        else {                                                   // SuffixArray::new on the device
+            void *dW = nullptr;
+            const int64_t wb = sa_amd_workspace_bytes(n);
+            rc = hrc(hipMalloc(&dW, (size_t)wb));
+            if (rc == SA_AMD_OK) rc = build_device(ix->dT, ix->dSA, n, dW, wb, nullptr, nullptr);
+            if (dW) (void)hipFree(dW);
+        }
+    }
+    if (rc != SA_AMD_OK) { if (ix->dT) (void)hipFree(ix->dT); if (ix->dSA) (void)hipFree(ix->dSA); delete ix; return rc; }
+    *out = ix;
+    return SA_AMD_OK;
+}
+
+SA_EXPORT void sa_amd_index_destroy(sa_amd_index *ix)
+{
+    if (!ix) return;
+    if (ix->dT) (void)hipFree(ix->dT);
+    if (ix->dSA) (void)hipFree(ix->dSA);
+    delete ix;
+}
+
+SA_EXPORT int32_t sa_amd_index_sa(const sa_amd_index *ix, uint32_t *SA_out)
+{
+    if (!ix || !SA_out) return SA_AMD_EINVAL;
+    return hipMemcpy(SA_out, ix->dSA, ((size_t)ix->n + 1) * 4, hipMemcpyDeviceToHost) == hipSuccess ? SA_AMD_OK : SA_AMD_EHIP;
+}
+
+SA_EXPORT int32_t sa_amd_index_buckets(const sa_amd_index *ix, uint32_t *bkt)
+{
+    if (!ix || !bkt) return SA_AMD_EINVAL;
+    uint32_t *dB = nullptr;
+    if (hipMalloc((void **)&dB, (size_t)sa::BKT_LEN * 4) != hipSuccess) return SA_AMD_ENOMEM;
+    int32_t rc = sa_amd_bucket_table_device(ix->dT, ix->dSA, ix->n, dB, nullptr);
+    if (rc == SA_AMD_OK && hipMemcpy(bkt, dB, (size_t)sa::BKT_LEN * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SA_AMD_EHIP;
+    (void)hipFree(dB);
+    return rc;
+}
+
+SA_EXPORT int32_t sa_amd_index_check_integrity(const sa_amd_index *ix)
+{
+    if (!ix) return SA_AMD_EINVAL;
+    void *dW = nullptr;
+    const int64_t wb = ((int64_t)ix->n + 1) * 4 + 256;
+    if (hipMalloc(&dW, (size_t)wb) != hipSuccess) return SA_AMD_ENOMEM;
+    const int32_t rc = sa_amd_check_integrity_device(ix->dT, ix->n, ix->dSA, dW, wb, nullptr);
+    (void)hipFree(dW);
+    return rc;
+}
+
+SA_EXPORT int32_t sa_amd_index_search(const sa_amd_index *ix, const uint8_t *pat_data, const int64_t *pat_off, int32_t count,
+                                      uint8_t *contains, uint32_t *range_lo, uint32_t *range_hi, uint32_t *lcp_start,
+                                      uint32_t *lcp_len)
+{
+    using namespace sa;
+    if (!ix || count < 0 || (count > 0 && !pat_off)) return SA_AMD_EINVAL;
+    if (count == 0) return SA_AMD_OK;
+    const int64_t total = pat_off[count];
+    if (total < 0 || (total > 0 && !pat_data)) return SA_AMD_EINVAL;
+    for (int32_t i = 0; i < count; ++i) if (pat_off[i + 1] < pat_off[i]) return SA_AMD_EINVAL;
+    auto hrc = [&](hipError_t e) { return e == hipSuccess ? SA_AMD_OK : (e == hipErrorOutOfMemory ? SA_AMD_ENOMEM : SA_AMD_EHIP); };
+    const size_t C = (size_t)count;
+    uint8_t *dP = nullptr; int64_t *dO = nullptr; uint8_t *dC = nullptr; uint32_t *dR = nullptr;
+    int32_t rc = hrc(hipMalloc((void **)&dP, total ? (size_t)total : 1));
+    if (rc == SA_AMD_OK) rc = hrc(hipMalloc((void **)&dO, (C + 1) * 8));
+    if (rc == SA_AMD_OK) rc = hrc(hipMalloc((void **)&dC, C));
+    if (rc == SA_AMD_OK) rc = hrc(hipMalloc((void **)&dR, C * 4 * 4));
+    if (rc == SA_AMD_OK && total) rc = hrc(hipMemcpy(dP, pat_data, (size_t)total, hipMemcpyHostToDevice));
+    if (rc == SA_AMD_OK) rc = hrc(hipMemcpy(dO, pat_off, (C + 1) * 8, hipMemcpyHostToDevice));
+    if (rc == SA_AMD_OK) {
+        const int64_t threads = (int64_t)count * WAVE;
+        hipLaunchKernelGGL(k_search_batch, dim3((unsigned)ceil_div(threads, SEARCH_THREADS)), dim3(SEARCH_THREADS), 0, nullptr,
+                           (const uint8_t *)ix->dT, (const uint32_t *)ix->dSA, (int64_t)ix->n, (const uint8_t *)dP,
+                           (const int64_t *)dO, count, dC, dR, dR + C, dR + 2 * C, dR + 3 * C);
+        rc = hrc(hipGetLastError());
+        if (rc == SA_AMD_OK) rc = hrc(hipDeviceSynchronize());
+    }
+    if (rc == SA_AMD_OK && contains) rc = hrc(hipMemcpy(contains, dC, C, hipMemcpyDeviceToHost));
+    if (rc == SA_AMD_OK && range_lo) rc = hrc(hipMemcpy(range_lo, dR, C * 4, hipMemcpyDeviceToHost));
+    if (rc == SA_AMD_OK && range_hi) rc = hrc(hipMemcpy(range_hi, dR + C, C * 4, hipMemcpyDeviceToHost));
+    if (rc == SA_AMD_OK && lcp_start) rc = hrc(hipMemcpy(lcp_start, dR + 2 * C, C * 4, hipMemcpyDeviceToHost));
+    if (rc == SA_AMD_OK && lcp_len) rc = hrc(hipMemcpy(lcp_len, dR + 3 * C, C * 4, hipMemcpyDeviceToHost));
+    if (dP) (void)hipFree(dP);
+    if (dO) (void)hipFree(dO);
+    if (dC) (void)hipFree(dC);
+    if (dR) (void)hipFree(dR);
+    return rc;
 }
 
 SA_EXPORT void sa_amd_release_cache(void) { sa::g_cache.release(); }

@@ -74,3 +74,87 @@ __global__ __launch_bounds__(256) void k_ci_check(const uint8_t *__restrict__ T,
 }
 
 }  // namespace sa
+
+// ------------------------------------------------------------------------------------------
+// Batched search: contains / search_all / search_lcp of reference
+// src/sa.rs:164-253 for MANY patterns at once, one wave per pattern.  The reference's API is one
+// pattern per call (latency-bound binary search, CPU-appropriate); the batched form is what a GPU
+// can help with.  Comparisons are done 64 bytes at a time: lane l compares byte c + l of the
+// pattern with byte c + l of the suffix, a ballot finds the first difference.
+// ------------------------------------------------------------------------------------------
+namespace sa {
+
+struct SuffixCmp { int ord; uint32_t lcp; };   // ord: -1 suffix < pattern, 0 equal, +1 suffix > pattern
+
+// Rust slice ordering of s[p..] against pat (lexicographic, a proper prefix is smaller) and their lcp
+__device__ __forceinline__ SuffixCmp wave_compare(const uint8_t *__restrict__ T, int64_t n, int64_t p,
+                                                  const uint8_t *__restrict__ pat, int64_t plen)
+{
+    const int l = lane_id();
+    const int64_t slen = n - p;
+    const int64_t common = slen < plen ? slen : plen;
+    for (int64_t c = 0; c < common; c += WAVE) {
+        const int64_t i = c + l;
+        const bool in = i < common;
+        const uint8_t a = in ? T[p + i] : 0, b = in ? pat[i] : 0;
+        const uint64_t diff = __ballot(in && a != b);
+        if (diff) {
+            const int first = __ffsll((unsigned long long)diff) - 1;
+            const int av = __shfl((int)a, first, WAVE), bv = __shfl((int)b, first, WAVE);
+            SuffixCmp r; r.ord = av < bv ? -1 : 1; r.lcp = (uint32_t)(c + first);
+            return r;
+        }
+    }
+    SuffixCmp r; r.lcp = (uint32_t)common;
+    r.ord = slen < plen ? -1 : (slen > plen ? 1 : 0);
+    return r;
+}
+
+constexpr int SEARCH_THREADS = 256;
+
+__global__ __launch_bounds__(SEARCH_THREADS) void k_search_batch(
+    const uint8_t *__restrict__ T, const uint32_t *__restrict__ SA, int64_t n, const uint8_t *__restrict__ pat_data,
+    const int64_t *__restrict__ pat_off, int32_t count, uint8_t *__restrict__ contains, uint32_t *__restrict__ range_lo,
+    uint32_t *__restrict__ range_hi, uint32_t *__restrict__ lcp_start, uint32_t *__restrict__ lcp_len)
+{
+    const int q = (int)((blockIdx.x * (int64_t)SEARCH_THREADS + threadIdx.x) / WAVE);
+    if (q >= count) return;                                   // whole waves leave together
+    const uint8_t *pat = pat_data + pat_off[q];
+    const int64_t plen = pat_off[q + 1] - pat_off[q];
+    const int64_t len = n + 1;                                // sa.len()
+    // search_all, first loop (reference src/sa.rs:182-190): first i with !(pat > s[sa[i]..])
+    int64_t lo = 0, hi = len;
+    while (lo < hi) {
+        const int64_t m = lo + (hi - lo) / 2;
+        if (wave_compare(T, n, (int64_t)SA[m], pat, plen).ord < 0) lo = m + 1; else hi = m;
+    }
+    const int64_t i = lo;
+    // second loop (src/sa.rs:192-201): first j >= i whose suffix does not start with pat
+    int64_t lo2 = i, hi2 = len;
+    while (lo2 < hi2) {
+        const int64_t m = lo2 + (hi2 - lo2) / 2;
+        if ((int64_t)wave_compare(T, n, (int64_t)SA[m], pat, plen).lcp == plen) lo2 = m + 1; else hi2 = m;
+    }
+    const int64_t j = lo2;
+    // search_lcp without buckets (src/sa.rs:207-253): i is also the insertion point of pat
+    uint32_t ls = (uint32_t)n, ll = 0;
+    {
+        SuffixCmp cb; cb.ord = 1; cb.lcp = 0;
+        if (i < len) cb = wave_compare(T, n, (int64_t)SA[i], pat, plen);
+        if (i < len && cb.ord == 0) { ls = SA[i]; ll = (uint32_t)(n - (int64_t)SA[i]); }            // Ok(i): start..s.len()
+        else if (i > 0 && i < len) {
+            const SuffixCmp ca = wave_compare(T, n, (int64_t)SA[i - 1], pat, plen);
+            if (ca.lcp > cb.lcp) { ls = SA[i - 1]; ll = ca.lcp; } else { ls = SA[i]; ll = cb.lcp; }
+        } else if (i == 0) { ls = SA[0]; ll = cb.lcp; }
+        else { const SuffixCmp ca = wave_compare(T, n, (int64_t)SA[i - 1], pat, plen); ls = SA[i - 1]; ll = ca.lcp; }
+    }
+    if (lane_id() == 0) {
+        if (contains) contains[q] = (uint8_t)(j > i);         // src/sa.rs:164-170: some suffix starts with pat
+        if (range_lo) range_lo[q] = (uint32_t)i;
+        if (range_hi) range_hi[q] = (uint32_t)j;
+        if (lcp_start) lcp_start[q] = ls;
+        if (lcp_len) lcp_len[q] = ll;
+    }
+}
+
+}  // namespace sa

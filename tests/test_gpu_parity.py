@@ -314,3 +314,94 @@ def test_from_parts_uses_gpu_check(oracle):
     assert sa.SuffixArray.from_parts(s, good) is not None
     bad = good.copy(); bad[100], bad[101] = bad[101], bad[100]
     assert sa.SuffixArray.from_parts(s, bad) is None
+
+
+# ---- next row 8f-4: batched search (reference src/sa.rs:164-253) --------------------------------
+# naive checkers restated from the reference's own tests, src/tests.rs:104-132
+
+def _lcp(a, b):
+    k = 0
+    while k < len(a) and k < len(b) and a[k] == b[k]:
+        k += 1
+    return k
+
+
+def naive_contains(s, pat):
+    return any(pat == s[i:min(len(s), i + len(pat))] for i in range(0, max(len(s) - len(pat), 0) + 1))
+
+
+def naive_search_all(s, pat):
+    return [i for i in range(0, max(len(s) - len(pat), 0) + 1) if pat == s[i:min(len(s), i + len(pat))]]
+
+
+def naive_search_lcp(s, pat):
+    best = 0
+    for i in range(len(s) + 1):
+        best = max(best, _lcp(pat, s[i:]))
+    return pat[:best]
+
+
+def _bytes_with_pat(rng, n):
+    """reference src/tests.rs:79-102: no_junk / trail_junk / all_junk patterns"""
+    s = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    m = int(n * rng.random())
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        i = int(rng.integers(0, n - m + 1)); pat = s[i:i + m]
+    elif kind == 1:
+        i = int(rng.integers(0, n - m + 1)); j = int(rng.integers(0, m + 1))
+        pat = s[i:i + (m - j)] + rng.integers(0, 256, j, dtype=np.uint8).tobytes()
+    else:
+        pat = rng.integers(0, 256, m, dtype=np.uint8).tobytes()
+    return s, pat
+
+
+def test_search_properties_of_the_reference():
+    """contains_correctness / search_all_correctness / search_lcp_correctness, reference src/tests.rs:19-59"""
+    rng = np.random.default_rng(99)
+    for it in range(60):
+        n = int(rng.integers(0, 600)) if it else 0
+        s, pat = _bytes_with_pat(rng, n)
+        obj = sa.SuffixArray(s)
+        assert obj.contains(pat) == naive_contains(s, pat)
+        assert sorted(int(x) for x in obj.search_all(pat)) == naive_search_all(s, pat)
+        r = obj.search_lcp(pat)
+        assert s[r.start:r.stop] == naive_search_lcp(s, pat)
+
+
+def test_doctests_of_the_reference():
+    """reference src/lib.rs:16-41"""
+    s = b"splendid splendor"
+    obj = sa.SuffixArray(s)
+    assert obj.contains(b"splend")
+    assert sorted(int(x) for x in obj.search_all(b"splend")) == [0, 9]
+    r = obj.search_lcp(b"splash")
+    assert s[r.start:r.stop] == b"spl"
+
+
+def test_batched_search_on_device_resident_index(oracle):
+    text = corpus.english(200_000, 12)
+    s = text.tobytes()
+    ix = sa.DeviceIndex(text)                      # array built on the device, never downloaded for the search
+    arr = oracle.sais(text)
+    assert np.array_equal(ix.suffix_array(), arr)
+    assert ix.check_integrity() and np.array_equal(ix.buckets(), oracle.bucket_table(text))
+    rng = np.random.default_rng(3)
+    pats = [b"", b"e", b" ras ", s[-7:], s[:300], b"zzzzzzzzzz", b"\xff"]
+    for _ in range(300):
+        i = int(rng.integers(0, len(s) - 40)); ln = int(rng.integers(1, 40))
+        p = s[i:i + ln]
+        if rng.random() < 0.4:
+            p = p[:-1] + bytes([int(rng.integers(0, 256))])
+        pats.append(p)
+    res = ix.search(pats)
+    for q, p in enumerate(pats):
+        occ = naive_search_all(s, p) if len(p) else list(range(len(s) + 1))
+        got = sorted(int(x) for x in arr[res["lo"][q]:res["hi"][q]])
+        assert got == occ, p
+        assert bool(res["contains"][q]) == (len(occ) > 0)
+        st, ln = int(res["lcp_start"][q]), int(res["lcp_len"][q])
+        assert s[st:st + ln] == p[:ln]
+        if q < 40:
+            assert ln == len(naive_search_lcp(s, p))
+    ix.close()
