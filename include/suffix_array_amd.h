@@ -155,6 +155,10 @@ void sa_amd_profile_begin(void);
 int32_t sa_amd_profile_end(double *ms, int64_t *launches, int64_t *units, int32_t capacity);
 const char *sa_amd_profile_kernel_name(int32_t index);
 
+/* diagnostic builds of the dominant kernel only (SA_AMD_SORT_VARIANT = the 'phase stamps' entry):
+ * cycles per phase summed over tiles and workgroups; reading zeroes the counters */
+int32_t sa_amd_debug_phase_cycles(uint64_t *out, int32_t count);
+
 /* ---- primitive test hooks: exercised by tests/ to localise a failing kernel ---- */
 
 /* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit); host buffers */

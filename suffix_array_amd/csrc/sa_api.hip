@@ -128,6 +128,9 @@ static const SortVariant sort_variants[] = {
     { 256, 16, 2, k_radix_downsweep_wcl<256, 16, 8>, "carry 256x16, granule 8, 2 workgroups per CU" },
     { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 8>, "carry 1024x8, granule 8" },
     { 512, 8, 4, k_radix_downsweep_wcl<512, 8, 4>, "carry 512x8, granule 4, 2-3 workgroups per CU" },
+    { 512, 12, 2, k_radix_downsweep_wcl<512, 12, 4, 4>, "carry 512x12, granule 4, <=128 vgpr, 2 workgroups per CU" },
+    { 512, 12, 2, k_radix_downsweep_wcl<512, 12, 8, 4>, "carry 512x12, granule 8, <=128 vgpr" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 16, 1, true>, "carry 1024x8 DIAGNOSTIC phase stamps" },
 };
 constexpr int SORT_DEFAULT_VARIANT = 22;
 static const SortVariant &sort_variant()
@@ -782,6 +785,16 @@ SA_EXPORT int32_t sa_amd_index_search(const sa_amd_index *ix, const uint8_t *pat
     if (dC) (void)hipFree(dC);
     if (dR) (void)hipFree(dR);
     return rc;
+}
+
+SA_EXPORT int32_t sa_amd_debug_phase_cycles(uint64_t *out, int32_t count)
+{
+    unsigned long long h[16] = { 0 };
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(sa::g_phase_cycles), sizeof(h)) != hipSuccess) return SA_AMD_EHIP;
+    for (int i = 0; i < count && i < 16; ++i) out[i] = h[i];
+    unsigned long long z[16] = { 0 };
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(sa::g_phase_cycles), z, sizeof(z));
+    return 16;
 }
 
 SA_EXPORT void sa_amd_release_cache(void) { sa::g_cache.release(); }

@@ -292,23 +292,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_upsweep(const uint64_t *
     else if (s) atomicAdd(&counts[(int64_t)threadIdx.x * G + g], s);     // counts zeroed by the host
 }
 
-// exclusive scan, in place, of `total` u32 counters by ONE workgroup (digit-major order)
 constexpr int SPINE_THREADS = 1024;
-__global__ __launch_bounds__(SPINE_THREADS) void k_excl_scan_u32(uint32_t *__restrict__ a, int64_t total,
-                                                                  uint32_t *__restrict__ out_total)
-{
-    __shared__ uint32_t lds[SPINE_THREADS / WAVE + 1];
-    const int64_t per = (total + SPINE_THREADS - 1) / SPINE_THREADS;
-    int64_t b = (int64_t)threadIdx.x * per, e = b + per;
-    if (b > total) b = total;
-    if (e > total) e = total;
-    uint32_t s = 0;
-    for (int64_t i = b; i < e; ++i) s += a[i];
-    uint32_t tot;
-    uint32_t off = block_excl_sum<SPINE_THREADS>(s, lds, &tot);
-    for (int64_t i = b; i < e; ++i) { uint32_t v = a[i]; a[i] = off; off += v; }
-    if (out_total && threadIdx.x == 0) *out_total = tot;
-}
 
 // Spine of one radix pass: block d turns counts[d][0..G) into exclusive prefixes (in place) and
 // writes the digit total; the downsweep prologue scans the 256 totals itself.  G <= 1024.
@@ -730,8 +714,11 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
 // w1 = max(w0, (c0+cnt) & ~15) are stored now -- first the old carry ([w0, c0), loop A), then the
 // tile's own elements -- and the rest lands in the carry at index (position - w1).
 // ------------------------------------------------------------------------------------------
-template <int THREADS, int ITEMS, int GR = 16>
-__global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
+// diagnostic build only (STAMP): cycles of wave 0 per phase, summed over tiles and workgroups
+__device__ unsigned long long g_phase_cycles[16];
+
+template <int THREADS, int ITEMS, int GR = 16, int MINW = 1, bool STAMP = false>
+__global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
     int64_t n, int shift, uint32_t dmask, int64_t tiles_per_wg, int G)
@@ -766,9 +753,18 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
     uint32_t *lds_v = (uint32_t *)lds_kv;
     const int e0 = w * WAVE_ELEMS + l;
     const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
+    unsigned long long t_prev = 0;
+    auto stamp = [&](int phase) {
+        if (STAMP && tid == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (phase >= 0) atomicAdd(&g_phase_cycles[phase], now - t_prev);
+            t_prev = now;
+        }
+    };
     for (int64_t t = 0; t < tiles_per_wg; ++t) {
         const int64_t base = (tile0 + t) * TILE;
         if (base >= n) break;
+        stamp(-1);
         const int valid = (n - base) >= TILE ? TILE : (int)(n - base);
         const bool full = valid == TILE;
         uint64_t key[ITEMS];
@@ -780,6 +776,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
         }
         for (int i = tid; i < NWAVES * RADIX / 2; i += THREADS) ((uint32_t *)&wave_hist[0][0])[i] = 0;
         __syncthreads();
+        stamp(0);      // key loads issued, counters zeroed
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const bool ok = full || (e0 + j * WAVE) < valid;
@@ -800,6 +797,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
             pos[j] = prior + below;
             __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(1);      // ranking (includes the wait for the keys)
         uint32_t val[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -807,6 +805,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
             val[j] = (full || e < valid) ? vals_in[base + e] : 0u;
         }
         __syncthreads();
+        stamp(2);      // value loads issued + barrier
         // ---- thread d: per-wave offsets, digit totals, carry bookkeeping ----
         uint32_t tot = 0;
         if (tid < RADIX) {
@@ -832,6 +831,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
             w0 = w1;
         }
         __syncthreads();
+        stamp(3);      // per-digit prefix + carry bookkeeping
         // ---- keys: stage in sorted order ----
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -847,6 +847,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
             if (i < (uint32_t)(RADIX * GR) && k < apnd[d]) keys_out[aold[d] + k] = carry_k[i];
         }
         __syncthreads();
+        stamp(4);      // keys -> LDS, old carry out
         uint32_t dpack[ITEMS / 4];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -862,6 +863,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
             }
         }
         __syncthreads();
+        stamp(5);      // keys LDS -> global
         // ---- values: the same through the same stage ----
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j)
@@ -873,6 +875,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
             if (i < (uint32_t)(RADIX * GR) && k < apnd[d]) vals_out[aold[d] + k] = carry_v[i];
         }
         __syncthreads();
+        stamp(6);      // values -> LDS, old carry out
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int idx = tid + j * THREADS;
@@ -885,6 +888,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wcl(
             }
         }
         __syncthreads();
+        stamp(7);      // values LDS -> global
     }
     // ---- flush what is left in the carries (at most 15 elements per digit) ----
     if (tid < RADIX) { aold[tid] = w0; apnd[tid] = c0 - w0; }
