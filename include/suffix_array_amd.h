@@ -74,6 +74,8 @@ typedef struct sa_amd_stats {
     int32_t sparse_mode;      /* 1: few tied suffixes, ranks looked up in the sorted keys instead of a full ISA */
     int64_t sorted_elements;  /* sum over sort passes of elements moved */
     int64_t unresolved_after_initial; /* suffixes still in groups > 1 after the initial sort */
+    int32_t text_rounds;      /* of `rounds`: text-keyed rounds (secondary key read from the text, no rank array) */
+    int32_t reserved;
 } sa_amd_stats;
 
 /* bytes of device scratch sa_amd_saca_device needs for a text of n bytes */

@@ -1,8 +1,8 @@
 """numpy model of the DEVICE algorithm (test infrastructure only, like everything in oracle/).
 
 It restates, step for step, what suffix_array_amd/csrc does on the GPU -- packed-symbol
-initial keys, a stable LSD sort, group-head ranks, and prefix-doubling refinement of the
-unresolved groups with the end-of-text rule -- so that the algorithm's logic (not the HIP
+initial keys, a stable LSD sort, group-head ranks, text-keyed refinement rounds while many
+suffixes are tied, then prefix-doubling refinement of the unresolved groups with the end-of-text rule -- so that the algorithm's logic (not the HIP
 code) can be checked on the CPU against oracle_naive_sa / oracle_sais.
 
 The output contract is the reference's: sa[0] = n, sa[1..] sorted suffix offsets
@@ -38,13 +38,26 @@ def pack_keys(text: np.ndarray):
     return key, bits, k
 
 
-def build(text_bytes: bytes, max_rounds: int = 64, stats: dict | None = None) -> np.ndarray:
+def _text_symbols(n: int, bits: int, se: int) -> int:
+    """symbols per text-keyed round: what fits below the group head in a 64-bit sort key"""
+    room = 64 - max(1, (max(n - 1, 1)).bit_length())
+    if bits:
+        return room // bits
+    s = 0
+    while se ** (s + 1) <= 2 ** room:
+        s += 1
+    return s
+
+
+def build(text_bytes: bytes, max_rounds: int = 64, stats: dict | None = None, sparse_div: int = 64,
+          max_text_rounds: int = 4) -> np.ndarray:
     t = np.frombuffer(text_bytes, dtype=np.uint8)
     n = t.size
     out = np.zeros(n + 1, dtype=np.uint32)
     out[0] = n
     if n == 0:
         return out
+    code, bits, k, se = alphabet(t)
     key, bits, k = pack_keys(t)
     sa = np.argsort(key, kind="stable").astype(np.int64)
     skey = key[sa]
@@ -52,36 +65,65 @@ def build(text_bytes: bytes, max_rounds: int = 64, stats: dict | None = None) ->
     head[1:] = skey[1:] != skey[:-1]
     pos = np.arange(n, dtype=np.int64)
     gh = np.maximum.accumulate(np.where(head, pos, 0))          # group head slot of each slot
-    isa = np.zeros(n, dtype=np.int64)
-    isa[sa] = gh + 1                                             # ranks start at 1
     nxt = np.ones(n, dtype=bool)
     nxt[:-1] = head[1:]
     unresolved = ~(head & nxt)
     U = pos[unresolved]                                          # slots still in groups > 1
     G = gh[unresolved]
     V = sa[U]
-    h = k
-    rounds = 0
+    depth = k
+    rounds = text_rounds = 0
+
+    def refine(key2):
+        """sort the tied suffixes by (group head, key2), write them back, re-rank, keep what is still tied"""
+        nonlocal U, G, V
+        order = np.lexsort((key2, G))
+        G2, k2, V2 = G[order], key2[order], V[order]
+        sa[U] = V2
+        m = U.size
+        nh = np.ones(m, dtype=bool)
+        nh[1:] = (G2[1:] != G2[:-1]) | (k2[1:] != k2[:-1])
+        ngh = np.maximum.accumulate(np.where(nh, U, 0))
+        nn = np.ones(m, dtype=bool)
+        nn[:-1] = nh[1:]
+        keep = ~(nh & nn)
+        changed = (V2, ngh)
+        U, G, V = U[keep], ngh[keep], V2[keep]
+        return changed
+
+    # ---- text-keyed rounds: while many suffixes are tied, the secondary key is the next s symbols of
+    # the text (zero codes past the end), so no rank array is needed; depth grows by s per round
+    s_sym = _text_symbols(n, bits, se)
+    symz = np.concatenate([code[t], np.zeros(s_sym + 1, dtype=np.uint64)])
+    progressing = True
+    while U.size > n // sparse_div and text_rounds < max_text_rounds and progressing and s_sym > 0:
+        before = U.size
+        p = V + depth
+        tk = np.zeros(U.size, dtype=np.uint64)
+        for i in range(s_sym):
+            c = symz[np.minimum(p + i, n)]
+            tk = ((tk << np.uint64(bits)) | c) if bits else (tk * np.uint64(se) + c)
+        refine(tk)
+        depth += s_sym
+        text_rounds += 1
+        rounds += 1
+        progressing = U.size * 4 <= before * 3
+    # ---- prefix doubling on what is left; ranks of the current order (the device looks them up in the
+    # sorted keys / the text, or scatters a full ISA -- same values)
+    isa = np.zeros(n, dtype=np.int64)
+    isa[sa] = pos + 1                                            # resolved suffix: its slot + 1
+    isa[V] = G + 1                                               # tied suffix: slot of its group head + 1
+    h = depth
     while U.size:
         rounds += 1
         assert rounds <= max_rounds
         p = V + h
         inside = p < n
         key2 = np.where(inside, n + isa[np.minimum(p, n - 1)], n - 1 - V)   # end-of-text rule
-        order = np.lexsort((key2, G))                            # sort by (group head, key2)
-        G, key2, V = G[order], key2[order], V[order]
-        sa[U] = V
-        m = U.size
-        nh = np.ones(m, dtype=bool)
-        nh[1:] = (G[1:] != G[:-1]) | (key2[1:] != key2[:-1])
-        ngh = np.maximum.accumulate(np.where(nh, U, 0))
-        isa[V] = ngh + 1
-        nn = np.ones(m, dtype=bool)
-        nn[:-1] = nh[1:]
-        keep = ~(nh & nn)
-        U, G, V = U[keep], ngh[keep], V[keep]
+        V2, ngh = refine(key2.astype(np.int64))
+        isa[V2] = ngh + 1
         h *= 2
     if stats is not None:
-        stats.update(rounds=rounds, bits=bits, k=k)
+        stats.update(rounds=rounds, text_rounds=text_rounds, bits=bits, k=k)
     out[1:] = sa.astype(np.uint32)
     return out

@@ -87,6 +87,7 @@ static thread_local sa_amd_stats g_last_stats;
 #define PROF(cls, units, st, launch_stmt)                                                          \
     do { g_prof.begin(cls, units, st); launch_stmt; g_prof.end(st); LAUNCH_CHECK(st); } while (0)
 
+constexpr int MAX_TEXT_ROUNDS = 4;   // text-keyed rounds before falling back to rank doubling with a full ISA
 constexpr int64_t SPARSE_DIV = 64;  // sparse refinement when at most n / 64 suffixes are tied after the initial sort
 constexpr int SORT_MAX_WG = 1024;   // spine rows are scanned by one 1024-thread block
 
@@ -162,7 +163,7 @@ static SortGrid sort_grid(int64_t count)
 
 // device scratch layout for a text of n bytes
 struct Workspace {
-    uint64_t *keysA, *keysB;
+    uint64_t *keysA, *keysB, *keysC;
     uint32_t *valsA, *valsB, *isa, *U0, *U1, *G0, *G1;
     uint32_t *spine, *digit_tot, *tcnt, *thead, *hist, *total, *has_isa;
     size_t bytes;
@@ -176,6 +177,7 @@ static Workspace carve(void *base, int64_t n)
     auto take = [&](size_t b) { size_t o = off; off = align_up(off + b, 256); return (char *)base + o; };
     w.keysA = (uint64_t *)take(N * 8);
     w.keysB = (uint64_t *)take(N * 8);
+    w.keysC = (uint64_t *)take(N * 8);
     w.valsA = (uint32_t *)take(N * 4);
     w.valsB = (uint32_t *)take(N * 4);
     w.isa = (uint32_t *)take(N * 4);
@@ -355,21 +357,24 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     int64_t m = m32;
     local.unresolved_after_initial = m;
     if (getenv("SA_AMD_TIMING_ONLY_INITIAL_SORT")) m = 0;   // ablation builds produce wrong orders; stop here
-    // few tied suffixes: do not build the ISA (n random writes); ranks of untouched suffixes are
-    // looked up in the sorted initial keys instead (k_gather_key2_sparse)
-    const bool sparse = m > 0 && m <= n / SPARSE_DIV && !getenv("SA_AMD_FORCE_DENSE");
-    local.sparse_mode = sparse ? 1 : 0;
+    // 5. refinement of the tied suffixes.  Three regimes:
+    //   text rounds  while more than n / SPARSE_DIV suffixes are tied: secondary key = the next symbols of
+    //                the text itself (no rank array needed yet), depth grows by s symbols per round;
+    //   sparse       few tied suffixes: prefix doubling, ranks looked up without an ISA (k_gather_key2_sparse);
+    //   dense        prefix doubling with a full ISA (repetitive texts, or forced for A/B measurements).
+    const int key2_bits = bit_length((uint64_t)(2 * n));
+    const int g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
+    const bool force_dense = getenv("SA_AMD_FORCE_DENSE") != nullptr;
+    const bool text_ok = !force_dense && !getenv("SA_AMD_NO_TEXT_ROUNDS");
+    int64_t sparse_div = SPARSE_DIV;
+    if (const char *e = getenv("SA_AMD_SPARSE_DIV")) { sparse_div = atoll(e); if (sparse_div < 1) sparse_div = 1; }   // tests / A-B
+    const int64_t sparse_limit = n / sparse_div;
+    bool sparse = false;
+    int64_t depth = P.k;                               // symbols the current order is sorted by
     uint64_t *rkA = w.keysA, *rkB = w.keysB;          // key buffers of the refinement rounds
     const uint64_t *sorted0 = sr.keys;
-    if (m > 0 && sparse) {
-        uint64_t *other = (sr.keys == w.keysA) ? w.keysB : w.keysA;   // keep the sorted initial keys intact
-        rkA = other;
-        rkB = other + (((size_t)n / 2 + 1) & ~(size_t)1);
-        HIP_TRY(hipMemsetAsync(w.has_isa, 0, ((size_t)n + 31) / 32 * 4, st));
-        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                    sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                    SA, w.isa, Ucur, Gcur, Vcur, 0u, w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total));
-    } else if (m > 0) {
+    const bool dense_first = m > 0 && (force_dense || (!text_ok && m > sparse_limit));
+    if (m > 0 && dense_first) {
         // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
         if (binned(n, n)) {
             uint64_t *pk = (sr.keys == w.keysA) ? w.keysB : w.keysA;
@@ -384,21 +389,86 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                         SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0,
                                                         (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total));
         }
+    } else if (m > 0) {
+        // compaction only; the sorted initial keys stay intact for the rank look-ups
+        rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+        rkB = w.keysC;
+        HIP_TRY(hipMemsetAsync(w.has_isa, 0, ((size_t)n + 31) / 32 * 4, st));
+        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                    SA, w.isa, Ucur, Gcur, Vcur, 0u, w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total));
+        // ---- text-keyed rounds ----
+        int s_sym = 0, tkb = 0;
+        {
+            const int room = 64 - g_bits;                   // bits left below the group head
+            if (P.bits > 0) { s_sym = room / P.bits; tkb = s_sym * P.bits; }
+            else {
+                unsigned __int128 pw = 1;
+                while (pw * P.sigma <= ((unsigned __int128)1 << room)) { pw *= P.sigma; ++s_sym; }
+                tkb = bit_length((uint64_t)(pw - 1));
+            }
+            if (s_sym > 64) s_sym = 64;
+        }
+        bool progressing = true;     // a text round that resolves little (runs, long repeats) is the last one
+        while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < MAX_TEXT_ROUNDS && progressing) {
+            const int64_t m_before = m;
+            uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+            int64_t gblocks = ceil_div(m, GK_THREADS);
+            if (gblocks > 8192) gblocks = 8192;
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, (const uint32_t *)Gcur, dT, P, m, n, depth, s_sym, tkb, rkA));
+            rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, tkb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
+            if (rc) return rc;
+            local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m;
+            uint32_t *Vnext = (sr.vals == w.valsA) ? w.valsB : w.valsA;
+            tiles = ceil_div(m, RR_TILE);
+            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, Ucur, m,
+                                                        w.tcnt, w.thead));
+            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                        (uint32_t)n, (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                                        (const uint32_t *)w.total));
+            HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            m = m32;
+            uint32_t *t;
+            t = Ucur; Ucur = Unext; Unext = t;
+            t = Gcur; Gcur = Gnext; Gnext = t;
+            Vcur = Vnext;
+            depth += s_sym;
+            local.text_rounds++;
+            local.rounds++;
+            progressing = m * 4 <= m_before * 3;
+        }
+        if (m > sparse_limit) {
+            // still many ties (repetitive text): build the ISA of the current order and double densely
+            int64_t blocks = ceil_div(n, 256);
+            if (blocks > 16384) blocks = 16384;
+            PROF(KC_SCATTER, n, st, hipLaunchKernelGGL((k_isa_from_sa), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)SA, w.isa, n));
+            blocks = ceil_div(m, 256);
+            if (blocks > 16384) blocks = 16384;
+            PROF(KC_SCATTER, m, st, hipLaunchKernelGGL((k_isa_tied), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)Vcur,
+                                                       (const uint32_t *)Gcur, w.isa, m, n));
+        } else {
+            sparse = m > 0;
+        }
     }
+    local.sparse_mode = sparse ? 1 : 0;
 
-    // 5. prefix doubling on the tied suffixes only
-    const int key2_bits = bit_length((uint64_t)(2 * n));
-    const int g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
-    int64_t h = P.k;
+    // prefix doubling on what is still tied; `depth` symbols are sorted, so the first offset is `depth`
+    const int64_t depth_text = depth;
+    int64_t h = depth;
     while (m > 0) {
-        if (local.rounds >= 40) return SA_AMD_EINTERNAL;
+        if (local.rounds >= 48) return SA_AMD_EINTERNAL;
         uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
         int64_t gblocks = ceil_div(m, GK_THREADS);
         if (gblocks > 8192) gblocks = 8192;
         if (sparse)
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2_sparse), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, (const uint32_t *)Gcur, (const uint32_t *)w.isa,
-                                                      (const uint32_t *)w.has_isa, sorted0, dT, P, m, n, h, key2_bits, rkA));
+                                                      (const uint32_t *)w.has_isa, sorted0, (const uint32_t *)SA, dT, P, m, n, h,
+                                                      depth_text, key2_bits, rkA));
         else
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st, Vcur, Gcur,
                                                       w.isa, m, n, h, key2_bits, rkA));

@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict_
 }
 
 // ISA_MODE: 0 = scatter ISA[suffix] = rank directly, 1 = the same plus the has_isa bitmap (sparse
-// refinement), 2 = write (suffix, rank) pairs in slot order; the host bins them by suffix position
+// refinement), 3 = no rank output at all (text-keyed rounds), 2 = write (suffix, rank) pairs in slot order; the host bins them by suffix position
 // with one radix pass and k_scatter_pairs then writes the ISA window by window (a random 4-byte
 // store costs a whole 64-byte memory transaction, a binned one is merged in the caches).
 template <bool FIRST, bool WRITE_SA, int ISA_MODE>
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
             slot[r] = FIRST ? (uint32_t)i : U[i];
             v[r] = V[i];
             // refinement rounds: the key's high part is the old group head, i.e. the rank already in ISA
-            oldrank[r] = (FIRST || SPARSE) ? 0u : (uint32_t)(keys[i] >> g_shift) + 1u;
+            oldrank[r] = (FIRST || ISA_MODE != 0) ? 0u : (uint32_t)(keys[i] >> g_shift) + 1u;
         } else { slot[r] = 0; v[r] = 0; oldrank[r] = 0; }
     }
     // group-head slot (+1): running max over (head ? slot + 1 : 0), seeded by the tiles before
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
             if (ISA_MODE == 2) {
                 pair_k[i] = (uint64_t)v[r];
                 pair_v[i] = run;
-            } else if (v[r] < n_text && run != oldrank[r]) {     // the first subgroup of a split group keeps its rank
+            } else if (ISA_MODE != 3 && v[r] < n_text && run != oldrank[r]) {     // the first subgroup of a split group keeps its rank
                 ISA[v[r]] = run;
                 if (SPARSE) atomicOr(&has_isa[v[r] >> 5], 1u << (v[r] & 31u));   // this rank overrides the initial one
             }
@@ -1089,15 +1089,60 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_key2(const uint32_t *__re
     }
 }
 
-// Sparse variant (few tied suffixes after the initial sort, e.g. DNA: 2 of 2^30): no ISA is built.
-// A suffix that has been in the tied list has its current rank in ISA (has_isa bit set, written by
-// k_rr_apply); every other suffix still has the rank the initial sort gave it, which is recovered by
-// a binary search of its packed key in the sorted initial keys: rank = lower_bound + 1 = (slot of
-// its group head) + 1, the same value the dense scatter would have stored.
+// symbol code of text position pos (0 past the end: the same padding the initial keys use)
+__device__ __forceinline__ uint64_t code_at(const uint8_t *__restrict__ T, const uint8_t *lcode, int64_t n, int64_t pos)
+{
+    return pos < n ? (uint64_t)lcode[T[pos]] : 0ull;
+}
+
+// Text-keyed refinement round (used while MANY suffixes are still tied): instead of ranks -- which
+// would need the ISA, n random 4-byte writes -- the secondary key is the next `s` symbols of the text
+// itself, T[v+h .. v+h+s), packed like the initial keys into `tkb` bits below the group head.  The
+// order after the round is by h + s symbols; depth grows additively, but no rank array exists yet.
+__global__ __launch_bounds__(GK_THREADS) void k_gather_textkey(const uint32_t *__restrict__ V, const uint32_t *__restrict__ G,
+                                                                const uint8_t *__restrict__ T, KeyParams P, int64_t m, int64_t n,
+                                                                int64_t h, int s, int tkb, uint64_t *__restrict__ keys)
+{
+    __shared__ uint8_t lcode[256];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    __syncthreads();
+    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
+    const int64_t stride = (int64_t)gridDim.x * GK_THREADS;
+    for (int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x; j < m; j += stride) {
+        const int64_t p = (int64_t)V[j] + h;
+        uint64_t tk = 0;
+        if (s <= 8 && aligned8 && p + 16 <= n) {
+            // the s <= 8 bytes at p straddle at most two aligned 8-byte words: two wide loads, not s byte loads
+            const uint64_t *W = (const uint64_t *)(T + (p & ~(int64_t)7));
+            const uint64_t w0 = W[0], w1 = W[1];
+            const int sh = (int)(p & 7) * 8;
+            const uint64_t bytes = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+            for (int i = 0; i < s; ++i) {
+                const uint64_t cs = (uint64_t)lcode[(bytes >> (8 * i)) & 255u];
+                tk = P.bits > 0 ? ((tk << P.bits) | cs) : (tk * P.sigma + cs);
+            }
+        } else {
+            for (int i = 0; i < s; ++i) {
+                const uint64_t cs = code_at(T, lcode, n, p + i);
+                tk = P.bits > 0 ? ((tk << P.bits) | cs) : (tk * P.sigma + cs);
+            }
+        }
+        keys[j] = ((uint64_t)G[j] << tkb) | tk;
+    }
+}
+
+// Sparse rank lookup (few tied suffixes): no ISA is built.  rank(q) of suffix q under the current order:
+//  - q has been in the tied list of a doubling round: ISA[q] (has_isa bit set by k_rr_apply);
+//  - otherwise its rank is still what the initial sort and the text-keyed rounds gave it.  The sorted
+//    initial keys give the slot range [lo, hi) of the suffixes sharing q's first k symbols (binary
+//    search); text-keyed rounds have ordered that range by the symbols k .. depth-1, so a second binary
+//    search on those symbols (read from the text) finds the first slot of q's group.  rank = slot + 1,
+//    the value a dense ISA scatter would have stored.
 __global__ __launch_bounds__(GK_THREADS) void k_gather_key2_sparse(
     const uint32_t *__restrict__ V, const uint32_t *__restrict__ G, const uint32_t *__restrict__ ISA,
-    const uint32_t *__restrict__ has_isa, const uint64_t *__restrict__ sorted_keys, const uint8_t *__restrict__ T,
-    KeyParams P, int64_t m, int64_t n, int64_t h, int key2_bits, uint64_t *__restrict__ keys)
+    const uint32_t *__restrict__ has_isa, const uint64_t *__restrict__ sorted_keys, const uint32_t *__restrict__ SA,
+    const uint8_t *__restrict__ T, KeyParams P, int64_t m, int64_t n, int64_t h, int64_t depth, int key2_bits,
+    uint64_t *__restrict__ keys)
 {
     __shared__ uint8_t lcode[256];
     lcode[threadIdx.x] = P.code[threadIdx.x];
@@ -1114,8 +1159,7 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_key2_sparse(
         } else {
             uint64_t kq = 0;
             for (int i = 0; i < P.k; ++i) {
-                const int64_t pos = p + i;
-                const uint64_t cs = (uint64_t)(pos < n ? lcode[T[pos]] : (uint8_t)0);
+                const uint64_t cs = code_at(T, lcode, n, p + i);
                 kq = P.bits > 0 ? ((kq << P.bits) | cs) : (kq * P.sigma + cs);
             }
             int64_t lo = 0, hi = n;                      // first slot whose key is >= kq
@@ -1123,9 +1167,49 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_key2_sparse(
                 const int64_t mid = (lo + hi) >> 1;
                 if (sorted_keys[mid] < kq) lo = mid + 1; else hi = mid;
             }
+            if (depth > P.k) {
+                int64_t a = lo, b = n;                   // first slot whose key is > kq
+                while (a < b) {
+                    const int64_t mid = (a + b) >> 1;
+                    if (sorted_keys[mid] <= kq) a = mid + 1; else b = mid;
+                }
+                int64_t l2 = lo, h2 = a;                 // inside [lo, a): first slot not smaller on symbols k .. depth-1
+                while (l2 < h2) {
+                    const int64_t mid = (l2 + h2) >> 1;
+                    const int64_t sfx = (int64_t)SA[mid];
+                    bool less = false;                   // suffix at mid < q on those symbols?
+                    for (int64_t i = P.k; i < depth; ++i) {
+                        const uint64_t ca = code_at(T, lcode, n, sfx + i), cb = code_at(T, lcode, n, p + i);
+                        if (ca != cb) { less = ca < cb; break; }
+                    }
+                    if (less) l2 = mid + 1; else h2 = mid;
+                }
+                lo = l2;
+            }
             key2 = (uint64_t)n + (uint64_t)lo + 1u;
         }
         keys[j] = ((uint64_t)G[j] << key2_bits) | key2;
+    }
+}
+
+// Dense fallback after text-keyed rounds that left many suffixes tied (repetitive text): every
+// resolved suffix has rank = its slot + 1, the tied ones the slot of their group head + 1.
+__global__ __launch_bounds__(256) void k_isa_from_sa(const uint32_t *__restrict__ SA, uint32_t *__restrict__ ISA, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const uint32_t v = SA[i];
+        if ((int64_t)v < n) ISA[v] = (uint32_t)i + 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_isa_tied(const uint32_t *__restrict__ V, const uint32_t *__restrict__ G,
+                                                   uint32_t *__restrict__ ISA, int64_t m, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += stride) {
+        const uint32_t v = V[j];
+        if ((int64_t)v < n) ISA[v] = G[j] + 1u;
     }
 }
 

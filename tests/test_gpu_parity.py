@@ -235,6 +235,28 @@ def test_max_length_text():
     sa.lib().sa_amd_release_cache()
 
 
+@pytest.mark.parametrize("gen,n,seed", [("english", 400_000, 3), ("dna_repeats", 1 << 20, 5), ("periodic", 150_001, 1),
+                                        ("uniform", 300_000, 2), ("tail_zeros", 90_000, 4)])
+@pytest.mark.parametrize("div", ["1000000000", "1", None])
+def test_refinement_regimes(oracle, monkeypatch, gen, n, seed, div):
+    """text-keyed rounds followed by the dense ISA rebuild (div = 1e9: never sparse), sparse doubling
+    from the start (div = 1), and the default switch-over; all must give the oracle's array"""
+    if gen == "periodic":
+        text = np.resize(np.frombuffer(b"abcab", dtype=np.uint8), n)
+    elif gen == "tail_zeros":
+        text = np.concatenate([corpus.english(n - 5000, seed), np.zeros(5000, dtype=np.uint8)])
+    else:
+        text = getattr(corpus, gen)(n, seed)
+    if div is not None:
+        monkeypatch.setenv("SA_AMD_SPARSE_DIV", div)
+    assert np.array_equal(build(text), oracle.sais(text))
+    st = sa.last_stats()
+    if div == "1000000000" and st["unresolved_after_initial"] > 0:
+        assert st["text_rounds"] >= 1 and st["sparse_mode"] == 0
+    if div == "1" and st["unresolved_after_initial"] > 0:
+        assert st["text_rounds"] == 0 and st["sparse_mode"] == 1
+
+
 # ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------
 
 @pytest.mark.parametrize("name", ["c2_uniform_64m", "c3_english_256m"])
