@@ -46,10 +46,10 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
 enum KClass { KC_BYTE_HIST = 0, KC_BUILD_KEYS, KC_UPSWEEP, KC_SPINE, KC_DOWNSWEEP, KC_RR_COUNT, KC_RR_SCAN, KC_RR_APPLY,
-              KC_GATHER, KC_SCATTER, KC_MISC, KC_COUNT };
+              KC_GATHER, KC_SCATTER, KC_LOCAL, KC_MISC, KC_COUNT };
 static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys", "k_radix_upsweep", "k_spine_rows",
                                                     "k_radix_downsweep", "k_rr_count", "k_rr_scan", "k_rr_apply",
-                                                    "k_gather_key2", "k_scatter_pairs", "misc" };
+                                                    "k_gather_key2", "k_scatter_pairs", "k_local_window_sort", "misc" };
 struct Profiler {
     bool on = false;
     struct Rec { int cls; hipEvent_t a, b; int64_t units; };
@@ -410,6 +410,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             if (s_sym > 64) s_sym = 64;
         }
         bool progressing = true;     // a text round that resolves little (runs, long repeats) is the last one
+        bool local_ok = !getenv("SA_AMD_NO_LOCAL_SORT") && tkb <= LW_MAJOR_SHIFT;
         while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < MAX_TEXT_ROUNDS && progressing) {
             const int64_t m_before = m;
             uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
@@ -417,16 +418,56 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             if (gblocks > 8192) gblocks = 8192;
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, (const uint32_t *)Gcur, dT, P, m, n, depth, s_sym, tkb, rkA));
-            rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, tkb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
-            if (rc) return rc;
-            local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m;
-            uint32_t *Vnext = (sr.vals == w.valsA) ? w.valsB : w.valsA;
+            const uint64_t *keysS = nullptr;                  // (group, text key) pairs ordered inside every group
+            const uint32_t *valsS = nullptr;
+            uint32_t *Vnext = nullptr;
             tiles = ceil_div(m, RR_TILE);
-            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, Ucur, m,
-                                                        w.tcnt, w.thead));
+            bool done_locally = false;
+            if (local_ok) {
+                // small groups: bitonic sort in registers, window by window; the rest is flagged
+                uint8_t *flags = (uint8_t *)Gnext;
+                const int64_t waves = ceil_div(m, WAVE);
+                PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_local_window_sort), dim3((unsigned)ceil_div(waves, LW_THREADS / WAVE)),
+                                                         dim3(LW_THREADS), 0, st, rkA, Vcur, (const uint32_t *)Ucur, m, tkb, flags));
+                PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            (const uint8_t *)flags, m, w.tcnt));
+                PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+                HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                const int64_t m_big = m32;
+                const size_t half = (((size_t)n / 2 + 1) & ~(size_t)1);
+                if ((size_t)m_big <= half) {
+                    if (m_big > 0) {
+                        // groups no window owns: global sort of (group head, text key), then back to their list positions
+                        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_flag_gather), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                                    (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, m,
+                                                                    (const uint32_t *)w.tcnt, rkB, Valt, Unext));
+                        rc = sort_pairs(rkB, Valt, rkB + half, Valt + half, m_big, 0, tkb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
+                        if (rc) return rc;
+                        local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m_big;
+                        PROF(KC_SCATTER, m_big, st, hipLaunchKernelGGL((k_scatter_back), dim3((unsigned)ceil_div(m_big, 256)), dim3(256), 0, st,
+                                                                       (const uint64_t *)sr.keys, (const uint32_t *)sr.vals,
+                                                                       (const uint32_t *)Unext, m_big, rkA, Vcur));
+                    }
+                    keysS = rkA; valsS = Vcur; Vnext = Valt;
+                    done_locally = true;
+                    local.locally_sorted += m - m_big;
+                    if (m_big * 2 > m) local_ok = false;           // mostly large groups: not worth another local pass
+                }
+            }
+            if (!done_locally) {
+                rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, tkb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
+                if (rc) return rc;
+                local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m;
+                keysS = sr.keys; valsS = sr.vals;
+                Vnext = (sr.vals == w.valsA) ? w.valsB : w.valsA;
+            }
+            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS,
+                                                        (const uint32_t *)Ucur, m, w.tcnt, w.thead));
             PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                        sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                        keysS, valsS, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
+                                                        (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, Vnext,
                                                         (uint32_t)n, (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
                                                         (const uint32_t *)w.total));
             HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));

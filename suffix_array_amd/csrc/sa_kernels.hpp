@@ -1131,6 +1131,156 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_textkey(const uint32_t *_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Local refinement of the SMALL groups of a text-keyed round.  After the initial sort the tied
+// suffixes sit in millions of tiny groups (mean size 5-10 on English-like text), so a global
+// 8-pass radix sort of (group head, text key) mostly re-establishes an order it already has.
+// The tied list is in slot order with every group contiguous; one wavefront takes the 128 list
+// elements [64w, 64w + 128) (two per lane), owns the groups that START in its first 64 and END
+// inside the 128, and sorts them with a 128-element bitonic network in registers (28 compare
+// steps, shuffles only; elements it does not own are keyed by their position and do not move).
+// Offset of an element inside its group = its slot minus the group-head slot, so group starts and
+// owners are known without any scan.  Elements of groups no window owns (longer than 64..128)
+// are flagged and go through the global radix sort afterwards.
+//   keys[j] = (group head slot << tkb) | text key      (in/out, list order)
+// ------------------------------------------------------------------------------------------
+constexpr int LW_THREADS = 256;
+constexpr int LW_MAJOR_SHIFT = 57;     // 7 bits of window position above the text key (needs tkb <= 57)
+
+__device__ __forceinline__ void bitonic_cas(uint64_t &k, uint32_t &v, uint64_t ok, uint32_t ov, bool keep_min)
+{
+    const bool take = keep_min ? (ok < k) : (ok > k);
+    k = take ? ok : k;
+    v = take ? ov : v;
+}
+
+__global__ __launch_bounds__(LW_THREADS) void k_local_window_sort(uint64_t *__restrict__ keys, uint32_t *__restrict__ V,
+                                                                   const uint32_t *__restrict__ U, int64_t m, int tkb,
+                                                                   uint8_t *__restrict__ bigflag)
+{
+    const int64_t w = (int64_t)blockIdx.x * (LW_THREADS / WAVE) + wave_id();
+    const int64_t base = w * WAVE;
+    if (base >= m) return;                                   // whole waves leave together
+    const int l = lane_id();
+    const uint64_t tmask = (1ull << tkb) - 1ull;
+    uint64_t sk[2]; uint32_t sv[2], ghead[2];
+    int64_t start[2];                                        // list index where the element's group starts
+    bool valid[2], head[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int64_t j = base + 64 * r + l;
+        valid[r] = j < m;
+        const uint64_t key = valid[r] ? keys[j] : 0ull;
+        const uint32_t slot = valid[r] ? U[j] : 0u;
+        sv[r] = valid[r] ? V[j] : 0u;
+        ghead[r] = (uint32_t)(key >> tkb);
+        sk[r] = key & tmask;
+        head[r] = !valid[r] || slot == ghead[r];             // past the end counts as a boundary
+        start[r] = j - (int64_t)(slot - ghead[r]);
+    }
+    bool head_ext = true;                                    // is list index base + 128 a group boundary?
+    if (base + 128 < m) {
+        const uint64_t kx = keys[base + 128];
+        head_ext = U[base + 128] == (uint32_t)(kx >> tkb);
+    }
+    const uint64_t hm0 = __ballot(head[0]), hm1 = __ballot(head[1]);
+    const uint64_t above = (l == 63) ? 0ull : (~0ull << (l + 1));
+    // end of the element's group = next boundary after its position (relative to base; 255: not within 128)
+    int e[2];
+    {
+        const uint64_t a0 = hm0 & above, a1 = hm1 & above;
+        e[0] = a0 ? __builtin_ctzll(a0) : (hm1 ? 64 + __builtin_ctzll(hm1) : (head_ext ? 128 : 255));
+        e[1] = a1 ? 64 + __builtin_ctzll(a1) : (head_ext ? 128 : 255);
+    }
+    bool mine[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        mine[r] = valid[r] && start[r] >= base && start[r] < base + 64 && e[r] <= 128;
+        const uint64_t major = mine[r] ? (uint64_t)(start[r] - base) : (uint64_t)(64 * r + l);
+        sk[r] = (major << LW_MAJOR_SHIFT) | (mine[r] ? sk[r] : 0ull);
+    }
+    // first-half elements decide (exactly once per element) whether some window owns their group
+    if (valid[0]) {
+        bool big;
+        if (start[0] >= base) big = e[0] > 128;
+        else if (start[0] >= base - 64) big = e[0] > 64;     // owner is the previous window: its limit is base + 64
+        else big = true;
+        bigflag[base + l] = big ? 1 : 0;
+    }
+    // ---- bitonic sort of the 128 (key, suffix) pairs; position i = 64 r + lane ----
+#pragma unroll
+    for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 64) {                                    // partner is the other register of the same lane (k == 128: ascending)
+                const uint64_t k0 = sk[0], k1 = sk[1];
+                const uint32_t v0 = sv[0], v1 = sv[1];
+                if (k1 < k0) { sk[0] = k1; sv[0] = v1; sk[1] = k0; sv[1] = v0; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint64_t ok = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(sk[r] >> 32), j, WAVE) << 32) |
+                                        (uint32_t)__shfl_xor((int)(uint32_t)sk[r], j, WAVE);
+                    const uint32_t ov = (uint32_t)__shfl_xor((int)sv[r], j, WAVE);
+                    const int i = 64 * r + l;
+                    const bool asc = (i & k) == 0, lower = (l & j) == 0;
+                    bitonic_cas(sk[r], sv[r], ok, ov, asc == lower);
+                }
+            }
+        }
+    }
+    // positions inside owned groups receive the sorted pairs; the group head of a position did not change
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (mine[r]) {
+            const int64_t j = base + 64 * r + l;
+            keys[j] = ((uint64_t)ghead[r] << tkb) | (sk[r] & ((1ull << LW_MAJOR_SHIFT) - 1ull));
+            V[j] = sv[r];
+        }
+    }
+}
+
+// ---- ordered compaction of the flagged elements (those the local pass could not own) ----
+__global__ __launch_bounds__(RR_THREADS) void k_flag_count(const uint8_t *__restrict__ flag, int64_t m, uint32_t *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
+    const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) if (idx0 + r < m) c += flag[idx0 + r];
+    uint32_t tot;
+    block_excl_sum<RR_THREADS>(c, lds, &tot);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(RR_THREADS) void k_flag_gather(const uint8_t *__restrict__ flag, const uint64_t *__restrict__ keys,
+                                                             const uint32_t *__restrict__ V, int64_t m, const uint32_t *__restrict__ tile_cnt,
+                                                             uint64_t *__restrict__ bk, uint32_t *__restrict__ bv, uint32_t *__restrict__ bidx)
+{
+    __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
+    const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) if (idx0 + r < m) c += flag[idx0 + r];
+    uint32_t tot;
+    uint32_t off = tile_cnt[blockIdx.x] + block_excl_sum<RR_THREADS>(c, lds, &tot);
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t j = idx0 + r;
+        if (j < m && flag[j]) { bk[off] = keys[j]; bv[off] = V[j]; bidx[off] = (uint32_t)j; ++off; }
+    }
+}
+
+// sorted flagged elements back to their list positions (sorted by group first, and bidx is increasing,
+// so the o-th sorted element belongs at the o-th flagged position)
+__global__ __launch_bounds__(256) void k_scatter_back(const uint64_t *__restrict__ bk, const uint32_t *__restrict__ bv,
+                                                       const uint32_t *__restrict__ bidx, int64_t count, uint64_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ V)
+{
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o < count) { const uint32_t j = bidx[o]; keys[j] = bk[o]; V[j] = bv[o]; }
+}
+
 // Sparse rank lookup (few tied suffixes): no ISA is built.  rank(q) of suffix q under the current order:
 //  - q has been in the tied list of a doubling round: ISA[q] (has_isa bit set by k_rr_apply);
 //  - otherwise its rank is still what the initial sort and the text-keyed rounds gave it.  The sorted
