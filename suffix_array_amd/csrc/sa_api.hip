@@ -301,6 +301,58 @@ static int scatter_binned(uint64_t *pk, uint32_t *pv, uint64_t *altk, uint32_t *
     return SA_AMD_OK;
 }
 
+struct Refined { const uint64_t *keys; const uint32_t *vals; uint32_t *vnext; };
+
+// Orders the tied list inside every group by the low `kb` bits of its keys ((group head << kb) | key2).
+// Small groups: in-register window sort (k_local_window_sort); groups no window owns, or everything
+// when *local_ok is off: the global radix sort.  scratchU / scratchG: two free 4n-byte buffers.
+static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *Valt, const uint32_t *Ucur, uint32_t *scratchU,
+                       uint32_t *scratchG, int64_t m, int64_t n, int kb, int g_bits, bool *local_ok, const Workspace &w,
+                       hipStream_t st, sa_amd_stats *local, Refined *out)
+{
+    const int64_t tiles = ceil_div(m, RR_TILE);
+    SortResult sr;
+    int rc;
+    if (*local_ok && kb <= LW_MAJOR_SHIFT) {
+        uint8_t *flags = (uint8_t *)scratchG;
+        const int64_t waves = ceil_div(m, WAVE);
+        PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_local_window_sort), dim3((unsigned)ceil_div(waves, LW_THREADS / WAVE)),
+                                                 dim3(LW_THREADS), 0, st, rkA, Vcur, Ucur, m, kb, flags));
+        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    (const uint8_t *)flags, m, w.tcnt));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+        uint32_t big32 = 0;
+        HIP_TRY(hipMemcpyAsync(&big32, w.total, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int64_t m_big = big32;
+        const size_t half = (((size_t)n / 2 + 1) & ~(size_t)1);
+        if ((size_t)m_big <= half) {
+            if (m_big > 0) {
+                // groups no window owns: global sort of (group head, key2), then back to their list positions
+                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_flag_gather), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, m,
+                                                            (const uint32_t *)w.tcnt, rkB, Valt, scratchU));
+                rc = sort_pairs(rkB, Valt, rkB + half, Valt + half, m_big, 0, kb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
+                if (rc) return rc;
+                local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m_big;
+                PROF(KC_SCATTER, m_big, st, hipLaunchKernelGGL((k_scatter_back), dim3((unsigned)ceil_div(m_big, 256)), dim3(256), 0, st,
+                                                               (const uint64_t *)sr.keys, (const uint32_t *)sr.vals,
+                                                               (const uint32_t *)scratchU, m_big, rkA, Vcur));
+            }
+            out->keys = rkA; out->vals = Vcur; out->vnext = Valt;
+            local->locally_sorted += m - m_big;
+            if (m_big * 2 > m) *local_ok = false;           // mostly large groups: not worth another local pass
+            return SA_AMD_OK;
+        }
+    }
+    rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, kb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
+    if (rc) return rc;
+    local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m;
+    out->keys = sr.keys; out->vals = sr.vals;
+    out->vnext = (sr.vals == Vcur) ? Valt : Vcur;
+    return SA_AMD_OK;
+}
+
 static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWork, int64_t work_bytes, hipStream_t st,
                         sa_amd_stats *stats)
 {
@@ -333,11 +385,44 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     const int key_bits = make_key_params(hist, &P, &sigma);
     local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
 
-    // 2. packed keys, 3. initial sort
+    const int g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
+    const bool force_dense = getenv("SA_AMD_FORCE_DENSE") != nullptr;
+    const bool text_ok = !force_dense && !getenv("SA_AMD_NO_TEXT_ROUNDS");
+    bool local_ok = !getenv("SA_AMD_NO_LOCAL_SORT");
+
+    // 2. entropy probe: do the top 32 key bits already separate (almost) all suffixes?  Then the initial
+    //    sort only needs those 4 digits and a cheap round on the low bits finishes the few ties.
+    int top_shift = 0;
+    if (text_ok && local_ok && key_bits > 32 && !getenv("SA_AMD_NO_TOP32")) {
+        bool use = getenv("SA_AMD_FORCE_TOP32") != nullptr;
+        if (!use && n >= ((int64_t)1 << 24)) {
+            const int64_t S = (int64_t)1 << 20;
+            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_keys), dim3((unsigned)ceil_div(S, GK_THREADS)), dim3(GK_THREADS), 0, st, dT, P, n, S,
+                                                    key_bits - 32, w.keysA));
+            SortResult ss;
+            int rcs = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, S, 32, 64, w.spine, w.digit_tot, nullptr, st, &ss);
+            if (rcs) return rcs;
+            local.sort_passes += ss.passes; local.sorted_elements += (int64_t)ss.passes * S;
+            HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
+            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, st,
+                                                    (const uint64_t *)ss.keys, S, w.total));
+            uint32_t dups = 0;
+            HIP_TRY(hipMemcpyAsync(&dups, w.total, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            // adjacent duplicates of a sorted sample under-count pairs only when runs are long, which is the
+            // "do not" case anyway; expected number of other suffixes sharing the top bits with a given one:
+            const double q = 2.0 * (double)dups / ((double)S * (double)S);
+            use = (double)n * q < 0.5;
+        }
+        if (use) top_shift = key_bits - 32;
+    }
+    local.top32_first = top_shift ? 1 : 0;
+
+    // 3. packed keys, 4. initial sort (all key bits, or the top 32 only)
     PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P, w.keysA,
                        w.valsA));
     SortResult sr;
-    int rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr);
+    int rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, top_shift, key_bits, w.spine, w.digit_tot, SA, st, &sr);
     if (rc) return rc;
     local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
     if (sr.vals != SA) {   // n == 1: no pass ran, the values are still in the input buffer
@@ -349,7 +434,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     uint32_t *Vcur = w.valsA;
     int64_t tiles = ceil_div(n, RR_TILE);
     PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys,
-                                                (const uint32_t *)nullptr, n, w.tcnt, w.thead));
+                                                (const uint32_t *)nullptr, n, w.tcnt, w.thead, top_shift));
     PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
     uint32_t m32 = 0;
     HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
@@ -357,46 +442,83 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     int64_t m = m32;
     local.unresolved_after_initial = m;
     if (getenv("SA_AMD_TIMING_ONLY_INITIAL_SORT")) m = 0;   // ablation builds produce wrong orders; stop here
+    uint64_t *rkA = w.keysA, *rkB = w.keysB;          // key buffers of the refinement rounds
+    uint64_t *sorted0 = sr.keys;                      // the initial keys in SA order (kept for the rank look-ups)
+    bool lists_ready = false;                         // (Ucur, Gcur, Vcur) already hold the tied suffixes
+    if (top_shift && m > 0) {
+        // finish the initial sort: the suffixes tied on the top 32 bits are ordered by their low key bits
+        rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+        rkB = w.keysC;
+        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    (const uint64_t *)sorted0, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
+                                                    (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
+                                                    w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total,
+                                                    top_shift));
+        PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_lowkey), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st,
+                                                  (const uint32_t *)Ucur, (const uint32_t *)Gcur, (const uint64_t *)sorted0, m, top_shift, rkA));
+        uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+        Refined rf;
+        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Unext, Gnext, m, n, top_shift, g_bits, &local_ok, w, st, &local, &rf);
+        if (rc) return rc;
+        PROF(KC_SCATTER, m, st, hipLaunchKernelGGL((k_fix_lowkeys), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st,
+                                                   (const uint32_t *)Ucur, rf.keys, m, top_shift, sorted0));
+        tiles = ceil_div(m, RR_TILE);
+        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rf.keys,
+                                                    (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    rf.keys, rf.vals, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
+                                                    (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, rf.vnext, (uint32_t)n,
+                                                    (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                                    (const uint32_t *)w.total, 0));
+        HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        m = m32;
+        uint32_t *t;
+        t = Ucur; Ucur = Unext; Unext = t;
+        t = Gcur; Gcur = Gnext; Gnext = t;
+        Vcur = rf.vnext;
+        lists_ready = true;
+        local.unresolved_after_initial = m;           // now: tied on the whole 64-bit key, as after a full sort
+    }
     // 5. refinement of the tied suffixes.  Three regimes:
     //   text rounds  while more than n / SPARSE_DIV suffixes are tied: secondary key = the next symbols of
     //                the text itself (no rank array needed yet), depth grows by s symbols per round;
     //   sparse       few tied suffixes: prefix doubling, ranks looked up without an ISA (k_gather_key2_sparse);
     //   dense        prefix doubling with a full ISA (repetitive texts, or forced for A/B measurements).
     const int key2_bits = bit_length((uint64_t)(2 * n));
-    const int g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
-    const bool force_dense = getenv("SA_AMD_FORCE_DENSE") != nullptr;
-    const bool text_ok = !force_dense && !getenv("SA_AMD_NO_TEXT_ROUNDS");
     int64_t sparse_div = SPARSE_DIV;
     if (const char *e = getenv("SA_AMD_SPARSE_DIV")) { sparse_div = atoll(e); if (sparse_div < 1) sparse_div = 1; }   // tests / A-B
     const int64_t sparse_limit = n / sparse_div;
     bool sparse = false;
     int64_t depth = P.k;                               // symbols the current order is sorted by
-    uint64_t *rkA = w.keysA, *rkB = w.keysB;          // key buffers of the refinement rounds
-    const uint64_t *sorted0 = sr.keys;
-    const bool dense_first = m > 0 && (force_dense || (!text_ok && m > sparse_limit));
+    const bool dense_first = m > 0 && !lists_ready && (force_dense || (!text_ok && m > sparse_limit));
     if (m > 0 && dense_first) {
         // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
         if (binned(n, n)) {
             uint64_t *pk = (sr.keys == w.keysA) ? w.keysB : w.keysA;
             PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total));
+                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total, 0));
             rc = scatter_binned(pk, w.U1, sr.keys, w.G1, n, n, w, st, &local);
             if (rc) return rc;
         } else {
             PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
                                                         SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0,
-                                                        (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total));
+                                                        (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
         }
     } else if (m > 0) {
         // compaction only; the sorted initial keys stay intact for the rank look-ups
-        rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
-        rkB = w.keysC;
         HIP_TRY(hipMemsetAsync(w.has_isa, 0, ((size_t)n + 31) / 32 * 4, st));
-        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                    sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                    SA, w.isa, Ucur, Gcur, Vcur, 0u, w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total));
+        if (!lists_ready) {
+            rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+            rkB = w.keysC;
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        (const uint64_t *)sorted0, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
+                                                        (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
+                                                        w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+        }
         // ---- text-keyed rounds ----
         int s_sym = 0, tkb = 0;
         {
@@ -410,7 +532,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             if (s_sym > 64) s_sym = 64;
         }
         bool progressing = true;     // a text round that resolves little (runs, long repeats) is the last one
-        bool local_ok = !getenv("SA_AMD_NO_LOCAL_SORT") && tkb <= LW_MAJOR_SHIFT;
+
         while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < MAX_TEXT_ROUNDS && progressing) {
             const int64_t m_before = m;
             uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
@@ -418,58 +540,21 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             if (gblocks > 8192) gblocks = 8192;
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, (const uint32_t *)Gcur, dT, P, m, n, depth, s_sym, tkb, rkA));
-            const uint64_t *keysS = nullptr;                  // (group, text key) pairs ordered inside every group
-            const uint32_t *valsS = nullptr;
-            uint32_t *Vnext = nullptr;
+            Refined rf;
+            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Unext, Gnext, m, n, tkb, g_bits, &local_ok, w, st, &local, &rf);
+            if (rc) return rc;
+            const uint64_t *keysS = rf.keys;                  // (group, text key) pairs ordered inside every group
+            const uint32_t *valsS = rf.vals;
+            uint32_t *Vnext = rf.vnext;
             tiles = ceil_div(m, RR_TILE);
-            bool done_locally = false;
-            if (local_ok) {
-                // small groups: bitonic sort in registers, window by window; the rest is flagged
-                uint8_t *flags = (uint8_t *)Gnext;
-                const int64_t waves = ceil_div(m, WAVE);
-                PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_local_window_sort), dim3((unsigned)ceil_div(waves, LW_THREADS / WAVE)),
-                                                         dim3(LW_THREADS), 0, st, rkA, Vcur, (const uint32_t *)Ucur, m, tkb, flags));
-                PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                            (const uint8_t *)flags, m, w.tcnt));
-                PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-                HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                const int64_t m_big = m32;
-                const size_t half = (((size_t)n / 2 + 1) & ~(size_t)1);
-                if ((size_t)m_big <= half) {
-                    if (m_big > 0) {
-                        // groups no window owns: global sort of (group head, text key), then back to their list positions
-                        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_flag_gather), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                                    (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, m,
-                                                                    (const uint32_t *)w.tcnt, rkB, Valt, Unext));
-                        rc = sort_pairs(rkB, Valt, rkB + half, Valt + half, m_big, 0, tkb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
-                        if (rc) return rc;
-                        local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m_big;
-                        PROF(KC_SCATTER, m_big, st, hipLaunchKernelGGL((k_scatter_back), dim3((unsigned)ceil_div(m_big, 256)), dim3(256), 0, st,
-                                                                       (const uint64_t *)sr.keys, (const uint32_t *)sr.vals,
-                                                                       (const uint32_t *)Unext, m_big, rkA, Vcur));
-                    }
-                    keysS = rkA; valsS = Vcur; Vnext = Valt;
-                    done_locally = true;
-                    local.locally_sorted += m - m_big;
-                    if (m_big * 2 > m) local_ok = false;           // mostly large groups: not worth another local pass
-                }
-            }
-            if (!done_locally) {
-                rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, tkb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
-                if (rc) return rc;
-                local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m;
-                keysS = sr.keys; valsS = sr.vals;
-                Vnext = (sr.vals == w.valsA) ? w.valsB : w.valsA;
-            }
             PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS,
-                                                        (const uint32_t *)Ucur, m, w.tcnt, w.thead));
+                                                        (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0));
             PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         keysS, valsS, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
                                                         (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, Vnext,
                                                         (uint32_t)n, (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
-                                                        (const uint32_t *)w.total));
+                                                        (const uint32_t *)w.total, 0));
             HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             m = m32;
@@ -508,7 +593,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         if (sparse)
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2_sparse), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, (const uint32_t *)Gcur, (const uint32_t *)w.isa,
-                                                      (const uint32_t *)w.has_isa, sorted0, (const uint32_t *)SA, dT, P, m, n, h,
+                                                      (const uint32_t *)w.has_isa, (const uint64_t *)sorted0, (const uint32_t *)SA, dT, P, m, n, h,
                                                       depth_text, key2_bits, rkA));
         else
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st, Vcur, Gcur,
@@ -519,25 +604,25 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         uint32_t *Vnext = (sr.vals == w.valsA) ? w.valsB : w.valsA;
         tiles = ceil_div(m, RR_TILE);
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys, Ucur, m, w.tcnt,
-                           w.thead));
+                           w.thead, 0));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
         if (sparse) {
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total));
+                                                        (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
         } else if (binned(n, m)) {
             // Gcur has been consumed by the gather, the other key buffer by nothing: they take the pairs
             uint64_t *pk = (sr.keys == rkA) ? rkB : rkA;
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total));
+                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total, 0));
             rc = scatter_binned(pk, Gcur, sr.keys, sr.vals, m, n, w, st, &local);
             if (rc) return rc;
         } else {
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, sr.vals, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
                                                         (uint32_t)n, (uint32_t *)nullptr, key2_bits, (uint64_t *)nullptr,
-                                                        (uint32_t *)nullptr, (const uint32_t *)w.total));
+                                                        (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
         }
         HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

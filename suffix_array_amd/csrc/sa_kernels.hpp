@@ -922,13 +922,13 @@ struct RRFlags {
 };
 
 // loads the thread's RR_ITEMS keys (blocked) and classifies them; idx0 = first element index
-__device__ __forceinline__ RRFlags rr_classify(const uint64_t *__restrict__ keys, int64_t m, int64_t idx0)
+__device__ __forceinline__ RRFlags rr_classify(const uint64_t *__restrict__ keys, int64_t m, int64_t idx0, int key_shift)
 {
     uint64_t k[RR_ITEMS + 2];
 #pragma unroll
     for (int r = 0; r < RR_ITEMS + 2; ++r) {
         const int64_t i = idx0 - 1 + r;
-        k[r] = (i >= 0 && i < m) ? keys[i] : 0;
+        k[r] = (i >= 0 && i < m) ? (keys[i] >> key_shift) : 0;      // groups are runs of equal key >> key_shift
     }
     RRFlags f; f.head = 0; f.tied = 0;
     uint32_t headx = 0;   // bit r: element idx0 - 1 + r starts a group (r in 1..RR_ITEMS+1)
@@ -954,11 +954,11 @@ template <bool FIRST>
 __global__ __launch_bounds__(RR_THREADS) void k_rr_count(const uint64_t *__restrict__ keys,
                                                           const uint32_t *__restrict__ U, int64_t m,
                                                           uint32_t *__restrict__ tile_cnt,
-                                                          uint32_t *__restrict__ tile_head)
+                                                          uint32_t *__restrict__ tile_head, int key_shift)
 {
     __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
     const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
-    const RRFlags f = rr_classify(keys, m, idx0);
+    const RRFlags f = rr_classify(keys, m, idx0, key_shift);
     uint32_t cnt = (uint32_t)__popc(f.tied);
     uint32_t lasthead = 0;
     if (f.head) {
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_head, uint32_t *__restrict__ SA,
     uint32_t *__restrict__ ISA, uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo,
     uint32_t n_text, uint32_t *__restrict__ has_isa, int g_shift, uint64_t *__restrict__ pair_k,
-    uint32_t *__restrict__ pair_v, const uint32_t *__restrict__ tile_total)
+    uint32_t *__restrict__ pair_v, const uint32_t *__restrict__ tile_total, int key_shift)
 {
     constexpr bool SPARSE = ISA_MODE == 1;
     __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         if (next == here) return;
     }
     const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
-    const RRFlags f = rr_classify(keys, m, idx0);
+    const RRFlags f = rr_classify(keys, m, idx0, key_shift);
     uint32_t slot[RR_ITEMS], v[RR_ITEMS], oldrank[RR_ITEMS];
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
@@ -1279,6 +1279,60 @@ __global__ __launch_bounds__(256) void k_scatter_back(const uint64_t *__restrict
 {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o < count) { const uint32_t j = bidx[o]; keys[j] = bk[o]; V[j] = bv[o]; }
+}
+
+// ---- entropy probe + two-stage initial sort ---------------------------------------------------
+// When the top 32 bits of the packed key already separate almost all suffixes (random bytes, DNA),
+// the initial sort only needs those 4 digits; the few ties are finished by a refinement round on the
+// low key bits (in-register window sort).  Whether that holds is measured, not assumed: the keys of
+// SAMPLE pseudo-random suffixes are sorted and their duplicates counted (a word-structured text looks
+// harmless under an iid model but is not).
+__global__ __launch_bounds__(GK_THREADS) void k_sample_keys(const uint8_t *__restrict__ T, KeyParams P, int64_t n, int64_t samples,
+                                                             int top_shift, uint64_t *__restrict__ out)
+{
+    __shared__ uint8_t lcode[256];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x;
+    if (i >= samples) return;
+    const uint64_t r = ((uint64_t)i + 1u) * 0x9E3779B97F4A7C15ull;
+    const int64_t p = (int64_t)((r >> 11) % (uint64_t)n);
+    uint64_t kq = 0;
+    for (int j = 0; j < P.k; ++j) {
+        const uint64_t cs = code_at(T, lcode, n, p + j);
+        kq = P.bits > 0 ? ((kq << P.bits) | cs) : (kq * P.sigma + cs);
+    }
+    out[i] = ((kq >> top_shift) << 32) | (uint64_t)(uint32_t)p;      // position in the low half: equal positions are not collisions
+}
+
+__global__ __launch_bounds__(256) void k_count_sample_dups(const uint64_t *__restrict__ sorted, int64_t samples, uint32_t *__restrict__ dups)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool d = false;
+    if (i > 0 && i < samples) d = (sorted[i] >> 32) == (sorted[i - 1] >> 32) && (uint32_t)sorted[i] != (uint32_t)sorted[i - 1];
+    const uint64_t b = __ballot(d);
+    if (b && lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(dups, (uint32_t)__popcll(b));
+}
+
+// secondary key of the round that finishes a top-bits initial sort: the low bits of the suffix's own key
+__global__ __launch_bounds__(256) void k_gather_lowkey(const uint32_t *__restrict__ U, const uint32_t *__restrict__ G,
+                                                        const uint64_t *__restrict__ sorted_keys, int64_t m, int low_bits,
+                                                        uint64_t *__restrict__ keys)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < m) keys[j] = ((uint64_t)G[j] << low_bits) | (sorted_keys[U[j]] & ((1ull << low_bits) - 1ull));
+}
+
+// ... and afterwards the sorted-keys array gets the low bits in their new order (the top bits of a slot did not change)
+__global__ __launch_bounds__(256) void k_fix_lowkeys(const uint32_t *__restrict__ U, const uint64_t *__restrict__ list_keys, int64_t m,
+                                                      int low_bits, uint64_t *__restrict__ sorted_keys)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < m) {
+        const uint64_t lm = (1ull << low_bits) - 1ull;
+        const uint32_t slot = U[j];
+        sorted_keys[slot] = (sorted_keys[slot] & ~lm) | (list_keys[j] & lm);
+    }
 }
 
 // Sparse rank lookup (few tied suffixes): no ISA is built.  rank(q) of suffix q under the current order:

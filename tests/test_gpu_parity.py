@@ -257,6 +257,26 @@ def test_refinement_regimes(oracle, monkeypatch, gen, n, seed, div):
         assert st["text_rounds"] == 0 and st["sparse_mode"] == 1
 
 
+@pytest.mark.parametrize("gen,n,seed", [("uniform", 500_000, 2), ("dna", 1 << 20, 4), ("english", 300_000, 3),
+                                        ("dna_repeats", 400_000, 5), ("periodic", 100_001, 1), ("sigma2", 250_000, 7)])
+def test_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed):
+    """initial sort on the top 32 key bits only, ties finished on the low bits (normally chosen by the
+    entropy probe for large high-entropy texts; forced here), with and without the window sort"""
+    if gen == "periodic":
+        text = np.resize(np.frombuffer(b"abcab", dtype=np.uint8), n)
+    elif gen == "sigma2":
+        text = corpus.sigma(n, seed, 2, 120)
+    else:
+        text = getattr(corpus, gen)(n, seed)
+    exp = oracle.sais(text)
+    monkeypatch.setenv("SA_AMD_FORCE_TOP32", "1")
+    assert np.array_equal(build(text), exp)
+    assert sa.last_stats()["top32_first"] == 1
+    monkeypatch.setenv("SA_AMD_NO_LOCAL_SORT", "1")      # the probe path is off without the local sort
+    assert np.array_equal(build(text), exp)
+    assert sa.last_stats()["top32_first"] == 0
+
+
 # ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------
 
 @pytest.mark.parametrize("name", ["c2_uniform_64m", "c3_english_256m"])
