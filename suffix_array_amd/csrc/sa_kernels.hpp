@@ -916,38 +916,52 @@ constexpr int RR_THREADS = 1024;
 constexpr int RR_ITEMS = 8;
 constexpr int RR_TILE = RR_THREADS * RR_ITEMS;   // 8192
 
-struct RRFlags {
-    uint32_t head;   // bit r: element r starts a group
-    uint32_t tied;   // bit r: element r is in a group of size > 1
-};
+constexpr int RR_WAVE_ELEMS = WAVE * RR_ITEMS;   // 512 consecutive elements per wave, item r of lane l = base + 64 r + l
 
-// loads the thread's RR_ITEMS keys (blocked) and classifies them; idx0 = first element index
-__device__ __forceinline__ RRFlags rr_classify(const uint64_t *__restrict__ keys, int64_t m, int64_t idx0, int key_shift)
+// Head / tied masks of one wave's 512 elements.  Loads are wave-striped (512 contiguous bytes per
+// instruction); the neighbour keys come from shuffles, so the whole classification is 8 ballots
+// and scalar bit arithmetic: head[r] bit l = element (r, l) starts a group, tied[r] bit l = it is
+// in a group of more than one element, valid[r] = it exists.
+struct WaveGroups { uint64_t head[RR_ITEMS], tied[RR_ITEMS], valid[RR_ITEMS]; };
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 {
-    uint64_t k[RR_ITEMS + 2];
-#pragma unroll
-    for (int r = 0; r < RR_ITEMS + 2; ++r) {
-        const int64_t i = idx0 - 1 + r;
-        k[r] = (i >= 0 && i < m) ? (keys[i] >> key_shift) : 0;      // groups are runs of equal key >> key_shift
-    }
-    RRFlags f; f.head = 0; f.tied = 0;
-    uint32_t headx = 0;   // bit r: element idx0 - 1 + r starts a group (r in 1..RR_ITEMS+1)
-#pragma unroll
-    for (int r = 1; r <= RR_ITEMS + 1; ++r) {
-        const int64_t i = idx0 - 1 + r;
-        const bool h = (i == 0) || (i >= m) || (k[r] != k[r - 1]);
-        headx |= (uint32_t)h << r;
-    }
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, WAVE);
+}
+
+__device__ __forceinline__ WaveGroups rr_wave_classify(const uint64_t *__restrict__ keys, int64_t m, int64_t wbase, int key_shift)
+{
+    const int l = lane_id();
+    uint64_t k[RR_ITEMS];
+    WaveGroups g;
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
-        const int64_t i = idx0 + r;
-        if (i < m) {
-            const bool h = (headx >> (r + 1)) & 1u, hn = (headx >> (r + 2)) & 1u;
-            f.head |= (uint32_t)h << r;
-            f.tied |= (uint32_t)(!(h && hn)) << r;
-        }
+        const int64_t i = wbase + 64 * r + l;
+        k[r] = i < m ? (keys[i] >> key_shift) : 0ull;           // groups are runs of equal key >> key_shift
+        g.valid[r] = __ballot(i < m);
     }
-    return f;
+    const uint64_t before = (wbase > 0 && wbase - 1 < m) ? (keys[wbase - 1] >> key_shift) : 0ull;
+    const uint64_t after = (wbase + RR_WAVE_ELEMS < m) ? (keys[wbase + RR_WAVE_ELEMS] >> key_shift) : 0ull;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        uint64_t up = shfl64(k[r], l ? l - 1 : 0);
+        const uint64_t prev_last = r ? shfl64(k[r ? r - 1 : 0], 63) : before;   // executed by every lane (no shuffle under divergence)
+        if (l == 0) up = prev_last;
+        const int64_t i = wbase + 64 * r + l;
+        g.head[r] = __ballot(i < m && (i == 0 || k[r] != up));
+    }
+    const uint64_t last_key = shfl64(k[RR_ITEMS - 1], 63);
+    const bool boundary_after = (wbase + RR_WAVE_ELEMS >= m) || after != last_key;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        // is the NEXT element a group boundary (a head, or past the end)?
+        const uint64_t bnd = g.head[r] | ~g.valid[r];
+        const uint64_t bnd_next0 = (r + 1 < RR_ITEMS) ? ((g.head[(r + 1) % RR_ITEMS] | ~g.valid[(r + 1) % RR_ITEMS]) & 1ull)
+                                                      : (boundary_after ? 1ull : 0ull);
+        const uint64_t next = (bnd >> 1) | (bnd_next0 << 63);
+        g.tied[r] = g.valid[r] & ~(g.head[r] & next);
+    }
+    return g;
 }
 
 template <bool FIRST>
@@ -956,19 +970,26 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_count(const uint64_t *__restr
                                                           uint32_t *__restrict__ tile_cnt,
                                                           uint32_t *__restrict__ tile_head, int key_shift)
 {
-    __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
-    const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
-    const RRFlags f = rr_classify(keys, m, idx0, key_shift);
-    uint32_t cnt = (uint32_t)__popc(f.tied);
-    uint32_t lasthead = 0;
-    if (f.head) {
-        const int r = 31 - __clz((int)f.head);
-        lasthead = (FIRST ? (uint32_t)(idx0 + r) : U[idx0 + r]) + 1u;
+    __shared__ uint32_t wcnt[RR_THREADS / WAVE], whead[RR_THREADS / WAVE];
+    const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)wave_id() * RR_WAVE_ELEMS;
+    const WaveGroups g = rr_wave_classify(keys, m, wbase, key_shift);
+    uint32_t cnt = 0, lasthead = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        cnt += (uint32_t)__popcll(g.tied[r]);
+        if (g.head[r]) {
+            const int64_t i = wbase + 64 * r + (63 - __builtin_clzll(g.head[r]));
+            lasthead = (FIRST ? (uint32_t)i : U[i]) + 1u;       // slots grow with the index: the last head wins
+        }
     }
-    uint32_t tot, mx;
-    block_excl_sum<RR_THREADS>(cnt, lds, &tot);
-    block_incl_max<RR_THREADS>(lasthead, lds, &mx);
-    if (threadIdx.x == 0) { tile_cnt[blockIdx.x] = tot; tile_head[blockIdx.x] = mx; }
+    if (lane_id() == 0) { wcnt[wave_id()] = cnt; whead[wave_id()] = lasthead; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0, mx = 0;
+        for (int w = 0; w < RR_THREADS / WAVE; ++w) { tot += wcnt[w]; mx = mx > whead[w] ? mx : whead[w]; }
+        tile_cnt[blockIdx.x] = tot;
+        tile_head[blockIdx.x] = mx;
+    }
 }
 
 // one workgroup: tile_cnt -> exclusive sums (+ total), tile_head -> exclusive running max
@@ -1014,55 +1035,67 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     uint32_t *__restrict__ pair_v, const uint32_t *__restrict__ tile_total, int key_shift)
 {
     constexpr bool SPARSE = ISA_MODE == 1;
-    __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
+    constexpr int NW = RR_THREADS / WAVE;
+    __shared__ uint32_t wcnt[NW], whead[NW];
     if (FIRST && !WRITE_SA && SPARSE) {
         // compaction-only pass (no SA, no ISA write): a tile without tied suffixes has nothing to do
         const uint32_t here = tile_cnt[blockIdx.x];
         const uint32_t next = (blockIdx.x + 1 < gridDim.x) ? tile_cnt[blockIdx.x + 1] : *tile_total;
         if (next == here) return;
     }
-    const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
-    const RRFlags f = rr_classify(keys, m, idx0, key_shift);
-    uint32_t slot[RR_ITEMS], v[RR_ITEMS], oldrank[RR_ITEMS];
+    const int l = lane_id(), w = wave_id();
+    const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)w * RR_WAVE_ELEMS;
+    const WaveGroups g = rr_wave_classify(keys, m, wbase, key_shift);
+    uint32_t slot[RR_ITEMS], v[RR_ITEMS];
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
-        const int64_t i = idx0 + r;
-        if (i < m) {
-            slot[r] = FIRST ? (uint32_t)i : U[i];
-            v[r] = V[i];
-            // refinement rounds: the key's high part is the old group head, i.e. the rank already in ISA
-            oldrank[r] = (FIRST || ISA_MODE != 0) ? 0u : (uint32_t)(keys[i] >> g_shift) + 1u;
-        } else { slot[r] = 0; v[r] = 0; oldrank[r] = 0; }
+        const int64_t i = wbase + 64 * r + l;
+        const bool in = i < m;
+        slot[r] = FIRST ? (uint32_t)i : (in ? U[i] : 0u);
+        v[r] = in ? V[i] : 0u;
     }
-    // group-head slot (+1): running max over (head ? slot + 1 : 0), seeded by the tiles before
-    uint32_t lasthead = 0;
-    if (f.head) lasthead = slot[31 - __clz((int)f.head)] + 1u;
-    uint32_t dummy;
-    uint32_t incm = block_incl_max<RR_THREADS>(lasthead, lds, &dummy);
-    uint32_t prevm = __shfl_up(incm, 1, WAVE);
-    __shared__ uint32_t wlast[RR_THREADS / WAVE];
-    if (lane_id() == WAVE - 1) wlast[wave_id()] = incm;
+    // this wave's totals -> offsets of the waves of the tile
+    {
+        uint32_t cnt = 0, lasthead = 0;
+#pragma unroll
+        for (int r = 0; r < RR_ITEMS; ++r) {
+            cnt += (uint32_t)__popcll(g.tied[r]);
+            if (g.head[r]) lasthead = (uint32_t)__shfl((int)slot[r], 63 - __builtin_clzll(g.head[r]), WAVE) + 1u;
+        }
+        if (l == 0) { wcnt[w] = cnt; whead[w] = lasthead; }
+    }
     __syncthreads();
-    if (lane_id() == 0) prevm = wave_id() ? wlast[wave_id() - 1] : 0u;
-    const uint32_t carry = tile_head[blockIdx.x];
-    uint32_t run = prevm > carry ? prevm : carry;
-    uint32_t tot;
-    uint32_t off = tile_cnt[blockIdx.x] + block_excl_sum<RR_THREADS>((uint32_t)__popc(f.tied), lds, &tot);
+    uint32_t run_cnt = tile_cnt[blockIdx.x], run_head = tile_head[blockIdx.x];     // carried in from the tiles before
+    for (int ww = 0; ww < w; ++ww) { run_cnt += wcnt[ww]; run_head = run_head > whead[ww] ? run_head : whead[ww]; }
+    const uint64_t le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);              // lanes <= l
+    const uint64_t lt_mask = le_mask >> 1;                                          // lanes <  l
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
-        const int64_t i = idx0 + r;
+        const int64_t i = wbase + 64 * r + l;
+        // rank = (slot of the group's first element) + 1: the last head at or before this lane, else the carry
+        const uint64_t hle = g.head[r] & le_mask;
+        const int src = hle ? 63 - __builtin_clzll(hle) : 0;
+        const uint32_t hslot = (uint32_t)__shfl((int)slot[r], src, WAVE);
+        const uint32_t run = hle ? hslot + 1u : run_head;
+        const uint32_t off = run_cnt + (uint32_t)__popcll(g.tied[r] & lt_mask);
         if (i < m) {
-            if ((f.head >> r) & 1u) run = slot[r] + 1u;
             if (WRITE_SA && slot[r] < n_text) SA[slot[r]] = v[r];
             if (ISA_MODE == 2) {
                 pair_k[i] = (uint64_t)v[r];
                 pair_v[i] = run;
-            } else if (ISA_MODE != 3 && v[r] < n_text && run != oldrank[r]) {     // the first subgroup of a split group keeps its rank
-                ISA[v[r]] = run;
-                if (SPARSE) atomicOr(&has_isa[v[r] >> 5], 1u << (v[r] & 31u));   // this rank overrides the initial one
+            } else if (ISA_MODE != 3 && v[r] < n_text) {
+                // refinement rounds: the key's high part is the old group head, i.e. the rank already in ISA;
+                // the first subgroup of a split group keeps its rank and is not rewritten
+                const uint32_t oldrank = (FIRST || ISA_MODE != 0) ? 0u : (uint32_t)(keys[i] >> g_shift) + 1u;
+                if (run != oldrank) {
+                    ISA[v[r]] = run;
+                    if (SPARSE) atomicOr(&has_isa[v[r] >> 5], 1u << (v[r] & 31u));   // this rank overrides the initial one
+                }
             }
-            if ((f.tied >> r) & 1u) { Uo[off] = slot[r]; Go[off] = run - 1u; Vo[off] = v[r]; ++off; }
+            if ((g.tied[r] >> l) & 1ull) { Uo[off] = slot[r]; Go[off] = run - 1u; Vo[off] = v[r]; }
         }
+        run_cnt += (uint32_t)__popcll(g.tied[r]);
+        if (g.head[r]) run_head = (uint32_t)__shfl((int)slot[r], 63 - __builtin_clzll(g.head[r]), WAVE) + 1u;
     }
 }
 
