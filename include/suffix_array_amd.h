@@ -150,6 +150,20 @@ int32_t sa_amd_index_search(const sa_amd_index *ix, const uint8_t *pat_data, con
                             uint8_t *contains, uint32_t *range_lo, uint32_t *range_hi, uint32_t *lcp_start,
                             uint32_t *lcp_len);
 
+/*
+ * Packed format of the `pack` feature (reference src/packed_sa.rs, src/sa.rs:255-361): header u32 magic
+ * "SA4x" LE (src/packed_sa.rs:6-7), u32 length, u64 data length (bincode little-endian Vec<u8>), then the
+ * suffix array bit-packed at ceil(log2(length)) bits in blocks of 128 (BitPacker4x), the last partial
+ * block right-trimmed of zero bytes (src/packed_sa.rs:36-46).  PARITY UNPINNED at byte level: the block
+ * layout is the external `bitpacking 0.8` crate's, restated from its published description; the
+ * reference's own test pins the round trip only (src/tests.rs:61-76).
+ * sa_amd_pack: SA has `length` entries, out has sa_amd_pack_bound(length) bytes; *out_len = bytes written.
+ * sa_amd_unpack: *length receives the stored length; SA (capacity entries) receives the array.
+ */
+int64_t sa_amd_pack_bound(int64_t length);
+int32_t sa_amd_pack(const uint32_t *SA, int64_t length, uint8_t *out, int64_t capacity, int64_t *out_len);
+int32_t sa_amd_unpack(const uint8_t *bytes, int64_t nbytes, uint32_t *SA, int64_t capacity, int64_t *length);
+
 /* ---- per-kernel timing (HIP events on the launch stream), per calling thread ----
  * begin() zeroes and enables the counters for builds issued by this thread; end() disables them and
  * copies up to `capacity` classes out (ms = summed event time, launches, units = elements or bytes

@@ -20,7 +20,7 @@ from typing import Optional
 import numpy as np
 
 __all__ = ["MAX_LENGTH", "saca", "SuffixArray", "SuffixArrayError", "lib", "library_path", "Stats",
-           "saca_batch", "workspace_bytes", "saca_device_ptr", "bucket_table", "check_integrity", "last_stats", "DeviceIndex"]
+           "saca_batch", "workspace_bytes", "saca_device_ptr", "bucket_table", "check_integrity", "last_stats", "DeviceIndex", "pack", "unpack"]
 
 #: reference src/saca.rs:6
 MAX_LENGTH = 2**31 - 1
@@ -88,6 +88,12 @@ def lib() -> ctypes.CDLL:
         L.sa_amd_index_check_integrity.restype = ctypes.c_int32
         L.sa_amd_index_search.argtypes = [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp]
         L.sa_amd_index_search.restype = ctypes.c_int32
+        L.sa_amd_pack_bound.argtypes = [ctypes.c_int64]
+        L.sa_amd_pack_bound.restype = ctypes.c_int64
+        L.sa_amd_pack.argtypes = [c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp]
+        L.sa_amd_pack.restype = ctypes.c_int32
+        L.sa_amd_unpack.argtypes = [c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp]
+        L.sa_amd_unpack.restype = ctypes.c_int32
         L.sa_amd_bucket_table.argtypes = [c_vp, ctypes.c_int32, c_vp, c_vp]
         L.sa_amd_bucket_table.restype = ctypes.c_int32
         L.sa_amd_saca_u8_buckets.argtypes = [c_vp, c_vp, ctypes.c_int32, c_vp]
@@ -193,6 +199,32 @@ def check_integrity(s, sa: np.ndarray) -> bool:
     if rc < 0:
         _check(rc)
     return rc == 1
+
+
+def pack(sa: np.ndarray) -> bytes:
+    """`PackedSuffixArray::from_sa(..).dump_bytes()` -- reference src/packed_sa.rs:17-53, :99-106 (bit packing on the GPU)"""
+    a = np.ascontiguousarray(sa, dtype=np.uint32)
+    cap = int(lib().sa_amd_pack_bound(a.size))
+    out = np.empty(cap, dtype=np.uint8)
+    n_out = ctypes.c_int64()
+    _check(lib().sa_amd_pack(a.ctypes.data, a.size, out.ctypes.data, cap, ctypes.byref(n_out)))
+    return out[:n_out.value].tobytes()
+
+
+def unpack(blob: bytes) -> np.ndarray:
+    """`PackedSuffixArray::load_bytes(..).into_sa()` -- reference src/packed_sa.rs:55-88, :117-124;
+    ValueError where the reference returns an InvalidData error"""
+    b = np.frombuffer(blob, dtype=np.uint8)
+    if b.size < 16:
+        raise ValueError("packed suffix array: truncated header")
+    length = int(np.frombuffer(blob[4:8], dtype="<u4")[0])
+    out = np.empty(max(length, 1), dtype=np.uint32)
+    got = ctypes.c_int64()
+    rc = lib().sa_amd_unpack(b.ctypes.data, b.size, out.ctypes.data, out.size, ctypes.byref(got))
+    if rc == -1:
+        raise ValueError("packed suffix array: invalid data")
+    _check(rc)
+    return out[:got.value]
 
 
 class DeviceIndex:
@@ -333,6 +365,25 @@ class SuffixArray:
         obj._bkt = None
         obj._ix = None
         return obj
+
+    # feature `pack`: reference src/sa.rs:255-361
+    def dump_bytes(self) -> bytes:
+        return pack(self._sa)
+
+    def dump(self, file) -> None:
+        file.write(self.dump_bytes())
+
+    @classmethod
+    def load_bytes(cls, s, blob: bytes) -> "SuffixArray":
+        """reference src/sa.rs:349-361: unpack, then check the integrity; ValueError = the reference's InvalidData"""
+        obj = cls.from_parts(s, unpack(blob))
+        if obj is None:
+            raise ValueError("inconsistent suffix array")
+        return obj
+
+    @classmethod
+    def load(cls, s, file) -> "SuffixArray":
+        return cls.load_bytes(s, file.read())
 
     def enable_buckets(self) -> None:
         """reference src/sa.rs:89-119; a no-op when the table exists (src/sa.rs:90-92)"""

@@ -983,6 +983,83 @@ SA_EXPORT int32_t sa_amd_index_search(const sa_amd_index *ix, const uint8_t *pat
     return rc;
 }
 
+// ---- packed format (reference src/packed_sa.rs); byte layout: u32 magic "SA4x" LE, u32 length, u64 data length
+//      (bincode's Vec<u8> prefix), data ----
+
+static int sa_bits_of(uint32_t length)          // reference src/packed_sa.rs:127-129
+{
+    const uint32_t v = length ? length - 1 : 0;
+    return v ? sa::bit_length(v) : 0;
+}
+
+SA_EXPORT int64_t sa_amd_pack_bound(int64_t length)
+{
+    if (length < 0 || length > 0xffffffffLL) return -1;
+    const int bits = sa_bits_of((uint32_t)length);
+    return 16 + (int64_t)((length + 127) / 128) * bits * 16;
+}
+
+SA_EXPORT int32_t sa_amd_pack(const uint32_t *SA, int64_t length, uint8_t *out, int64_t capacity, int64_t *out_len)
+{
+    using namespace sa;
+    if (!SA || !out || !out_len || length < 1 || length > 0xffffffffLL) return SA_AMD_EINVAL;
+    if (capacity < sa_amd_pack_bound(length)) return SA_AMD_EINVAL;
+    if (sa_amd_device_count() <= 0) return SA_AMD_ENODEVICE;
+    const int bits = sa_bits_of((uint32_t)length);
+    const int64_t blocks = (length + 127) / 128;
+    const int64_t words = blocks * bits * 4;
+    int64_t data_len = 0;
+    if (bits > 0) {
+        uint32_t *dS = nullptr, *dO = nullptr;
+        HIP_TRY(hipMalloc((void **)&dS, (size_t)length * 4));
+        HIP_TRY(hipMalloc((void **)&dO, (size_t)words * 4));
+        HIP_TRY(hipMemcpy(dS, SA, (size_t)length * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_pack4x, dim3((unsigned)ceil_div(words, 256)), dim3(256), 0, nullptr, (const uint32_t *)dS, length, bits, dO, words);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out + 16, dO, (size_t)words * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(dS); (void)hipFree(dO);
+        data_len = words * 4;
+        if (length % 128) {                                   // a partial last block loses its trailing zero bytes (src/packed_sa.rs:41-45)
+            const int64_t last = (blocks - 1) * bits * 16;
+            while (data_len > last && out[16 + data_len - 1] == 0) --data_len;
+        }
+    }
+    const uint32_t magic = 2016690515u, len32 = (uint32_t)length;   // src/packed_sa.rs:7
+    const uint64_t dl = (uint64_t)data_len;
+    memcpy(out, &magic, 4); memcpy(out + 4, &len32, 4); memcpy(out + 8, &dl, 8);
+    *out_len = 16 + data_len;
+    return SA_AMD_OK;
+}
+
+SA_EXPORT int32_t sa_amd_unpack(const uint8_t *bytes, int64_t nbytes, uint32_t *SA, int64_t capacity, int64_t *length)
+{
+    using namespace sa;
+    if (!bytes || !length || nbytes < 16) return SA_AMD_EINVAL;
+    uint32_t magic, len32; uint64_t dl;
+    memcpy(&magic, bytes, 4); memcpy(&len32, bytes + 4, 4); memcpy(&dl, bytes + 8, 8);
+    if (magic != 2016690515u || dl != (uint64_t)(nbytes - 16)) return SA_AMD_EINVAL;       // InvalidData in the reference
+    *length = len32;
+    if (!SA || capacity < (int64_t)len32) return SA_AMD_EINVAL;
+    const int bits = sa_bits_of(len32);
+    const int64_t blocks = ((int64_t)len32 + 127) / 128;
+    if ((int64_t)dl > blocks * bits * 16) return SA_AMD_EINVAL;
+    if (len32 == 0) return SA_AMD_OK;
+    if (bits == 0) { SA[0] = 0; return SA_AMD_OK; }           // length 1: the reference's unpack loop does not terminate here
+    if (sa_amd_device_count() <= 0) return SA_AMD_ENODEVICE;
+    const int64_t in_words = ((int64_t)dl + 3) / 4;
+    uint32_t *dI = nullptr, *dS = nullptr;
+    HIP_TRY(hipMalloc((void **)&dI, (size_t)(in_words ? in_words : 1) * 4));
+    HIP_TRY(hipMalloc((void **)&dS, (size_t)len32 * 4));
+    HIP_TRY(hipMemset(dI, 0, (size_t)(in_words ? in_words : 1) * 4));
+    if (dl) HIP_TRY(hipMemcpy(dI, bytes + 16, (size_t)dl, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_unpack4x, dim3((unsigned)ceil_div((int64_t)len32, 256)), dim3(256), 0, nullptr, (const uint32_t *)dI, in_words,
+                       (int64_t)len32, bits, dS);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(SA, dS, (size_t)len32 * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dI); (void)hipFree(dS);
+    return SA_AMD_OK;
+}
+
 SA_EXPORT int32_t sa_amd_debug_phase_cycles(uint64_t *out, int32_t count)
 {
     unsigned long long h[16] = { 0 };

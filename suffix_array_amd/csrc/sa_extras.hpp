@@ -158,3 +158,55 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_batch(
 }
 
 }  // namespace sa
+
+// ------------------------------------------------------------------------------------------
+// Packed on-disk format, reference src/packed_sa.rs: fixed-width bit packing
+// of the SA in blocks of 128 integers with `bitpacking::BitPacker4x`, bits = ceil(log2(length))
+// (src/packed_sa.rs:127-129).  PARITY UNPINNED AT BYTE LEVEL: the block layout belongs to the
+// external `bitpacking 0.8` crate, whose source is not under /root/reference; it is restated here
+// from its published description (SIMD-BP128 "vertical" layout): a block is 32 rows of 4 lanes,
+// integer 4 i + c is row i of lane c; every lane is an independent little-endian bit stream of
+// 32 * bits bits (row i at bit offset i * bits); the output is `bits` 16-byte registers, register j
+// holding the j-th 32-bit word of lanes 0..3.  The reference's own test only pins the round trip
+// (src/tests.rs:61-76), which tests/ reproduces.
+// ------------------------------------------------------------------------------------------
+namespace sa {
+
+// one thread per output 32-bit word; block b, register j, lane c -> word index (b * bits + j) * 4 + c
+__global__ __launch_bounds__(256) void k_pack4x(const uint32_t *__restrict__ SA, int64_t len, int bits,
+                                                 uint32_t *__restrict__ out, int64_t out_words)
+{
+    const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= out_words) return;
+    const int c = (int)(wi & 3);
+    const int64_t reg = wi >> 2;
+    const int64_t blk = reg / bits;
+    const int j = (int)(reg % bits);
+    const int first_bit = 32 * j;                         // bit range [32 j, 32 j + 32) of lane c's stream
+    uint32_t word = 0;
+    for (int i = first_bit / bits; i < 32 && i * bits < first_bit + 32; ++i) {
+        const int64_t src = blk * 128 + 4 * i + c;
+        const uint64_t v = src < len ? (uint64_t)SA[src] : 0ull;     // the last block is zero padded (src/packed_sa.rs:37-39)
+        const int sh = i * bits - first_bit;              // where row i starts relative to this word
+        word |= sh >= 0 ? (uint32_t)(v << sh) : (uint32_t)(v >> (-sh));
+    }
+    out[wi] = word;
+}
+
+// one thread per integer
+__global__ __launch_bounds__(256) void k_unpack4x(const uint32_t *__restrict__ in, int64_t in_words, int64_t len, int bits,
+                                                   uint32_t *__restrict__ SA)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= len) return;
+    const int64_t blk = idx / 128;
+    const int r = (int)(idx % 128), i = r >> 2, c = r & 3;
+    const int bit0 = i * bits, j = bit0 >> 5, off = bit0 & 31;
+    const int64_t w0 = (blk * bits + j) * 4 + c;
+    const uint64_t lo = w0 < in_words ? in[w0] : 0u;      // trimmed trailing zero bytes read as zero
+    const uint64_t hi = (off + bits > 32 && w0 + 4 < in_words) ? in[w0 + 4] : 0u;
+    const uint64_t both = lo | (hi << 32);
+    SA[idx] = (uint32_t)((both >> off) & ((bits >= 32) ? 0xffffffffull : ((1ull << bits) - 1ull)));
+}
+
+}  // namespace sa

@@ -447,3 +447,39 @@ def test_batched_search_on_device_resident_index(oracle):
         if q < 40:
             assert ln == len(naive_search_lcp(s, p))
     ix.close()
+
+
+# ---- next row 8f-3: packed format (reference src/packed_sa.rs; byte-level parity unpinned) ---------
+
+def test_pack_matches_model_and_round_trips(oracle):
+    import pack_model
+    rng = np.random.default_rng(11)
+    for length in (1, 2, 5, 127, 128, 129, 1000, 4096, 4097, 100_001):
+        arr = rng.permutation(length).astype(np.uint32)
+        blob = sa.pack(arr)
+        if length <= 5000:
+            assert blob == pack_model.pack(arr), length
+        assert np.array_equal(sa.unpack(blob), arr), length
+    with pytest.raises(ValueError):
+        sa.unpack(b"XXXX" + blob[4:])
+    with pytest.raises(ValueError):
+        sa.unpack(blob[:-3])
+
+
+def test_pack_correctness_property_of_the_reference(oracle):
+    """reference src/tests.rs:61-76: dump == dump_bytes, load_bytes round-trips to the same array"""
+    import io
+    rng = np.random.default_rng(8)
+    for it in range(25):
+        n = int(rng.integers(0, 4096)) if it else 0
+        s = rng.integers(0, 256, n, dtype=np.uint8)
+        sa1 = sa.SuffixArray(s)
+        bytes1 = sa1.dump_bytes()
+        buf = io.BytesIO()
+        sa1.dump(buf)
+        assert buf.getvalue() == bytes1
+        sa2 = sa.SuffixArray.load_bytes(s, bytes1)
+        assert np.array_equal(sa1.into_parts()[1], sa2.into_parts()[1])
+    bad = sa.SuffixArray(b"banana").dump_bytes()
+    with pytest.raises(ValueError):
+        sa.SuffixArray.load_bytes(b"bananb", bad)       # integrity check fails: the reference's InvalidData

@@ -102,3 +102,23 @@ def test_bucket_table_restatement(oracle):
     idx = c0 * 257 + (c1 + 1) + 1
     rng = sa[bkt[idx - 1]:bkt[idx]]
     assert sorted(int(p) for p in rng) == [0, 9]
+
+
+def test_pack_model_round_trip_and_layout():
+    """numpy restatement of the packed format (reference src/packed_sa.rs); byte-level parity with the
+    external bitpacking crate is unpinned, the round trip is what the reference's own test pins"""
+    import pack_model
+    rng = np.random.default_rng(4)
+    for length in (1, 2, 3, 127, 128, 129, 255, 256, 1000, 4097):
+        sa = rng.permutation(length).astype(np.uint32)
+        blob = pack_model.pack(sa)
+        assert np.array_equal(pack_model.unpack(blob), sa)
+        bits = pack_model.sa_bits(length)
+        assert len(blob) <= 16 + ((length + 127) // 128) * bits * 16
+    # hand-checked block: bits = 7 for length 128; value 4 i + c of the identity sits at row i of lane c
+    blob = pack_model.pack(np.arange(128, dtype=np.uint32))
+    assert blob[:4] == b"SA4x" and blob[4:8] == (128).to_bytes(4, "little") and len(blob) == 16 + 7 * 16
+    lane0_word0 = int.from_bytes(blob[16:20], "little")
+    assert lane0_word0 & 0x7F == 0 and (lane0_word0 >> 7) & 0x7F == 4 and (lane0_word0 >> 14) & 0x7F == 8
+    lane1_word0 = int.from_bytes(blob[20:24], "little")
+    assert lane1_word0 & 0x7F == 1 and (lane1_word0 >> 7) & 0x7F == 5
