@@ -277,6 +277,37 @@ def test_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed):
     assert sa.last_stats()["top32_first"] == 0
 
 
+def test_randomised_inputs_and_regimes(oracle, monkeypatch):
+    """short form of tools/stress.py: random sizes, alphabets and structures with the regime switches
+    toggled at random; every array equals the oracle's"""
+    rng = np.random.default_rng(2026)
+    switches = ["SA_AMD_FORCE_TOP32", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TEXT_ROUNDS", "SA_AMD_FORCE_DENSE",
+                "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_TOP32"]
+    for it in range(250):
+        n = int(rng.choice([rng.integers(0, 200), rng.integers(200, 9000), rng.integers(9000, 120000)]))
+        kind = it % 4
+        if kind == 0:
+            s = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1:
+            s = (rng.integers(0, int(rng.integers(1, 6)), n) + 60).astype(np.uint8)
+        elif kind == 2:
+            s = np.resize(rng.integers(0, 256, int(rng.integers(1, 30)), dtype=np.uint8), n).astype(np.uint8)
+        else:
+            s = rng.integers(0, 256, n, dtype=np.uint8)
+            if n > 100:
+                ln = int(rng.integers(2, n // 3)); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln))
+                s[b:b + ln] = s[a:a + ln]
+        s = np.ascontiguousarray(s)
+        for k in switches + ["SA_AMD_SPARSE_DIV"]:
+            monkeypatch.delenv(k, raising=False)
+        for k in switches:
+            if rng.random() < 0.2:
+                monkeypatch.setenv(k, "1")
+        if rng.random() < 0.3:
+            monkeypatch.setenv("SA_AMD_SPARSE_DIV", str(int(rng.choice([1, 4, 64, 10**9]))))
+        assert np.array_equal(build(s), oracle.sais(s)), (it, n, kind)
+
+
 # ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------
 
 @pytest.mark.parametrize("name", ["c2_uniform_64m", "c3_english_256m"])

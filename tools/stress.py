@@ -1,0 +1,58 @@
+"""Randomised stress test on the GPU: random sizes / alphabets / structures, every regime switch
+toggled at random, each result compared bit for bit with the oracle.  python tools/stress.py [seconds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import suffix_array_amd as sa
+from suffix_array_amd import corpus
+from conftest import Oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+orc = Oracle()
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+BIG = int(sys.argv[3]) if len(sys.argv) > 3 else 400000
+ENV = ["SA_AMD_FORCE_TOP32", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TEXT_ROUNDS", "SA_AMD_FORCE_DENSE", "SA_AMD_BINNED_ISA_ALWAYS",
+       "SA_AMD_NO_TOP32"]
+t0 = time.time(); cases = 0; fails = 0
+while time.time() - t0 < budget:
+    n = int(rng.choice([rng.integers(0, 300), rng.integers(300, 20000), rng.integers(20000, BIG)]))
+    kind = int(rng.integers(0, 7))
+    if kind == 0:
+        s = rng.integers(0, 256, n, dtype=np.uint8)
+    elif kind == 1:
+        sig = int(rng.integers(1, 6)); s = (rng.integers(0, sig, n) + int(rng.integers(0, 250))).astype(np.uint8)
+    elif kind == 2:
+        s = corpus.english(n, int(rng.integers(0, 1 << 30))) if n else np.zeros(0, np.uint8)
+    elif kind == 3:
+        per = rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8); s = np.resize(per, n).astype(np.uint8) if n else np.zeros(0, np.uint8)
+    elif kind == 4:
+        s = rng.integers(0, 256, n, dtype=np.uint8)
+        for _ in range(int(rng.integers(1, 6))):
+            if n > 50:
+                ln = int(rng.integers(2, max(3, n // 3))); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln)); s[b:b + ln] = s[a:a + ln]
+    elif kind == 5:
+        s = np.concatenate([rng.integers(0, 3, n // 2, dtype=np.uint8), np.zeros(n - n // 2, dtype=np.uint8)])
+    else:
+        s = corpus.dna_repeats(n, int(rng.integers(0, 1 << 30)), 0.4) if n > 5000 else rng.integers(65, 69, n, dtype=np.uint8)
+    s = np.ascontiguousarray(s, dtype=np.uint8)
+    for k in ENV + ["SA_AMD_SPARSE_DIV"]:
+        os.environ.pop(k, None)
+    chosen = [k for k in ENV if rng.random() < 0.2]
+    for k in chosen:
+        os.environ[k] = "1"
+    if rng.random() < 0.3:
+        os.environ["SA_AMD_SPARSE_DIV"] = str(int(rng.choice([1, 4, 64, 10**9]))); chosen.append("DIV=" + os.environ["SA_AMD_SPARSE_DIV"])
+    try:
+        got = sa.SuffixArray(s).into_parts()[1]
+        ok = np.array_equal(got, orc.sais(s))
+    except Exception as e:
+        ok = False; print("EXC", e)
+    cases += 1
+    if not ok:
+        fails += 1
+        print("FAIL n", n, "kind", kind, "env", chosen, sa.last_stats())
+        np.save(f"gpurun_out/stress_fail_{fails}.npy", s)
+        if fails >= 5: break
+print(f"stress: {cases} cases, {fails} failures, {time.time()-t0:.0f} s")
+sys.exit(1 if fails else 0)
