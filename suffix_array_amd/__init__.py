@@ -338,6 +338,12 @@ class SuffixArray:
         self._sa = np.resize(self._sa, t.size + 1)
         saca(t, self._sa)
 
+    def fit(self) -> None:                             # src/sa.rs:36-38 (shrink_to_fit: numpy arrays carry no slack)
+        self._sa = np.ascontiguousarray(self._sa)
+
+    def as_ref(self) -> np.ndarray:                    # AsRef<[u8]>, src/sa.rs:370-374
+        return self._s
+
     def len(self) -> int:                              # src/sa.rs:41-43
         return int(self._s.size)
 
