@@ -181,6 +181,9 @@ int32_t sa_amd_debug_phase_cycles(uint64_t *out, int32_t count);
 /* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit); host buffers */
 int32_t sa_amd_test_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit,
                                int32_t end_bit);
+/* the 32-bit-key form of the same sort (first stage of the two-stage initial sort) */
+int32_t sa_amd_test_sort_pairs32(uint32_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit,
+                                 int32_t end_bit);
 /* initial packed keys of a text (host buffers; keys has n entries); returns bits in *bits, symbols in *k */
 int32_t sa_amd_test_build_keys(const uint8_t *T, int32_t n, uint64_t *keys, int32_t *bits, int32_t *k);
 

@@ -111,6 +111,8 @@ def lib() -> ctypes.CDLL:
         L.sa_amd_profile_kernel_name.restype = ctypes.c_char_p
         L.sa_amd_test_sort_pairs.argtypes = [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
         L.sa_amd_test_sort_pairs.restype = ctypes.c_int32
+        L.sa_amd_test_sort_pairs32.argtypes = [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+        L.sa_amd_test_sort_pairs32.restype = ctypes.c_int32
         L.sa_amd_test_build_keys.argtypes = [c_vp, ctypes.c_int32, c_vp, c_vp, c_vp]
         L.sa_amd_test_build_keys.restype = ctypes.c_int32
         _lib = L

@@ -244,6 +244,67 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
     return SA_AMD_OK;
 }
 
+// 32-bit keys (two-stage initial sort): same three-kernel pass, 16 Ki-pair tiles (the 64 KiB stage holds twice the elements)
+struct SortResult32 { uint32_t *keys; uint32_t *vals; int passes; };
+constexpr int SORT32_THREADS = 1024;
+typedef void (*Downsweep32Fn)(const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint32_t *, int64_t, int,
+                              uint32_t, int64_t, int);
+struct Sort32Variant { int items; Downsweep32Fn fn; };
+static const Sort32Variant sort32_variants[] = {
+    { 16, k_radix_downsweep_wcl<SORT32_THREADS, 16, 16, 1, false, uint32_t> },
+    { 12, k_radix_downsweep_wcl<SORT32_THREADS, 12, 16, 1, false, uint32_t> },
+    { 8, k_radix_downsweep_wcl<SORT32_THREADS, 8, 16, 1, false, uint32_t> },
+};
+static const Sort32Variant &sort32_variant()
+{
+    const char *e = getenv("SA_AMD_SORT32_VARIANT");
+    int v = e ? atoi(e) : 1;          // 1024 x 12: no spills, measured best on C4 / C5
+    if (v < 0 || v > 2) v = 1;
+    return sort32_variants[v];
+}
+
+static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit,
+                        int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals, hipStream_t st, SortResult32 *res)
+{
+    res->keys = keys_in; res->vals = vals_in; res->passes = 0;
+    if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
+    const Sort32Variant &sv = sort32_variant();
+    const int64_t SORT32_TILE = (int64_t)SORT32_THREADS * sv.items;
+    const int64_t tiles = ceil_div(count, SORT32_TILE);
+    int64_t tiles_per_wg = ceil_div(tiles, 512);
+    if (tiles_per_wg < 1) tiles_per_wg = 1;
+    const int G = (int)ceil_div(tiles, tiles_per_wg);
+    uint32_t *kin = keys_in, *kout = keys_alt, *vin = vals_in, *vout = vals_alt;
+    for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
+        const int nb = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
+        const uint32_t dmask = (1u << nb) - 1u;
+        const bool last = shift + RADIX_BITS >= end_bit;
+        uint32_t *vdst = (last && final_vals) ? final_vals : vout;
+        {
+            const int64_t chunk = tiles_per_wg * SORT32_TILE;
+            int split = 2048 / G;
+            if (split < 1) split = 1;
+            while (split > 1 && chunk / split < 8192) split /= 2;
+            const int64_t sub = (ceil_div(chunk, split) + 3) & ~(int64_t)3;
+            if (split > 1) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * G * 4, st));
+            PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep32), dim3(G * split), dim3(SORT_THREADS), 0, st,
+                                                           (const uint32_t *)kin, spine, count, shift, dmask, chunk, G, split, sub));
+        }
+        PROF(KC_SPINE, (int64_t)RADIX * G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st, spine, digit_tot, G));
+        PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((sv.fn),
+                                                         dim3(G), dim3(SORT32_THREADS), 0, st, (const uint32_t *)kin, (const uint32_t *)vin, kout,
+                                                         vdst, (const uint32_t *)spine, (const uint32_t *)digit_tot, count, shift, dmask,
+                                                         tiles_per_wg, G));
+        uint32_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *free_v = vin;
+        vin = vdst;
+        vout = free_v;
+        res->passes++;
+    }
+    res->keys = kin; res->vals = vin;
+    return SA_AMD_OK;
+}
+
 // symbol codes and key geometry from the sigma = 256 histogram; returns the number of key bits to sort
 static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out)
 {
@@ -418,13 +479,30 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     }
     local.top32_first = top_shift ? 1 : 0;
 
-    // 3. packed keys, 4. initial sort (all key bits, or the top 32 only)
-    PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P, w.keysA,
-                       w.valsA));
+    // 3. packed keys, 4. initial sort: all key bits as (u64 key, u32 suffix) pairs, or only the top 32 bits as
+    //    (u32, u32) pairs in 16 Ki-element tiles -- two thirds of the bytes per pass and half the passes
     SortResult sr;
-    int rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, top_shift, key_bits, w.spine, w.digit_tot, SA, st, &sr);
-    if (rc) return rc;
-    local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
+    sr.keys = w.keysA; sr.vals = w.valsA; sr.passes = 0;
+    const uint32_t *sorted32 = nullptr;               // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
+    int rc;
+    if (top_shift) {
+        uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
+        PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                      (uint64_t *)nullptr, w.valsA, k32a, top_shift));
+        SortResult32 s32;
+        rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.spine, w.digit_tot, SA, st, &s32);
+        if (rc) return rc;
+        local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
+        sorted32 = s32.keys;
+        sr.vals = s32.vals; sr.passes = s32.passes;
+        sr.keys = (s32.keys == k32a) ? w.keysA : w.keysB;      // the 8n-byte buffer that now holds the sorted 32-bit keys
+    } else {
+        PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                      w.keysA, w.valsA, (uint32_t *)nullptr, 0));
+        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr);
+        if (rc) return rc;
+        local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
+    }
     if (sr.vals != SA) {   // n == 1: no pass ran, the values are still in the input buffer
         PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_copy_u32), dim3(1), dim3(256), 0, st, sr.vals, SA, n));
     }
@@ -433,8 +511,12 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     uint32_t *Ucur = w.U0, *Unext = w.U1, *Gcur = w.G0, *Gnext = w.G1;
     uint32_t *Vcur = w.valsA;
     int64_t tiles = ceil_div(n, RR_TILE);
-    PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sr.keys,
-                                                (const uint32_t *)nullptr, n, w.tcnt, w.thead, top_shift));
+    if (top_shift)
+        PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sorted32,
+                                                    (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0));
+    else
+        PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)sr.keys,
+                                                    (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0));
     PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
     uint32_t m32 = 0;
     HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
@@ -449,19 +531,16 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         // finish the initial sort: the suffixes tied on the top 32 bits are ordered by their low key bits
         rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
         rkB = w.keysC;
-        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                    (const uint64_t *)sorted0, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
+        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    sorted32, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
                                                     (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
-                                                    w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total,
-                                                    top_shift));
-        PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_lowkey), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st,
-                                                  (const uint32_t *)Ucur, (const uint32_t *)Gcur, (const uint64_t *)sorted0, m, top_shift, rkA));
+                                                    w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+        PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_lowkey_text), dim3((unsigned)ceil_div(m, GK_THREADS)), dim3(GK_THREADS), 0, st,
+                                                  (const uint32_t *)Vcur, (const uint32_t *)Gcur, dT, P, m, n, top_shift, rkA));
         uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
         Refined rf;
         rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Unext, Gnext, m, n, top_shift, g_bits, &local_ok, w, st, &local, &rf);
         if (rc) return rc;
-        PROF(KC_SCATTER, m, st, hipLaunchKernelGGL((k_fix_lowkeys), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st,
-                                                   (const uint32_t *)Ucur, rf.keys, m, top_shift, sorted0));
         tiles = ceil_div(m, RR_TILE);
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rf.keys,
                                                     (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0));
@@ -594,7 +673,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2_sparse), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, (const uint32_t *)Gcur, (const uint32_t *)w.isa,
                                                       (const uint32_t *)w.has_isa, (const uint64_t *)sorted0, (const uint32_t *)SA, dT, P, m, n, h,
-                                                      depth_text, key2_bits, rkA));
+                                                      depth_text, key2_bits, rkA, sorted32, top_shift));
         else
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st, Vcur, Gcur,
                                                       w.isa, m, n, h, key2_bits, rkA));
@@ -1149,6 +1228,30 @@ SA_EXPORT int32_t sa_amd_test_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t
     return rc;
 }
 
+SA_EXPORT int32_t sa_amd_test_sort_pairs32(uint32_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit, int32_t end_bit)
+{
+    using namespace sa;
+    if (count < 0 || (count > 0 && (!keys || !vals)) || begin_bit < 0 || end_bit > 32) return SA_AMD_EINVAL;
+    if (sa_amd_device_count() <= 0) return SA_AMD_ENODEVICE;
+    if (count == 0) return SA_AMD_OK;
+    uint32_t *dk = nullptr, *dv = nullptr, *spine = nullptr;
+    const size_t N = ((size_t)count + 3) & ~(size_t)3;
+    HIP_TRY(hipMalloc((void **)&dk, N * 4 * 2));
+    HIP_TRY(hipMalloc((void **)&dv, N * 4 * 2));
+    HIP_TRY(hipMalloc((void **)&spine, ((size_t)RADIX * SORT_MAX_WG + RADIX) * 4));
+    HIP_TRY(hipMemcpy(dk, keys, (size_t)count * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv, vals, (size_t)count * 4, hipMemcpyHostToDevice));
+    SortResult32 sr;
+    int rc = sort_pairs32(dk, dv, dk + N, dv + N, count, begin_bit, end_bit, spine, spine + (size_t)RADIX * SORT_MAX_WG, nullptr, nullptr, &sr);
+    if (rc == SA_AMD_OK) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(keys, sr.keys, (size_t)count * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(vals, sr.vals, (size_t)count * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dk); (void)hipFree(dv); (void)hipFree(spine);
+    return rc;
+}
+
 SA_EXPORT int32_t sa_amd_test_build_keys(const uint8_t *T, int32_t n, uint64_t *keys, int32_t *bits, int32_t *k)
 {
     using namespace sa;
@@ -1169,8 +1272,8 @@ SA_EXPORT int32_t sa_amd_test_build_keys(const uint8_t *T, int32_t n, uint64_t *
     HIP_TRY(hipMemcpy(hist, dh, 1024, hipMemcpyDeviceToHost));
     KeyParams P; int sigma;
     make_key_params(hist, &P, &sigma);
-    hipLaunchKernelGGL(k_build_keys, dim3((unsigned)ceil_div((int64_t)n, KB_TILE)), dim3(KB_THREADS), 0, nullptr, dT,
-                       (int64_t)n, P, dk, dv);
+    hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div((int64_t)n, KB_TILE)), dim3(KB_THREADS), 0, nullptr, dT,
+                       (int64_t)n, P, dk, dv, (uint32_t *)nullptr, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(keys, dk, (size_t)n * 8, hipMemcpyDeviceToHost));

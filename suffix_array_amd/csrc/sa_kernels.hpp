@@ -151,9 +151,12 @@ struct KeyParams {
     uint64_t top;      //   base-sigma number; top = sigma^(k-1).  sigma = 56 packs 11 symbols, not 10.
 };
 
+// TOP32: only the top 32 bits of every key are stored (keys32), for the two-stage initial sort
+template <bool TOP32>
 __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__restrict__ T, int64_t n,
                                                             KeyParams P, uint64_t *__restrict__ keys,
-                                                            uint32_t *__restrict__ vals)
+                                                            uint32_t *__restrict__ vals, uint32_t *__restrict__ keys32,
+                                                            int top_shift)
 {
     __shared__ uint8_t lcode[256];
     __shared__ __attribute__((aligned(16))) uint8_t c[KB_TILE + KB_HALO];
@@ -206,9 +209,17 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
     }
     const int64_t g0 = base + p0;
     if (g0 + KB_ITEMS <= n) {
-        ulonglong2 *ko = (ulonglong2 *)(keys + g0);
+        if (TOP32) {
+            uint4 *ko = (uint4 *)(keys32 + g0);
+            ko[0] = make_uint4((uint32_t)(kk[0] >> top_shift), (uint32_t)(kk[1] >> top_shift), (uint32_t)(kk[2] >> top_shift),
+                               (uint32_t)(kk[3] >> top_shift));
+            ko[1] = make_uint4((uint32_t)(kk[4] >> top_shift), (uint32_t)(kk[5] >> top_shift), (uint32_t)(kk[6] >> top_shift),
+                               (uint32_t)(kk[7] >> top_shift));
+        } else {
+            ulonglong2 *ko = (ulonglong2 *)(keys + g0);
 #pragma unroll
-        for (int r = 0; r < KB_ITEMS / 2; ++r) ko[r] = make_ulonglong2(kk[2 * r], kk[2 * r + 1]);
+            for (int r = 0; r < KB_ITEMS / 2; ++r) ko[r] = make_ulonglong2(kk[2 * r], kk[2 * r + 1]);
+        }
         uint4 *vo = (uint4 *)(vals + g0);
         const uint32_t v0 = (uint32_t)g0;
         vo[0] = make_uint4(v0, v0 + 1, v0 + 2, v0 + 3);
@@ -216,7 +227,10 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
     } else {
 #pragma unroll
         for (int r = 0; r < KB_ITEMS; ++r)
-            if (g0 + r < n) { keys[g0 + r] = kk[r]; vals[g0 + r] = (uint32_t)(g0 + r); }
+            if (g0 + r < n) {
+                if (TOP32) keys32[g0 + r] = (uint32_t)(kk[r] >> top_shift); else keys[g0 + r] = kk[r];
+                vals[g0 + r] = (uint32_t)(g0 + r);
+            }
     }
 }
 
@@ -238,6 +252,10 @@ constexpr int SORT_WAVES = SORT_THREADS / WAVE;
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, uint32_t dmask)
 {
     return (uint32_t)(key >> shift) & dmask;
+}
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, uint32_t dmask)
+{
+    return (key >> shift) & dmask;
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void k_radix_upsweep(const uint64_t *__restrict__ keys,
@@ -265,7 +283,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_upsweep(const uint64_t *
     const int64_t npair = (end - begin) / 2;
     const ulonglong2 *K2 = (const ulonglong2 *)(keys + begin);
     auto count2 = [&](const ulonglong2 &q) {
-        const uint32_t d0 = digit_of(q.x, shift, dmask), d1 = digit_of(q.y, shift, dmask);
+        const uint32_t d0 = digit_of((uint64_t)q.x, shift, dmask), d1 = digit_of((uint64_t)q.y, shift, dmask);
         // constant digits (all-equal high bits) would serialise the LDS atomic 64 ways
         const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d0);
         const uint64_t act = __ballot(1);                          // evaluated by every active lane
@@ -293,6 +311,54 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_upsweep(const uint64_t *
 }
 
 constexpr int SPINE_THREADS = 1024;
+
+// the same for 32-bit keys (two-stage initial sort: only the top 32 key bits are sorted), four keys per 16-byte load
+__global__ __launch_bounds__(SORT_THREADS) void k_radix_upsweep32(const uint32_t *__restrict__ keys,
+                                                                   uint32_t *__restrict__ counts, int64_t n,
+                                                                   int shift, uint32_t dmask,
+                                                                   int64_t chunk_elems, int G, int split,
+                                                                   int64_t sub_elems)
+{
+    __shared__ uint32_t h[SORT_WAVES][RADIX];
+    for (int i = threadIdx.x; i < SORT_WAVES * RADIX; i += SORT_THREADS) (&h[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t *mine = h[wave_id()];
+    const int g = (int)(blockIdx.x / split), part = (int)(blockIdx.x % split);
+    const int64_t cbegin = (int64_t)g * chunk_elems;
+    int64_t cend = cbegin + chunk_elems;
+    if (cend > n) cend = n;
+    int64_t begin = cbegin + (int64_t)part * sub_elems;      // sub_elems is a multiple of 4: 16-byte aligned parts
+    int64_t end = begin + sub_elems;
+    if (begin > cend) begin = cend;
+    if (end > cend || part == split - 1) end = cend;
+    const int64_t nquad = (end - begin) / 4;
+    const uint4 *K4 = (const uint4 *)(keys + begin);
+    auto count4 = [&](const uint4 &q) {
+        const uint32_t d0 = digit_of((uint32_t)q.x, shift, dmask), d1 = digit_of((uint32_t)q.y, shift, dmask);
+        const uint32_t d2 = digit_of((uint32_t)q.z, shift, dmask), d3 = digit_of((uint32_t)q.w, shift, dmask);
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d0);
+        const uint64_t act = __ballot(1);
+        if (__all(d0 == f && d1 == f && d2 == f && d3 == f)) {
+            if (lane_id() == __ffsll((unsigned long long)act) - 1) atomicAdd(&mine[f], 4u * (uint32_t)__popcll(act));
+        } else {
+            atomicAdd(&mine[d0], 1u); atomicAdd(&mine[d1], 1u); atomicAdd(&mine[d2], 1u); atomicAdd(&mine[d3], 1u);
+        }
+    };
+    int64_t i = threadIdx.x;
+    for (; i + 3 * SORT_THREADS < nquad; i += 4 * SORT_THREADS) {
+        const uint4 q0 = K4[i], q1 = K4[i + SORT_THREADS], q2 = K4[i + 2 * SORT_THREADS], q3 = K4[i + 3 * SORT_THREADS];
+        count4(q0); count4(q1); count4(q2); count4(q3);
+    }
+    for (; i < nquad; i += SORT_THREADS) count4(K4[i]);
+    if (threadIdx.x == 0)
+        for (int64_t t = begin + nquad * 4; t < end; ++t) atomicAdd(&mine[digit_of(keys[t], shift, dmask)], 1u);
+    __syncthreads();
+    uint32_t s = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) s += h[w][threadIdx.x];
+    if (split == 1) counts[(int64_t)threadIdx.x * G + g] = s;
+    else if (s) atomicAdd(&counts[(int64_t)threadIdx.x * G + g], s);
+}
 
 // Spine of one radix pass: block d turns counts[d][0..G) into exclusive prefixes (in place) and
 // writes the digit total; the downsweep prologue scans the 256 totals itself.  G <= 1024.
@@ -717,9 +783,9 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
 // diagnostic build only (STAMP): cycles of wave 0 per phase, summed over tiles and workgroups
 __device__ unsigned long long g_phase_cycles[16];
 
-template <int THREADS, int ITEMS, int GR = 16, int MINW = 1, bool STAMP = false>
+template <int THREADS, int ITEMS, int GR = 16, int MINW = 1, bool STAMP = false, typename KeyT = uint64_t>
 __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
-    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
+    const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KeyT *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
     int64_t n, int shift, uint32_t dmask, int64_t tiles_per_wg, int G)
 {
@@ -730,8 +796,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
     static_assert(THREADS >= RADIX, "thread / digit mapping");
     static_assert(ITEMS % 4 == 0, "digits are packed four to a register");
     static_assert(TILE < 65536, "16-bit tile-local counters");
-    __shared__ __attribute__((aligned(16))) uint64_t lds_kv[TILE];
-    __shared__ __attribute__((aligned(16))) uint64_t carry_k[RADIX * GR];
+    __shared__ __attribute__((aligned(16))) KeyT lds_kv[TILE];
+    __shared__ __attribute__((aligned(16))) KeyT carry_k[RADIX * GR];
     __shared__ __attribute__((aligned(16))) uint32_t carry_v[RADIX * GR];
     __shared__ uint16_t wave_hist[NWAVES][RADIX];   // a wave holds 64 * ITEMS <= 65535 elements, a tile < 65536
     __shared__ uint32_t digit_base[RADIX];     // first stage slot of digit d
@@ -767,12 +833,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
         stamp(-1);
         const int valid = (n - base) >= TILE ? TILE : (int)(n - base);
         const bool full = valid == TILE;
-        uint64_t key[ITEMS];
+        KeyT key[ITEMS];
         uint32_t pos[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int e = e0 + j * WAVE;
-            key[j] = (full || e < valid) ? keys_in[base + e] : ~0ull;
+            key[j] = (full || e < valid) ? keys_in[base + e] : (KeyT)~(KeyT)0;
         }
         for (int i = tid; i < NWAVES * RADIX / 2; i += THREADS) ((uint32_t *)&wave_hist[0][0])[i] = 0;
         __syncthreads();
@@ -854,7 +920,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
             const int idx = tid + j * THREADS;
             if ((j & 3) == 0) dpack[j >> 2] = 0;
             if (full || idx < valid) {
-                const uint64_t kx = lds_kv[idx];
+                const KeyT kx = lds_kv[idx];
                 const uint32_t d = digit_of(kx, shift, dmask);
                 dpack[j >> 2] |= d << (8 * (j & 3));
                 const uint32_t gp = goff[d] + (uint32_t)idx, lim = wlim[d];
@@ -929,7 +995,8 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
     return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, WAVE);
 }
 
-__device__ __forceinline__ WaveGroups rr_wave_classify(const uint64_t *__restrict__ keys, int64_t m, int64_t wbase, int key_shift)
+template <typename KeyT>
+__device__ __forceinline__ WaveGroups rr_wave_classify(const KeyT *__restrict__ keys, int64_t m, int64_t wbase, int key_shift)
 {
     const int l = lane_id();
     uint64_t k[RR_ITEMS];
@@ -937,11 +1004,11 @@ __device__ __forceinline__ WaveGroups rr_wave_classify(const uint64_t *__restric
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
         const int64_t i = wbase + 64 * r + l;
-        k[r] = i < m ? (keys[i] >> key_shift) : 0ull;           // groups are runs of equal key >> key_shift
+        k[r] = i < m ? ((uint64_t)keys[i] >> key_shift) : 0ull; // groups are runs of equal key >> key_shift
         g.valid[r] = __ballot(i < m);
     }
-    const uint64_t before = (wbase > 0 && wbase - 1 < m) ? (keys[wbase - 1] >> key_shift) : 0ull;
-    const uint64_t after = (wbase + RR_WAVE_ELEMS < m) ? (keys[wbase + RR_WAVE_ELEMS] >> key_shift) : 0ull;
+    const uint64_t before = (wbase > 0 && wbase - 1 < m) ? ((uint64_t)keys[wbase - 1] >> key_shift) : 0ull;
+    const uint64_t after = (wbase + RR_WAVE_ELEMS < m) ? ((uint64_t)keys[wbase + RR_WAVE_ELEMS] >> key_shift) : 0ull;
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
         uint64_t up = shfl64(k[r], l ? l - 1 : 0);
@@ -964,8 +1031,8 @@ __device__ __forceinline__ WaveGroups rr_wave_classify(const uint64_t *__restric
     return g;
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(RR_THREADS) void k_rr_count(const uint64_t *__restrict__ keys,
+template <bool FIRST, typename KeyT = uint64_t>
+__global__ __launch_bounds__(RR_THREADS) void k_rr_count(const KeyT *__restrict__ keys,
                                                           const uint32_t *__restrict__ U, int64_t m,
                                                           uint32_t *__restrict__ tile_cnt,
                                                           uint32_t *__restrict__ tile_head, int key_shift)
@@ -1026,9 +1093,9 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict_
 // refinement), 3 = no rank output at all (text-keyed rounds), 2 = write (suffix, rank) pairs in slot order; the host bins them by suffix position
 // with one radix pass and k_scatter_pairs then writes the ISA window by window (a random 4-byte
 // store costs a whole 64-byte memory transaction, a binned one is merged in the caches).
-template <bool FIRST, bool WRITE_SA, int ISA_MODE>
+template <bool FIRST, bool WRITE_SA, int ISA_MODE, typename KeyT = uint64_t>
 __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
-    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ V, const uint32_t *__restrict__ U, int64_t m,
+    const KeyT *__restrict__ keys, const uint32_t *__restrict__ V, const uint32_t *__restrict__ U, int64_t m,
     const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_head, uint32_t *__restrict__ SA,
     uint32_t *__restrict__ ISA, uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo,
     uint32_t n_text, uint32_t *__restrict__ has_isa, int g_shift, uint64_t *__restrict__ pair_k,
@@ -1086,7 +1153,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
             } else if (ISA_MODE != 3 && v[r] < n_text) {
                 // refinement rounds: the key's high part is the old group head, i.e. the rank already in ISA;
                 // the first subgroup of a split group keeps its rank and is not rewritten
-                const uint32_t oldrank = (FIRST || ISA_MODE != 0) ? 0u : (uint32_t)(keys[i] >> g_shift) + 1u;
+                const uint32_t oldrank = (FIRST || ISA_MODE != 0) ? 0u : (uint32_t)((uint64_t)keys[i] >> g_shift) + 1u;
                 if (run != oldrank) {
                     ISA[v[r]] = run;
                     if (SPARSE) atomicOr(&has_isa[v[r] >> 5], 1u << (v[r] & 31u));   // this rank overrides the initial one
@@ -1128,6 +1195,35 @@ __device__ __forceinline__ uint64_t code_at(const uint8_t *__restrict__ T, const
     return pos < n ? (uint64_t)lcode[T[pos]] : 0ull;
 }
 
+// packed key of the `nsym` symbols T[p .. p + nsym) (zero codes past the end), most significant first.
+// Away from the end of an 8-byte aligned text the bytes come from aligned 8-byte loads, not byte loads.
+__device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ T, const uint8_t *lcode, const KeyParams &P, int64_t n,
+                                             int64_t p, int nsym, bool aligned8)
+{
+    uint64_t tk = 0;
+    if (aligned8 && p + nsym + 16 <= n) {
+        const uint64_t *W = (const uint64_t *)(T + (p & ~(int64_t)7));
+        const int sh = (int)(p & 7) * 8;
+        uint64_t w0 = W[0];
+        for (int done = 0, wi = 1; done < nsym; done += 8, ++wi) {
+            const uint64_t w1 = W[wi];
+            const uint64_t bytes = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+            const int cnt = nsym - done < 8 ? nsym - done : 8;
+            for (int i = 0; i < cnt; ++i) {
+                const uint64_t cs = (uint64_t)lcode[(bytes >> (8 * i)) & 255u];
+                tk = P.bits > 0 ? ((tk << P.bits) | cs) : (tk * P.sigma + cs);
+            }
+            w0 = w1;
+        }
+    } else {
+        for (int i = 0; i < nsym; ++i) {
+            const uint64_t cs = code_at(T, lcode, n, p + i);
+            tk = P.bits > 0 ? ((tk << P.bits) | cs) : (tk * P.sigma + cs);
+        }
+    }
+    return tk;
+}
+
 // Text-keyed refinement round (used while MANY suffixes are still tied): instead of ranks -- which
 // would need the ISA, n random 4-byte writes -- the secondary key is the next `s` symbols of the text
 // itself, T[v+h .. v+h+s), packed like the initial keys into `tkb` bits below the group head.  The
@@ -1143,23 +1239,7 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_textkey(const uint32_t *_
     const int64_t stride = (int64_t)gridDim.x * GK_THREADS;
     for (int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x; j < m; j += stride) {
         const int64_t p = (int64_t)V[j] + h;
-        uint64_t tk = 0;
-        if (s <= 8 && aligned8 && p + 16 <= n) {
-            // the s <= 8 bytes at p straddle at most two aligned 8-byte words: two wide loads, not s byte loads
-            const uint64_t *W = (const uint64_t *)(T + (p & ~(int64_t)7));
-            const uint64_t w0 = W[0], w1 = W[1];
-            const int sh = (int)(p & 7) * 8;
-            const uint64_t bytes = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
-            for (int i = 0; i < s; ++i) {
-                const uint64_t cs = (uint64_t)lcode[(bytes >> (8 * i)) & 255u];
-                tk = P.bits > 0 ? ((tk << P.bits) | cs) : (tk * P.sigma + cs);
-            }
-        } else {
-            for (int i = 0; i < s; ++i) {
-                const uint64_t cs = code_at(T, lcode, n, p + i);
-                tk = P.bits > 0 ? ((tk << P.bits) | cs) : (tk * P.sigma + cs);
-            }
-        }
+        const uint64_t tk = text_key(T, lcode, P, n, p, s, aligned8);
         keys[j] = ((uint64_t)G[j] << tkb) | tk;
     }
 }
@@ -1330,11 +1410,7 @@ __global__ __launch_bounds__(GK_THREADS) void k_sample_keys(const uint8_t *__res
     if (i >= samples) return;
     const uint64_t r = ((uint64_t)i + 1u) * 0x9E3779B97F4A7C15ull;
     const int64_t p = (int64_t)((r >> 11) % (uint64_t)n);
-    uint64_t kq = 0;
-    for (int j = 0; j < P.k; ++j) {
-        const uint64_t cs = code_at(T, lcode, n, p + j);
-        kq = P.bits > 0 ? ((kq << P.bits) | cs) : (kq * P.sigma + cs);
-    }
+    const uint64_t kq = text_key(T, lcode, P, n, p, P.k, (((uintptr_t)T) & 7) == 0);
     out[i] = ((kq >> top_shift) << 32) | (uint64_t)(uint32_t)p;      // position in the low half: equal positions are not collisions
 }
 
@@ -1347,24 +1423,27 @@ __global__ __launch_bounds__(256) void k_count_sample_dups(const uint64_t *__res
     if (b && lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(dups, (uint32_t)__popcll(b));
 }
 
-// secondary key of the round that finishes a top-bits initial sort: the low bits of the suffix's own key
-__global__ __launch_bounds__(256) void k_gather_lowkey(const uint32_t *__restrict__ U, const uint32_t *__restrict__ G,
-                                                        const uint64_t *__restrict__ sorted_keys, int64_t m, int low_bits,
-                                                        uint64_t *__restrict__ keys)
+// secondary key of the round that finishes the top-32-bit initial sort: the low bits of the suffix's own key,
+// recomputed from the text (the first stage sorted 32-bit keys only)
+__global__ __launch_bounds__(GK_THREADS) void k_gather_lowkey_text(const uint32_t *__restrict__ V, const uint32_t *__restrict__ G,
+                                                                    const uint8_t *__restrict__ T, KeyParams P, int64_t m, int64_t n,
+                                                                    int low_bits, uint64_t *__restrict__ keys)
 {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j < m) keys[j] = ((uint64_t)G[j] << low_bits) | (sorted_keys[U[j]] & ((1ull << low_bits) - 1ull));
-}
-
-// ... and afterwards the sorted-keys array gets the low bits in their new order (the top bits of a slot did not change)
-__global__ __launch_bounds__(256) void k_fix_lowkeys(const uint32_t *__restrict__ U, const uint64_t *__restrict__ list_keys, int64_t m,
-                                                      int low_bits, uint64_t *__restrict__ sorted_keys)
-{
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint8_t lcode[256];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    __syncthreads();
+    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
+    const int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x;
     if (j < m) {
-        const uint64_t lm = (1ull << low_bits) - 1ull;
-        const uint32_t slot = U[j];
-        sorted_keys[slot] = (sorted_keys[slot] & ~lm) | (list_keys[j] & lm);
+        uint64_t low;
+        if (P.bits > 0 && low_bits % P.bits == 0) {
+            // bit-field keys: the low bits ARE the last low_bits / bits symbols of the key
+            const int ns = low_bits / P.bits;
+            low = text_key(T, lcode, P, n, (int64_t)V[j] + (P.k - ns), ns, aligned8);
+        } else {
+            low = text_key(T, lcode, P, n, (int64_t)V[j], P.k, aligned8) & ((1ull << low_bits) - 1ull);
+        }
+        keys[j] = ((uint64_t)G[j] << low_bits) | low;
     }
 }
 
@@ -1379,8 +1458,11 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_key2_sparse(
     const uint32_t *__restrict__ V, const uint32_t *__restrict__ G, const uint32_t *__restrict__ ISA,
     const uint32_t *__restrict__ has_isa, const uint64_t *__restrict__ sorted_keys, const uint32_t *__restrict__ SA,
     const uint8_t *__restrict__ T, KeyParams P, int64_t m, int64_t n, int64_t h, int64_t depth, int key2_bits,
-    uint64_t *__restrict__ keys)
+    uint64_t *__restrict__ keys, const uint32_t *__restrict__ sorted_top32, int top_shift)
 {
+    // sorted_top32 != nullptr: the first stage sorted only the top 32 key bits (no 64-bit sorted keys exist);
+    // level 1 then searches those, level 2 compares ALL symbols 0 .. depth-1 through the text
+    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
     __shared__ uint8_t lcode[256];
     lcode[threadIdx.x] = P.code[threadIdx.x];
     __syncthreads();
@@ -1394,28 +1476,26 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_key2_sparse(
         } else if ((has_isa[p >> 5] >> (p & 31)) & 1u) {
             key2 = (uint64_t)n + (uint64_t)ISA[p];
         } else {
-            uint64_t kq = 0;
-            for (int i = 0; i < P.k; ++i) {
-                const uint64_t cs = code_at(T, lcode, n, p + i);
-                kq = P.bits > 0 ? ((kq << P.bits) | cs) : (kq * P.sigma + cs);
+            const uint64_t kq = text_key(T, lcode, P, n, p, P.k, aligned8);
+            int64_t lo = 0, hi = n, a = 0;              // [lo, a): slots whose (top) key equals q's
+            if (sorted_top32) {
+                const uint32_t kt = (uint32_t)(kq >> top_shift);
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_top32[mid] < kt) lo = mid + 1; else hi = mid; }
+                a = lo; int64_t b = n;
+                while (a < b) { const int64_t mid = (a + b) >> 1; if (sorted_top32[mid] <= kt) a = mid + 1; else b = mid; }
+            } else {
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_keys[mid] < kq) lo = mid + 1; else hi = mid; }
+                a = lo; int64_t b = n;
+                if (depth > P.k) while (a < b) { const int64_t mid = (a + b) >> 1; if (sorted_keys[mid] <= kq) a = mid + 1; else b = mid; }
             }
-            int64_t lo = 0, hi = n;                      // first slot whose key is >= kq
-            while (lo < hi) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (sorted_keys[mid] < kq) lo = mid + 1; else hi = mid;
-            }
-            if (depth > P.k) {
-                int64_t a = lo, b = n;                   // first slot whose key is > kq
-                while (a < b) {
-                    const int64_t mid = (a + b) >> 1;
-                    if (sorted_keys[mid] <= kq) a = mid + 1; else b = mid;
-                }
-                int64_t l2 = lo, h2 = a;                 // inside [lo, a): first slot not smaller on symbols k .. depth-1
+            const int64_t from = sorted_top32 ? 0 : P.k;  // symbols already decided by level 1
+            if (depth > from && a - lo > 1) {
+                int64_t l2 = lo, h2 = a;                 // inside [lo, a): first slot not smaller on symbols from .. depth-1
                 while (l2 < h2) {
                     const int64_t mid = (l2 + h2) >> 1;
                     const int64_t sfx = (int64_t)SA[mid];
                     bool less = false;                   // suffix at mid < q on those symbols?
-                    for (int64_t i = P.k; i < depth; ++i) {
+                    for (int64_t i = from; i < depth; ++i) {
                         const uint64_t ca = code_at(T, lcode, n, sfx + i), cb = code_at(T, lcode, n, p + i);
                         if (ca != cb) { less = ca < cb; break; }
                     }

@@ -44,6 +44,23 @@ def test_radix_sort_pairs(count, bits):
     assert np.array_equal(k2, keys[order])
 
 
+@pytest.mark.parametrize("count,bits", [(1, (0, 32)), (3, (0, 32)), (16383, (0, 32)), (16384, (0, 32)), (16385, (0, 32)),
+                                        (100_001, (0, 32)), (2_000_003, (0, 32)), (300_000, (8, 24)), (5_000_000, (0, 32))])
+def test_radix_sort_pairs_32bit_keys(count, bits):
+    rng = np.random.default_rng(count + bits[1])
+    keys = rng.integers(0, 2**32, count, dtype=np.uint32)
+    if count > 10:
+        keys[count // 3: count // 3 + count // 10] &= np.uint32(0xFF)
+        keys[-(count // 7):] = 0x01020304
+    vals = np.arange(count, dtype=np.uint32)
+    lo, hi = bits
+    field = (keys.astype(np.uint64) & np.uint64((1 << hi) - 1)) >> np.uint64(lo)
+    order = np.argsort(field, kind="stable")
+    k2, v2 = keys.copy(), vals.copy()
+    assert sa.lib().sa_amd_test_sort_pairs32(k2.ctypes.data, v2.ctypes.data, count, lo, hi) == 0
+    assert np.array_equal(v2, vals[order]) and np.array_equal(k2, keys[order])
+
+
 def test_radix_sort_constant_and_skewed_digits():
     count = 777_777
     keys = np.full(count, 0x0102030405060708, dtype=np.uint64)
