@@ -27,10 +27,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-DOMINANT = "k_radix_downsweep"
+DOMINANT = ("k_radix_downsweep", "k_radix_downsweep32")     # 64-bit-key / 32-bit-key tile scatter: the one with more time
 # algorithmic bytes per unit (element) of each kernel class, DESIGN.md section 3
 ALGO_BYTES = {"k_byte_hist": 1, "k_build_keys": 13, "k_radix_upsweep": 8, "k_radix_downsweep": 24,
-              "k_rr_count": 8, "k_rr_apply": 24, "k_gather_key2": 20, "k_scatter_pairs": 16}
+              "k_rr_count": 8, "k_rr_apply": 24, "k_gather_key2": 20, "k_scatter_pairs": 16,
+              "k_radix_upsweep32": 4, "k_radix_downsweep32": 16}
 
 
 def parse():
@@ -169,9 +170,8 @@ def main():
         if launches[i]:
             kernels[name] = {"ms_per_step": round(ms[i] / args.steps, 3), "launches_per_step": launches[i] / args.steps,
                              "units_per_step": units[i] // args.steps}
-    dom = DOMINANT
-    d_ms, d_launch, d_units = [(ms[i], launches[i], units[i]) for i in range(ncls)
-                               if L.sa_amd_profile_kernel_name(i).decode() == dom][0]
+    d_ms, d_launch, d_units, dom = max((ms[i], launches[i], units[i], L.sa_amd_profile_kernel_name(i).decode())
+                                       for i in range(ncls) if L.sa_amd_profile_kernel_name(i).decode() in DOMINANT)
     avg_ms = d_ms / max(d_launch, 1)
     achieved = (ALGO_BYTES[dom] * d_units) / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
     # HBM traffic of the dominant kernel from the committed PMC passes of this same command (if any)

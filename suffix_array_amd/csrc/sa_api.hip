@@ -46,10 +46,11 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
 enum KClass { KC_BYTE_HIST = 0, KC_BUILD_KEYS, KC_UPSWEEP, KC_SPINE, KC_DOWNSWEEP, KC_RR_COUNT, KC_RR_SCAN, KC_RR_APPLY,
-              KC_GATHER, KC_SCATTER, KC_LOCAL, KC_MISC, KC_COUNT };
+              KC_GATHER, KC_SCATTER, KC_LOCAL, KC_MISC, KC_UPSWEEP32, KC_DOWNSWEEP32, KC_COUNT };
 static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys", "k_radix_upsweep", "k_spine_rows",
                                                     "k_radix_downsweep", "k_rr_count", "k_rr_scan", "k_rr_apply",
-                                                    "k_gather_key2", "k_scatter_pairs", "k_local_window_sort", "misc" };
+                                                    "k_gather_key2", "k_scatter_pairs", "k_local_window_sort", "misc",
+                                                    "k_radix_upsweep32", "k_radix_downsweep32" };
 struct Profiler {
     bool on = false;
     struct Rec { int cls; hipEvent_t a, b; int64_t units; };
@@ -287,11 +288,11 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
             while (split > 1 && chunk / split < 8192) split /= 2;
             const int64_t sub = (ceil_div(chunk, split) + 3) & ~(int64_t)3;
             if (split > 1) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * G * 4, st));
-            PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep32), dim3(G * split), dim3(SORT_THREADS), 0, st,
+            PROF(KC_UPSWEEP32, count, st, hipLaunchKernelGGL((k_radix_upsweep32), dim3(G * split), dim3(SORT_THREADS), 0, st,
                                                            (const uint32_t *)kin, spine, count, shift, dmask, chunk, G, split, sub));
         }
         PROF(KC_SPINE, (int64_t)RADIX * G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st, spine, digit_tot, G));
-        PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((sv.fn),
+        PROF(KC_DOWNSWEEP32, count, st, hipLaunchKernelGGL((sv.fn),
                                                          dim3(G), dim3(SORT32_THREADS), 0, st, (const uint32_t *)kin, (const uint32_t *)vin, kout,
                                                          vdst, (const uint32_t *)spine, (const uint32_t *)digit_tot, count, shift, dmask,
                                                          tiles_per_wg, G));
@@ -364,21 +365,28 @@ static int scatter_binned(uint64_t *pk, uint32_t *pv, uint64_t *altk, uint32_t *
 
 struct Refined { const uint64_t *keys; const uint32_t *vals; uint32_t *vnext; };
 
-// Orders the tied list inside every group by the low `kb` bits of its keys ((group head << kb) | key2).
-// Small groups: in-register window sort (k_local_window_sort); groups no window owns, or everything
-// when *local_ok is off: the global radix sort.  scratchU / scratchG: two free 4n-byte buffers.
-static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *Valt, const uint32_t *Ucur, uint32_t *scratchU,
-                       uint32_t *scratchG, int64_t m, int64_t n, int kb, int g_bits, bool *local_ok, const Workspace &w,
-                       hipStream_t st, sa_amd_stats *local, Refined *out)
+// One refinement round of the tied list with a secondary key taken from the text (KeySrc): afterwards every
+// group is ordered by (group head << kb) | key2.  Small groups: gather fused with the in-LDS group sort
+// (k_group_sort); groups no tile owns, or everything when *local_ok is off: plain gather + global radix sort.
+// scratchU / scratchG: two free 4n-byte buffers.
+static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *Valt, const uint32_t *Ucur, const uint32_t *Gcur,
+                       uint32_t *scratchU, uint32_t *scratchG, int64_t m, int64_t n, const uint8_t *dT, const KeyParams &P,
+                       const KeySrc &K, int g_bits, bool *local_ok, const Workspace &w, hipStream_t st, sa_amd_stats *local,
+                       Refined *out)
 {
     const int64_t tiles = ceil_div(m, RR_TILE);
+    const int kb = K.kb;
     SortResult sr;
     int rc;
-    if (*local_ok && kb <= LW_MAJOR_SHIFT) {
+    if (*local_ok) {
         uint8_t *flags = (uint8_t *)scratchG;
-        const int64_t waves = ceil_div(m, WAVE);
-        PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_local_window_sort), dim3((unsigned)ceil_div(waves, LW_THREADS / WAVE)),
-                                                 dim3(LW_THREADS), 0, st, rkA, Vcur, Ucur, m, kb, flags));
+        const unsigned gs_blocks = (unsigned)ceil_div(m, GS_TILE);
+        if (K.mode == KS_TEXT)
+            PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_TEXT>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags));
+        else
+            PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_LOWKEY>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags));
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     (const uint8_t *)flags, m, w.tcnt));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
@@ -405,6 +413,16 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
             if (m_big * 2 > m) *local_ok = false;           // mostly large groups: not worth another local pass
             return SA_AMD_OK;
         }
+    }
+    else {
+        int64_t gblocks = ceil_div(m, GK_THREADS);
+        if (gblocks > 8192) gblocks = 8192;
+        if (K.mode == KS_TEXT)
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_TEXT>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
+        else
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_LOWKEY>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
     }
     rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, kb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
     if (rc) return rc;
@@ -535,11 +553,10 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                     sorted32, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
                                                     (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
                                                     w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
-        PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_lowkey_text), dim3((unsigned)ceil_div(m, GK_THREADS)), dim3(GK_THREADS), 0, st,
-                                                  (const uint32_t *)Vcur, (const uint32_t *)Gcur, dT, P, m, n, top_shift, rkA));
         uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
         Refined rf;
-        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Unext, Gnext, m, n, top_shift, g_bits, &local_ok, w, st, &local, &rf);
+        KeySrc K; K.mode = KS_LOWKEY; K.h = 0; K.s = 0; K.kb = top_shift;
+        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf);
         if (rc) return rc;
         tiles = ceil_div(m, RR_TILE);
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rf.keys,
@@ -615,12 +632,9 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < MAX_TEXT_ROUNDS && progressing) {
             const int64_t m_before = m;
             uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
-            int64_t gblocks = ceil_div(m, GK_THREADS);
-            if (gblocks > 8192) gblocks = 8192;
-            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
-                                                      (const uint32_t *)Vcur, (const uint32_t *)Gcur, dT, P, m, n, depth, s_sym, tkb, rkA));
             Refined rf;
-            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Unext, Gnext, m, n, tkb, g_bits, &local_ok, w, st, &local, &rf);
+            KeySrc K; K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
+            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf);
             if (rc) return rc;
             const uint64_t *keysS = rf.keys;                  // (group, text key) pairs ordered inside every group
             const uint32_t *valsS = rf.vals;

@@ -1226,130 +1226,153 @@ __device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ T, cons
 
 // Text-keyed refinement round (used while MANY suffixes are still tied): instead of ranks -- which
 // would need the ISA, n random 4-byte writes -- the secondary key is the next `s` symbols of the text
-// itself, T[v+h .. v+h+s), packed like the initial keys into `tkb` bits below the group head.  The
+// itself, T[v+h .. v+h+s), packed like the initial keys into `kb` bits below the group head.  The
 // order after the round is by h + s symbols; depth grows additively, but no rank array exists yet.
+// The round that finishes a top-32-bit initial sort is the same thing with the low `kb` bits of the
+// suffix's own 64-bit key as the secondary key (KS_LOWKEY).
+enum { KS_TEXT = 0, KS_LOWKEY = 1 };
+struct KeySrc {
+    int mode;          // KS_TEXT / KS_LOWKEY
+    int64_t h;         // KS_TEXT: symbols already sorted (offset of the first symbol of the secondary key)
+    int s;             // KS_TEXT: symbols per secondary key
+    int kb;            // bits of the secondary key
+};
+
+template <int MODE>
+__device__ __forceinline__ uint64_t text_key2(const uint8_t *__restrict__ T, const uint8_t *lcode, const KeyParams &P, int64_t n,
+                                              const KeySrc &K, uint32_t v, bool aligned8)
+{
+    if (MODE == KS_TEXT) return text_key(T, lcode, P, n, (int64_t)v + K.h, K.s, aligned8);
+    if (P.bits > 0 && K.kb % P.bits == 0) {
+        // bit-field keys: the low bits ARE the last kb / bits symbols of the key
+        const int ns = K.kb / P.bits;
+        return text_key(T, lcode, P, n, (int64_t)v + (P.k - ns), ns, aligned8);
+    }
+    return text_key(T, lcode, P, n, (int64_t)v, P.k, aligned8) & ((1ull << K.kb) - 1ull);
+}
+
+// plain gather (the tied list then goes through the global radix sort): keys[j] = (group head << kb) | key2
+template <int MODE>
 __global__ __launch_bounds__(GK_THREADS) void k_gather_textkey(const uint32_t *__restrict__ V, const uint32_t *__restrict__ G,
                                                                 const uint8_t *__restrict__ T, KeyParams P, int64_t m, int64_t n,
-                                                                int64_t h, int s, int tkb, uint64_t *__restrict__ keys)
+                                                                KeySrc K, uint64_t *__restrict__ keys)
 {
     __shared__ uint8_t lcode[256];
     lcode[threadIdx.x] = P.code[threadIdx.x];
     __syncthreads();
     const bool aligned8 = (((uintptr_t)T) & 7) == 0;
     const int64_t stride = (int64_t)gridDim.x * GK_THREADS;
-    for (int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x; j < m; j += stride) {
-        const int64_t p = (int64_t)V[j] + h;
-        const uint64_t tk = text_key(T, lcode, P, n, p, s, aligned8);
-        keys[j] = ((uint64_t)G[j] << tkb) | tk;
-    }
+    for (int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x; j < m; j += stride)
+        keys[j] = ((uint64_t)G[j] << K.kb) | text_key2<MODE>(T, lcode, P, n, K, V[j], aligned8);
 }
 
 // ------------------------------------------------------------------------------------------
-// Local refinement of the SMALL groups of a text-keyed round.  After the initial sort the tied
-// suffixes sit in millions of tiny groups (mean size 5-10 on English-like text), so a global
-// 8-pass radix sort of (group head, text key) mostly re-establishes an order it already has.
-// The tied list is in slot order with every group contiguous; one wavefront takes the 128 list
-// elements [64w, 64w + 128) (two per lane), owns the groups that START in its first 64 and END
-// inside the 128, and sorts them with a 128-element bitonic network in registers (28 compare
-// steps, shuffles only; elements it does not own are keyed by their position and do not move).
-// Offset of an element inside its group = its slot minus the group-head slot, so group starts and
-// owners are known without any scan.  Elements of groups no window owns (longer than 64..128)
-// are flagged and go through the global radix sort afterwards.
-//   keys[j] = (group head slot << tkb) | text key      (in/out, list order)
+// k_group_sort: gather of the secondary keys FUSED with the refinement of the small groups.
+// After the initial sort the tied suffixes sit in millions of tiny groups (mean size 5-10 on
+// English-like text), so a global 8-pass radix sort of (group head, key2) mostly re-establishes
+// an order it already has.  The tied list is in slot order with every group contiguous, and the
+// offset of an element inside its group is its slot minus the group-head slot, so group starts
+// are known without a scan.  One workgroup takes GS_TILE consecutive list elements:
+//   1. every thread loads (V, G, U) of its elements and gathers their secondary keys from the
+//      text (the random accesses of the round; all of a thread's loads are in flight together);
+//      keys and a group-start bitmap go to LDS;
+//   2. a group that lies completely inside the tile and has at most GS_CAP members is OWNED: every
+//      member counts the members that order before it (key, then list position) -- an LDS
+//      broadcast read per step, wave cost = its largest group -- which is its place in the group;
+//   3. (key, suffix) pairs are permuted through LDS and stored coalesced.  Members of groups that
+//      are not owned keep their place and are flagged; they go through the global radix sort.
+// Algorithmic traffic per element: 12 B read + the text gather, 13 B written.
 // ------------------------------------------------------------------------------------------
-constexpr int LW_THREADS = 256;
-constexpr int LW_MAJOR_SHIFT = 57;     // 7 bits of window position above the text key (needs tkb <= 57)
+constexpr int GS_THREADS = 256;
+constexpr int GS_ITEMS = 8;
+constexpr int GS_TILE = GS_THREADS * GS_ITEMS;
+constexpr int GS_WORDS = GS_TILE / 64;
+constexpr int GS_CAP = 512;
 
-__device__ __forceinline__ void bitonic_cas(uint64_t &k, uint32_t &v, uint64_t ok, uint32_t ov, bool keep_min)
+template <int MODE>
+__global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, const uint32_t *__restrict__ G,
+                                                            const uint32_t *__restrict__ U, const uint8_t *__restrict__ T, KeyParams P,
+                                                            int64_t m, int64_t n, KeySrc K, uint64_t *__restrict__ keys,
+                                                            uint32_t *Vout, uint8_t *__restrict__ bigflag)   // Vout may be Vin
 {
-    const bool take = keep_min ? (ok < k) : (ok > k);
-    k = take ? ok : k;
-    v = take ? ov : v;
-}
-
-__global__ __launch_bounds__(LW_THREADS) void k_local_window_sort(uint64_t *__restrict__ keys, uint32_t *__restrict__ V,
-                                                                   const uint32_t *__restrict__ U, int64_t m, int tkb,
-                                                                   uint8_t *__restrict__ bigflag)
-{
-    const int64_t w = (int64_t)blockIdx.x * (LW_THREADS / WAVE) + wave_id();
-    const int64_t base = w * WAVE;
-    if (base >= m) return;                                   // whole waves leave together
-    const int l = lane_id();
-    const uint64_t tmask = (1ull << tkb) - 1ull;
-    uint64_t sk[2]; uint32_t sv[2], ghead[2];
-    int64_t start[2];                                        // list index where the element's group starts
-    bool valid[2], head[2];
+    __shared__ uint64_t s_key[GS_TILE];
+    __shared__ uint32_t s_val[GS_TILE];
+    __shared__ uint64_t s_head[GS_WORDS + 1];
+    __shared__ uint8_t lcode[256];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    __syncthreads();
+    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
+    const int64_t base = (int64_t)blockIdx.x * GS_TILE;
+    const int t = threadIdx.x;
+    uint32_t v[GS_ITEMS], g[GS_ITEMS], u[GS_ITEMS];
+    uint64_t key[GS_ITEMS];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int64_t j = base + 64 * r + l;
-        valid[r] = j < m;
-        const uint64_t key = valid[r] ? keys[j] : 0ull;
-        const uint32_t slot = valid[r] ? U[j] : 0u;
-        sv[r] = valid[r] ? V[j] : 0u;
-        ghead[r] = (uint32_t)(key >> tkb);
-        sk[r] = key & tmask;
-        head[r] = !valid[r] || slot == ghead[r];             // past the end counts as a boundary
-        start[r] = j - (int64_t)(slot - ghead[r]);
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        const int64_t j = base + r * GS_THREADS + t;
+        const bool valid = j < m;
+        v[r] = valid ? Vin[j] : 0u;
+        g[r] = valid ? G[j] : 0u;
+        u[r] = valid ? U[j] : 0u;
     }
-    bool head_ext = true;                                    // is list index base + 128 a group boundary?
-    if (base + 128 < m) {
-        const uint64_t kx = keys[base + 128];
-        head_ext = U[base + 128] == (uint32_t)(kx >> tkb);
-    }
-    const uint64_t hm0 = __ballot(head[0]), hm1 = __ballot(head[1]);
-    const uint64_t above = (l == 63) ? 0ull : (~0ull << (l + 1));
-    // end of the element's group = next boundary after its position (relative to base; 255: not within 128)
-    int e[2];
-    {
-        const uint64_t a0 = hm0 & above, a1 = hm1 & above;
-        e[0] = a0 ? __builtin_ctzll(a0) : (hm1 ? 64 + __builtin_ctzll(hm1) : (head_ext ? 128 : 255));
-        e[1] = a1 ? 64 + __builtin_ctzll(a1) : (head_ext ? 128 : 255);
-    }
-    bool mine[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        mine[r] = valid[r] && start[r] >= base && start[r] < base + 64 && e[r] <= 128;
-        const uint64_t major = mine[r] ? (uint64_t)(start[r] - base) : (uint64_t)(64 * r + l);
-        sk[r] = (major << LW_MAJOR_SHIFT) | (mine[r] ? sk[r] : 0ull);
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        const int64_t j = base + r * GS_THREADS + t;
+        key[r] = j < m ? text_key2<MODE>(T, lcode, P, n, K, v[r], aligned8) : 0ull;
     }
-    // first-half elements decide (exactly once per element) whether some window owns their group
-    if (valid[0]) {
-        bool big;
-        if (start[0] >= base) big = e[0] > 128;
-        else if (start[0] >= base - 64) big = e[0] > 64;     // owner is the previous window: its limit is base + 64
-        else big = true;
-        bigflag[base + l] = big ? 1 : 0;
+#pragma unroll
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        const int jl = r * GS_THREADS + t;
+        const bool head = (base + jl >= m) || u[r] == g[r];       // past the end counts as a group start
+        const uint64_t hb = __ballot(head);
+        if (lane_id() == 0) s_head[jl >> 6] = hb;
+        s_key[jl] = key[r];
     }
-    // ---- bitonic sort of the 128 (key, suffix) pairs; position i = 64 r + lane ----
+    if (t == 0) {
+        // does a group start exactly at the first element after the tile?
+        const int64_t jx = base + GS_TILE;
+        s_head[GS_WORDS] = (jx >= m || U[jx] == G[jx]) ? 1ull : 0ull;
+    }
+    __syncthreads();
+    int dest[GS_ITEMS];
+    bool big[GS_ITEMS];
 #pragma unroll
-    for (int k = 2; k <= 128; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j == 64) {                                    // partner is the other register of the same lane (k == 128: ascending)
-                const uint64_t k0 = sk[0], k1 = sk[1];
-                const uint32_t v0 = sv[0], v1 = sv[1];
-                if (k1 < k0) { sk[0] = k1; sv[0] = v1; sk[1] = k0; sv[1] = v0; }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint64_t ok = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(sk[r] >> 32), j, WAVE) << 32) |
-                                        (uint32_t)__shfl_xor((int)(uint32_t)sk[r], j, WAVE);
-                    const uint32_t ov = (uint32_t)__shfl_xor((int)sv[r], j, WAVE);
-                    const int i = 64 * r + l;
-                    const bool asc = (i & k) == 0, lower = (l & j) == 0;
-                    bitonic_cas(sk[r], sv[r], ok, ov, asc == lower);
-                }
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        const int jl = r * GS_THREADS + t;
+        const bool valid = base + jl < m;
+        const int start = jl - (int)(u[r] - g[r]);               // negative: the group starts before the tile
+        // end of the group = next group start after jl (GS_TILE: the tile ends with the group)
+        int end = -1;
+        {
+            int wi = jl >> 6;
+            uint64_t wbits = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
+            const int wlast = min(GS_WORDS, wi + GS_CAP / 64 + 1);
+            while (!wbits && wi < wlast) wbits = s_head[++wi];
+            if (wbits) end = wi * 64 + __builtin_ctzll(wbits);
+        }
+        const bool owned = valid && start >= 0 && end >= 0 && end - start <= GS_CAP;
+        int rank = 0;
+        if (owned) {
+            const uint64_t mine = key[r];
+            for (int i = start; i < end; ++i) {
+                const uint64_t k = s_key[i];
+                rank += (k < mine || (k == mine && i < jl)) ? 1 : 0;
             }
         }
+        dest[r] = owned ? start + rank : jl;
+        big[r] = valid && !owned;
     }
-    // positions inside owned groups receive the sorted pairs; the group head of a position did not change
+    __syncthreads();                                             // every rank is known: the key slots can be reused
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (mine[r]) {
-            const int64_t j = base + 64 * r + l;
-            keys[j] = ((uint64_t)ghead[r] << tkb) | (sk[r] & ((1ull << LW_MAJOR_SHIFT) - 1ull));
-            V[j] = sv[r];
-        }
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        s_key[dest[r]] = ((uint64_t)g[r] << K.kb) | key[r];
+        s_val[dest[r]] = v[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        const int jl = r * GS_THREADS + t;
+        const int64_t j = base + jl;
+        if (j < m) { keys[j] = s_key[jl]; Vout[j] = s_val[jl]; bigflag[j] = big[r] ? 1 : 0; }
     }
 }
 
@@ -1421,30 +1444,6 @@ __global__ __launch_bounds__(256) void k_count_sample_dups(const uint64_t *__res
     if (i > 0 && i < samples) d = (sorted[i] >> 32) == (sorted[i - 1] >> 32) && (uint32_t)sorted[i] != (uint32_t)sorted[i - 1];
     const uint64_t b = __ballot(d);
     if (b && lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(dups, (uint32_t)__popcll(b));
-}
-
-// secondary key of the round that finishes the top-32-bit initial sort: the low bits of the suffix's own key,
-// recomputed from the text (the first stage sorted 32-bit keys only)
-__global__ __launch_bounds__(GK_THREADS) void k_gather_lowkey_text(const uint32_t *__restrict__ V, const uint32_t *__restrict__ G,
-                                                                    const uint8_t *__restrict__ T, KeyParams P, int64_t m, int64_t n,
-                                                                    int low_bits, uint64_t *__restrict__ keys)
-{
-    __shared__ uint8_t lcode[256];
-    lcode[threadIdx.x] = P.code[threadIdx.x];
-    __syncthreads();
-    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
-    const int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x;
-    if (j < m) {
-        uint64_t low;
-        if (P.bits > 0 && low_bits % P.bits == 0) {
-            // bit-field keys: the low bits ARE the last low_bits / bits symbols of the key
-            const int ns = low_bits / P.bits;
-            low = text_key(T, lcode, P, n, (int64_t)V[j] + (P.k - ns), ns, aligned8);
-        } else {
-            low = text_key(T, lcode, P, n, (int64_t)V[j], P.k, aligned8) & ((1ull << low_bits) - 1ull);
-        }
-        keys[j] = ((uint64_t)G[j] << low_bits) | low;
-    }
 }
 
 // Sparse rank lookup (few tied suffixes): no ISA is built.  rank(q) of suffix q under the current order:

@@ -21,10 +21,10 @@ def load(counter_dir):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for f in glob.glob(counter_dir + "/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sa::", "")
-            k = k.split("<")[0]
-            if k.startswith("k_radix_downsweep"):
-                k = "k_radix_downsweep"          # all tile-scatter variants are one kernel class in bench.py
+            full = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sa::", "")
+            k = full.split("<")[0]
+            if k.startswith("k_radix_downsweep"):     # all tile-scatter variants are one kernel class per key width in bench.py
+                k = "k_radix_downsweep32" if "unsigned int>" in full else "k_radix_downsweep"
             agg[k][0] += 1
             agg[k][1] += float(r["Counter_Value"])
     return agg
