@@ -1376,6 +1376,59 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
     }
 }
 
+// The groups k_group_sort could not own only because they straddle a tile boundary: one workgroup per
+// boundary sorts the (at most one) group of up to GS_CAP members that contains it, the same way, on
+// the keys the first kernel stored, and clears its flags.  What stays flagged are groups > GS_CAP.
+constexpr int GX_THREADS = 256;
+constexpr int GX_ITEMS = GS_CAP / GX_THREADS;
+__global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__restrict__ keys, uint32_t *__restrict__ V,
+                                                                     const uint32_t *__restrict__ G, const uint32_t *__restrict__ U,
+                                                                     int64_t m, uint8_t *__restrict__ bigflag)
+{
+    __shared__ uint64_t s_key[GS_CAP];
+    __shared__ int s_end;
+    const int64_t b = ((int64_t)blockIdx.x + 1) * GS_TILE;          // first element of the next tile
+    if (b >= m) return;
+    const uint32_t ub = U[b], gb = G[b];
+    if (ub == gb) return;                                            // a group starts here: nothing straddles
+    const int64_t span = (int64_t)(ub - gb);                         // members before the boundary
+    if (span >= GS_CAP) return;
+    const int64_t start = b - span;
+    const int t = threadIdx.x;
+    if (t == 0) s_end = GS_CAP + 1;
+    __syncthreads();
+    // end of the group: the first group start after the boundary, at most GS_CAP from `start`
+    for (int i = (int)span + 1 + t; i <= GS_CAP; i += GX_THREADS) {
+        const int64_t j = start + i;
+        if (j >= m || U[j] == G[j]) { atomicMin(&s_end, i); break; }
+    }
+    __syncthreads();
+    const int size = s_end;
+    if (size > GS_CAP) return;
+    uint64_t key[GX_ITEMS]; uint32_t v[GX_ITEMS];
+#pragma unroll
+    for (int r = 0; r < GX_ITEMS; ++r) {
+        const int i = r * GX_THREADS + t;
+        key[r] = 0; v[r] = 0;
+        if (i < size) { key[r] = keys[start + i]; v[r] = V[start + i]; s_key[i] = key[r]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < GX_ITEMS; ++r) {
+        const int i = r * GX_THREADS + t;
+        if (i < size) {
+            int rank = 0;
+            for (int q = 0; q < size; ++q) {
+                const uint64_t k = s_key[q];
+                rank += (k < key[r] || (k == key[r] && q < i)) ? 1 : 0;
+            }
+            keys[start + rank] = key[r];
+            V[start + rank] = v[r];
+            bigflag[start + i] = 0;
+        }
+    }
+}
+
 // ---- ordered compaction of the flagged elements (those the local pass could not own) ----
 __global__ __launch_bounds__(RR_THREADS) void k_flag_count(const uint8_t *__restrict__ flag, int64_t m, uint32_t *__restrict__ tile_cnt)
 {
