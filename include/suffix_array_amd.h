@@ -76,7 +76,7 @@ typedef struct sa_amd_stats {
     int64_t unresolved_after_initial; /* suffixes still in groups > 1 after the initial sort */
     int32_t text_rounds;      /* of `rounds`: text-keyed rounds (secondary key read from the text, no rank array) */
     int32_t top32_first;      /* 1: the entropy probe chose to sort on the top 32 key bits first and finish the ties locally */
-    int64_t locally_sorted;   /* tied suffixes refined by the in-register window sort instead of the global radix sort */
+    int64_t locally_sorted;   /* tied suffixes refined by the in-LDS group sort instead of the global radix sort */
 } sa_amd_stats;
 
 /* bytes of device scratch sa_amd_saca_device needs for a text of n bytes */

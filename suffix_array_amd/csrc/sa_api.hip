@@ -49,7 +49,7 @@ enum KClass { KC_BYTE_HIST = 0, KC_BUILD_KEYS, KC_UPSWEEP, KC_SPINE, KC_DOWNSWEE
               KC_GATHER, KC_SCATTER, KC_LOCAL, KC_MISC, KC_UPSWEEP32, KC_DOWNSWEEP32, KC_COUNT };
 static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys", "k_radix_upsweep", "k_spine_rows",
                                                     "k_radix_downsweep", "k_rr_count", "k_rr_scan", "k_rr_apply",
-                                                    "k_gather_key2", "k_scatter_pairs", "k_local_window_sort", "misc",
+                                                    "k_gather_key2", "k_scatter_pairs", "k_group_sort", "misc",
                                                     "k_radix_upsweep32", "k_radix_downsweep32" };
 struct Profiler {
     bool on = false;
@@ -381,15 +381,17 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
     if (*local_ok) {
         uint8_t *flags = (uint8_t *)scratchG;
         const unsigned gs_blocks = (unsigned)ceil_div(m, GS_TILE);
+        int cap = GS_CAP;                                // largest group ordered in LDS (C3: 1024 beats 512 by 1%)
+        if (const char *e = getenv("SA_AMD_GROUP_CAP")) { cap = atoi(e); if (cap < 2) cap = 2; if (cap > GS_CAP) cap = GS_CAP; }
         if (K.mode == KS_TEXT)
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_TEXT>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
-                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags));
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
         else
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_LOWKEY>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
-                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags));
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
         if (gs_blocks > 1)
             PROF(KC_LOCAL, 0, st, hipLaunchKernelGGL((k_group_sort_straddle), dim3(gs_blocks - 1), dim3(GX_THREADS), 0, st, rkA, Vcur, Gcur,
-                                                     Ucur, m, flags));
+                                                     Ucur, m, flags, cap));
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     (const uint8_t *)flags, m, w.tcnt));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));

@@ -1287,13 +1287,13 @@ constexpr int GS_THREADS = 256;
 constexpr int GS_ITEMS = 8;
 constexpr int GS_TILE = GS_THREADS * GS_ITEMS;
 constexpr int GS_WORDS = GS_TILE / 64;
-constexpr int GS_CAP = 512;
+constexpr int GS_CAP = 1024;        // upper bound of the run-time group-size cap
 
 template <int MODE>
 __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, const uint32_t *__restrict__ G,
                                                             const uint32_t *__restrict__ U, const uint8_t *__restrict__ T, KeyParams P,
                                                             int64_t m, int64_t n, KeySrc K, uint64_t *__restrict__ keys,
-                                                            uint32_t *Vout, uint8_t *__restrict__ bigflag)   // Vout may be Vin
+                                                            uint32_t *Vout, uint8_t *__restrict__ bigflag, int cap)   // Vout may be Vin
 {
     __shared__ uint64_t s_key[GS_TILE];
     __shared__ uint32_t s_val[GS_TILE];
@@ -1345,11 +1345,11 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         {
             int wi = jl >> 6;
             uint64_t wbits = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
-            const int wlast = min(GS_WORDS, wi + GS_CAP / 64 + 1);
+            const int wlast = min(GS_WORDS, wi + cap / 64 + 1);
             while (!wbits && wi < wlast) wbits = s_head[++wi];
             if (wbits) end = wi * 64 + __builtin_ctzll(wbits);
         }
-        const bool owned = valid && start >= 0 && end >= 0 && end - start <= GS_CAP;
+        const bool owned = valid && start >= 0 && end >= 0 && end - start <= cap;
         int rank = 0;
         if (owned) {
             const uint64_t mine = key[r];
@@ -1383,7 +1383,7 @@ constexpr int GX_THREADS = 256;
 constexpr int GX_ITEMS = GS_CAP / GX_THREADS;
 __global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__restrict__ keys, uint32_t *__restrict__ V,
                                                                      const uint32_t *__restrict__ G, const uint32_t *__restrict__ U,
-                                                                     int64_t m, uint8_t *__restrict__ bigflag)
+                                                                     int64_t m, uint8_t *__restrict__ bigflag, int cap)
 {
     __shared__ uint64_t s_key[GS_CAP];
     __shared__ int s_end;
@@ -1392,19 +1392,19 @@ __global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__
     const uint32_t ub = U[b], gb = G[b];
     if (ub == gb) return;                                            // a group starts here: nothing straddles
     const int64_t span = (int64_t)(ub - gb);                         // members before the boundary
-    if (span >= GS_CAP) return;
+    if (span >= cap) return;
     const int64_t start = b - span;
     const int t = threadIdx.x;
-    if (t == 0) s_end = GS_CAP + 1;
+    if (t == 0) s_end = cap + 1;
     __syncthreads();
     // end of the group: the first group start after the boundary, at most GS_CAP from `start`
-    for (int i = (int)span + 1 + t; i <= GS_CAP; i += GX_THREADS) {
+    for (int i = (int)span + 1 + t; i <= cap; i += GX_THREADS) {
         const int64_t j = start + i;
         if (j >= m || U[j] == G[j]) { atomicMin(&s_end, i); break; }
     }
     __syncthreads();
     const int size = s_end;
-    if (size > GS_CAP) return;
+    if (size > cap) return;
     uint64_t key[GX_ITEMS]; uint32_t v[GX_ITEMS];
 #pragma unroll
     for (int r = 0; r < GX_ITEMS; ++r) {
@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(256) void k_scatter_back(const uint64_t *__restrict
 // ---- entropy probe + two-stage initial sort ---------------------------------------------------
 // When the top 32 bits of the packed key already separate almost all suffixes (random bytes, DNA),
 // the initial sort only needs those 4 digits; the few ties are finished by a refinement round on the
-// low key bits (in-register window sort).  Whether that holds is measured, not assumed: the keys of
+// low key bits (k_group_sort).  Whether that holds is measured, not assumed: the keys of
 // SAMPLE pseudo-random suffixes are sorted and their duplicates counted (a word-structured text looks
 // harmless under an iid model but is not).
 __global__ __launch_bounds__(GK_THREADS) void k_sample_keys(const uint8_t *__restrict__ T, KeyParams P, int64_t n, int64_t samples,

@@ -278,7 +278,7 @@ def test_refinement_regimes(oracle, monkeypatch, gen, n, seed, div):
                                         ("dna_repeats", 400_000, 5), ("periodic", 100_001, 1), ("sigma2", 250_000, 7)])
 def test_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed):
     """initial sort on the top 32 key bits only, ties finished on the low bits (normally chosen by the
-    entropy probe for large high-entropy texts; forced here), with and without the window sort"""
+    entropy probe for large high-entropy texts; forced here), with and without the in-LDS group sort"""
     if gen == "periodic":
         text = np.resize(np.frombuffer(b"abcab", dtype=np.uint8), n)
     elif gen == "sigma2":
