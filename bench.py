@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DOMINANT = ("k_radix_downsweep", "k_radix_downsweep32")     # 64-bit-key / 32-bit-key tile scatter: the one with more time
 # algorithmic bytes per unit (element) of each kernel class, DESIGN.md section 3
-ALGO_BYTES = {"k_byte_hist": 1, "k_build_keys": 13, "k_radix_upsweep": 8, "k_radix_downsweep": 24,
+ALGO_BYTES = {"k_byte_hist": 1, "k_build_keys": 9, "k_radix_upsweep": 8, "k_radix_downsweep": 24,
               "k_rr_count": 8, "k_rr_apply": 24, "k_gather_key2": 20, "k_scatter_pairs": 16,
               "k_radix_upsweep32": 4, "k_radix_downsweep32": 16}
 

@@ -133,8 +133,11 @@ static const SortVariant sort_variants[] = {
     { 512, 12, 2, k_radix_downsweep_wcl<512, 12, 4, 4>, "carry 512x12, granule 4, <=128 vgpr, 2 workgroups per CU" },
     { 512, 12, 2, k_radix_downsweep_wcl<512, 12, 8, 4>, "carry 512x12, granule 8, <=128 vgpr" },
     { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 16, 1, true>, "carry 1024x8 DIAGNOSTIC phase stamps" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 16, 1, false, uint64_t, 4>, "carry 1024x8 + LDS prefetch of 4/8 of the next tile's keys" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 8, 1, false, uint64_t, 4>, "carry 1024x8 granule 8 + LDS prefetch 4/8" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 8, 1, false, uint64_t, 6>, "carry 1024x8 granule 8 + LDS prefetch 6/8" },
 };
-constexpr int SORT_DEFAULT_VARIANT = 22;
+constexpr int SORT_DEFAULT_VARIANT = 35;
 static const SortVariant &sort_variant()
 {
     static int v = -1;
@@ -206,7 +209,7 @@ struct SortResult { uint64_t *keys; uint32_t *vals; int passes; };
 // straight into SA this way).
 static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, uint32_t *vals_alt, int64_t count,
                       int begin_bit, int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals,
-                      hipStream_t st, SortResult *res)
+                      hipStream_t st, SortResult *res, bool iota = false)   // iota: value i = index i, vals_in is scratch only
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
@@ -232,7 +235,7 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
         PROF(KC_SPINE, (int64_t)RADIX * g.G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st,
                                                                     spine, digit_tot, g.G));
         PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((sv.fn), dim3(g.G), dim3(sv.threads), 0, st,
-                                                         (const uint64_t *)kin, (const uint32_t *)vin, kout, vdst,
+                                                         (const uint64_t *)kin, (const uint32_t *)((iota && res->passes == 0) ? nullptr : vin), kout, vdst,
                                                          (const uint32_t *)spine, (const uint32_t *)digit_tot, count, shift,
                                                          dmask, g.tiles_per_wg, g.G));
         uint64_t *tk = kin; kin = kout; kout = tk;
@@ -255,17 +258,20 @@ static const Sort32Variant sort32_variants[] = {
     { 16, k_radix_downsweep_wcl<SORT32_THREADS, 16, 16, 1, false, uint32_t> },
     { 12, k_radix_downsweep_wcl<SORT32_THREADS, 12, 16, 1, false, uint32_t> },
     { 8, k_radix_downsweep_wcl<SORT32_THREADS, 8, 16, 1, false, uint32_t> },
+    { 12, k_radix_downsweep_wcl<SORT32_THREADS, 12, 16, 1, false, uint32_t, 12> },    // + next tile's keys prefetched into LDS
+    { 8, k_radix_downsweep_wcl<SORT32_THREADS, 8, 16, 1, false, uint32_t, 8> },
 };
 static const Sort32Variant &sort32_variant()
 {
     const char *e = getenv("SA_AMD_SORT32_VARIANT");
-    int v = e ? atoi(e) : 1;          // 1024 x 12: no spills, measured best on C4 / C5
-    if (v < 0 || v > 2) v = 1;
+    int v = e ? atoi(e) : 3;          // 1024 x 12 with the next tile's keys prefetched into LDS: measured best on C4 / C5
+    if (v < 0 || v > 4) v = 3;
     return sort32_variants[v];
 }
 
 static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit,
-                        int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals, hipStream_t st, SortResult32 *res)
+                        int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals, hipStream_t st, SortResult32 *res,
+                        bool iota = false)
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
@@ -293,7 +299,8 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
         }
         PROF(KC_SPINE, (int64_t)RADIX * G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st, spine, digit_tot, G));
         PROF(KC_DOWNSWEEP32, count, st, hipLaunchKernelGGL((sv.fn),
-                                                         dim3(G), dim3(SORT32_THREADS), 0, st, (const uint32_t *)kin, (const uint32_t *)vin, kout,
+                                                         dim3(G), dim3(SORT32_THREADS), 0, st, (const uint32_t *)kin,
+                                                         (const uint32_t *)((iota && res->passes == 0) ? nullptr : vin), kout,
                                                          vdst, (const uint32_t *)spine, (const uint32_t *)digit_tot, count, shift, dmask,
                                                          tiles_per_wg, G));
         uint32_t *tk = kin; kin = kout; kout = tk;
@@ -508,12 +515,15 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     sr.keys = w.keysA; sr.vals = w.valsA; sr.passes = 0;
     const uint32_t *sorted32 = nullptr;               // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
     int rc;
+    // value of pair i = i: not stored by k_build_keys, the first sort pass takes the index (saves 8 B / suffix)
+    const bool iota = n >= 2 && key_bits > 0;
+    uint32_t *vals0 = iota ? (uint32_t *)nullptr : w.valsA;
     if (top_shift) {
         uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
         PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P,
-                                                      (uint64_t *)nullptr, w.valsA, k32a, top_shift));
+                                                      (uint64_t *)nullptr, vals0, k32a, top_shift));
         SortResult32 s32;
-        rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.spine, w.digit_tot, SA, st, &s32);
+        rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.spine, w.digit_tot, SA, st, &s32, iota);
         if (rc) return rc;
         local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
         sorted32 = s32.keys;
@@ -521,8 +531,8 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         sr.keys = (s32.keys == k32a) ? w.keysA : w.keysB;      // the 8n-byte buffer that now holds the sorted 32-bit keys
     } else {
         PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P,
-                                                      w.keysA, w.valsA, (uint32_t *)nullptr, 0));
-        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr);
+                                                      w.keysA, vals0, (uint32_t *)nullptr, 0));
+        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr, iota);
         if (rc) return rc;
         local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
     }

@@ -67,6 +67,47 @@ __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t *lds, ui
     return woff + inc - v;
 }
 
+// LDS-only workgroup barrier: orders LDS traffic (lgkmcnt) but, unlike __syncthreads(), does not drain the
+// vector-memory counter -- a prefetch (global -> LDS DMA) or stores in flight stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// global -> LDS DMA, BYTES per lane (4 or 16); the LDS destination is wave-uniform base + lane * BYTES
+template <int BYTES>
+__device__ __forceinline__ void glds(const void *src, void *lds_dst)
+{
+#if defined(__HIP_DEVICE_COMPILE__)      // the builtin exists in the device pass only
+    if (BYTES == 16) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)lds_dst, 4, 0, 0);
+#endif
+}
+
+// block_excl_sum with LDS-only barriers (RAW = true) or plain ones
+template <int THREADS, bool RAW>
+__device__ __forceinline__ uint32_t block_excl_sum_b(uint32_t v, uint32_t *lds, uint32_t *total)
+{
+    if (!RAW) return block_excl_sum<THREADS>(v, lds, total);
+    constexpr int NW = THREADS / WAVE;
+    const int l = lane_id(), w = wave_id();
+    uint32_t inc = wave_incl_sum(v);
+    if (l == WAVE - 1) lds[w] = inc;
+    lds_barrier();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        uint32_t s = lds[i];
+        if (i < w) woff += s;
+        tot += s;
+    }
+    lds_barrier();
+    *total = tot;
+    return woff + inc - v;
+}
+
 // Inclusive block max-scan over THREADS threads; *total receives the block max. lds: THREADS/64 words.
 template <int THREADS>
 __device__ __forceinline__ uint32_t block_incl_max(uint32_t v, uint32_t *lds, uint32_t *total)
@@ -89,8 +130,10 @@ __device__ __forceinline__ uint32_t block_incl_max(uint32_t v, uint32_t *lds, ui
 }
 
 // ------------------------------------------------------------------------------------------
-// k_byte_hist: sigma = 256 histogram, one private 256-counter table per wave in LDS,
-// merged into the global table with one atomic per (block, byte value).
+// k_byte_hist: WHICH of the 256 byte values occur (hist[c] != 0 <=> c occurs).  The symbol codes
+// and the key geometry only need the set of used values, not their counts, so instead of LDS
+// atomics (which serialise on a 4-symbol text: 0.9 TB/s on DNA) every byte is a plain LDS store
+// of 1 to its flag word -- same-address stores of a wave need no ordering.
 // Algorithmic traffic: 1 B read per input byte.
 // ------------------------------------------------------------------------------------------
 constexpr int BH_THREADS = 256;
@@ -98,10 +141,9 @@ constexpr int BH_THREADS = 256;
 __global__ __launch_bounds__(BH_THREADS) void k_byte_hist(const uint8_t *__restrict__ T, int64_t n,
                                                            uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t h[BH_THREADS / WAVE][256];
-    for (int i = threadIdx.x; i < (BH_THREADS / WAVE) * 256; i += BH_THREADS) (&h[0][0])[i] = 0;
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t *mine = h[wave_id()];
     // 16-byte aligned body, scalar head and tail
     const uintptr_t addr = (uintptr_t)T;
     int64_t head = (int64_t)((16 - (addr & 15)) & 15);
@@ -116,18 +158,15 @@ __global__ __launch_bounds__(BH_THREADS) void k_byte_hist(const uint8_t *__restr
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) atomicAdd(&mine[(w4[a] >> (8 * b)) & 255u], 1u);
+            for (int b = 0; b < 4; ++b) h[(w4[a] >> (8 * b)) & 255u] = 1u;
         }
     }
     if (blockIdx.x == 0) {
-        for (int64_t i = threadIdx.x; i < head; i += BH_THREADS) atomicAdd(&mine[T[i]], 1u);
-        for (int64_t i = head + nvec * 16 + threadIdx.x; i < n; i += BH_THREADS) atomicAdd(&mine[T[i]], 1u);
+        for (int64_t i = threadIdx.x; i < head; i += BH_THREADS) h[T[i]] = 1u;
+        for (int64_t i = head + nvec * 16 + threadIdx.x; i < n; i += BH_THREADS) h[T[i]] = 1u;
     }
     __syncthreads();
-    uint32_t s = 0;
-#pragma unroll
-    for (int w = 0; w < BH_THREADS / WAVE; ++w) s += h[w][threadIdx.x];
-    if (s) atomicAdd(&hist[threadIdx.x], s);
+    if (h[threadIdx.x]) hist[threadIdx.x] = 1u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -220,16 +259,18 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
 #pragma unroll
             for (int r = 0; r < KB_ITEMS / 2; ++r) ko[r] = make_ulonglong2(kk[2 * r], kk[2 * r + 1]);
         }
-        uint4 *vo = (uint4 *)(vals + g0);
-        const uint32_t v0 = (uint32_t)g0;
-        vo[0] = make_uint4(v0, v0 + 1, v0 + 2, v0 + 3);
-        vo[1] = make_uint4(v0 + 4, v0 + 5, v0 + 6, v0 + 7);
+        if (vals) {                                           // nullptr: the first sort pass takes the index as the value
+            uint4 *vo = (uint4 *)(vals + g0);
+            const uint32_t v0 = (uint32_t)g0;
+            vo[0] = make_uint4(v0, v0 + 1, v0 + 2, v0 + 3);
+            vo[1] = make_uint4(v0 + 4, v0 + 5, v0 + 6, v0 + 7);
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < KB_ITEMS; ++r)
             if (g0 + r < n) {
                 if (TOP32) keys32[g0 + r] = (uint32_t)(kk[r] >> top_shift); else keys[g0 + r] = kk[r];
-                vals[g0 + r] = (uint32_t)(g0 + r);
+                if (vals) vals[g0 + r] = (uint32_t)(g0 + r);
             }
     }
 }
@@ -434,7 +475,7 @@ __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ keys_in, 
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = e0 + j * WAVE;
-        val[j] = (FULL || e < valid) ? ((ABLATE & 4) ? __builtin_nontemporal_load(vals_in + base + e) : vals_in[base + e]) : 0u;
+        val[j] = (FULL || e < valid) ? (!vals_in ? (uint32_t)(base + e) : (ABLATE & 4) ? __builtin_nontemporal_load(vals_in + base + e) : vals_in[base + e]) : 0u;
     }
     __syncthreads();
     // thread d: per-wave counts of digit d -> per-wave offsets; exclusive scan of the digit totals
@@ -595,7 +636,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
             const int e = e0 + j * WAVE;
             const bool in = e < rem;
             key[j] = in ? keys_in[tb + e] : ~0ull;
-            val[j] = in ? vals_in[tb + e] : 0u;
+            val[j] = in ? (vals_in ? vals_in[tb + e] : (uint32_t)(tb + e)) : 0u;
         }
     };
     if (tile0 * TILE < n) load_tile(tile0 * TILE);
@@ -783,7 +824,10 @@ __global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
 // diagnostic build only (STAMP): cycles of wave 0 per phase, summed over tiles and workgroups
 __device__ unsigned long long g_phase_cycles[16];
 
-template <int THREADS, int ITEMS, int GR = 16, int MINW = 1, bool STAMP = false, typename KeyT = uint64_t>
+// PF > 0: the first PF of a thread's ITEMS keys of the NEXT tile are prefetched into LDS by global->LDS DMA
+// (no registers) right after this tile's keys are in registers, and stay in flight across the LDS-only
+// barriers of the ranking / prefix / staging phases; the tile's own stores are issued behind them.
+template <int THREADS, int ITEMS, int GR = 16, int MINW = 1, bool STAMP = false, typename KeyT = uint64_t, int PF = 0>
 __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
     const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KeyT *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
@@ -806,6 +850,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
     __shared__ uint32_t aold[RADIX];           // w0 | pending << 28 is too narrow -> w0 only; pending in apnd
     __shared__ uint32_t apnd[RADIX];           // old carry elements to flush this tile (0 when nothing is stored)
     __shared__ uint32_t scan_lds[NWAVES + 1];
+    constexpr int KPL = 16 / (int)sizeof(KeyT);                   // keys per lane of one 16-byte DMA
+    constexpr int PF_WAVE = WAVE * (PF > 0 ? PF : 1);             // prefetched keys per wave
+    static_assert(PF == 0 || (PF % KPL == 0 && PF <= ITEMS), "whole 1 KiB DMA instructions");
+    __shared__ __attribute__((aligned(16))) KeyT next_k[PF > 0 ? THREADS * PF : KPL];
+    bool have_pre = false;                                        // next_k holds this tile's first PF items per thread
 
     const int tid = threadIdx.x, l = lane_id(), w = wave_id();
     uint32_t c0 = 0, w0 = 0;
@@ -827,6 +876,32 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
             t_prev = now;
         }
     };
+    // global -> LDS DMA of (the first PF items per thread of) the tile at nb; LDS index = element index (PF == ITEMS)
+    // or w * PF_WAVE + 64 j + lane.  A full tile moves as 1 KiB wave-instructions, the last partial one dword by dword.
+    auto prefetch = [&](int64_t nb) {
+        if (nb >= n) return;
+        const int64_t left = n - nb;
+        if (left >= TILE) {
+#pragma unroll
+            for (int i = 0; i < PF / KPL; ++i) {
+                const KeyT *src = keys_in + nb + w * WAVE_ELEMS + i * (WAVE * KPL) + l * KPL;
+                glds<16>(src, next_k + w * PF_WAVE + i * (WAVE * KPL));
+            }
+        } else if (PF == ITEMS) {
+            constexpr int DW = (int)sizeof(KeyT) / 4;                // dwords per key
+            const uint32_t *src32 = (const uint32_t *)(keys_in + nb);
+#pragma unroll
+            for (int i = 0; i < PF * DW; ++i) {
+                const int dw = (w * WAVE_ELEMS) * DW + i * WAVE + l;  // dword index inside the tile
+                if (dw < (int)left * DW)
+                    glds<4>(src32 + dw, (uint32_t *)next_k + (w * WAVE_ELEMS) * DW + i * WAVE);
+            }
+        }
+    };
+    if (PF == ITEMS) {
+        prefetch(tile0 * TILE);
+        __syncthreads();                                              // vmcnt(0) + barrier: the first tile's keys are in LDS
+    }
     for (int64_t t = 0; t < tiles_per_wg; ++t) {
         const int64_t base = (tile0 + t) * TILE;
         if (base >= n) break;
@@ -838,10 +913,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int e = e0 + j * WAVE;
-            key[j] = (full || e < valid) ? keys_in[base + e] : (KeyT)~(KeyT)0;
+            if (PF == ITEMS) key[j] = (full || e < valid) ? next_k[e] : (KeyT)~(KeyT)0;          // every key comes through LDS
+            else if (PF > 0 && j < PF && have_pre) key[j] = next_k[w * PF_WAVE + j * WAVE + l];  // (have_pre: the tile is full)
+            else key[j] = (full || e < valid) ? keys_in[base + e] : (KeyT)~(KeyT)0;
         }
         for (int i = tid; i < NWAVES * RADIX / 2; i += THREADS) ((uint32_t *)&wave_hist[0][0])[i] = 0;
         __syncthreads();
+        if (PF == ITEMS && t + 1 < tiles_per_wg) prefetch(base + TILE);   // all waves hold their keys: the buffer takes the next tile
         stamp(0);      // key loads issued, counters zeroed
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -864,13 +942,25 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(1);      // ranking (includes the wait for the keys)
-        uint32_t val[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int e = e0 + j * WAVE;
-            val[j] = (full || e < valid) ? vals_in[base + e] : 0u;
+        if (PF > 0 && PF < ITEMS) {
+            // partial prefetch: issued only now, after the last use of the keys that came by ordinary loads (hipcc waits
+            // vmcnt(0), DMA included, at such a use); it overlaps the prefix, the staging and the carry stores
+            const int64_t nb = base + TILE;
+            have_pre = (t + 1 < tiles_per_wg) && (nb + TILE <= n);
+            if (have_pre) prefetch(nb);
         }
-        __syncthreads();
+        uint32_t val[ITEMS];
+        if (vals_in) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int e = e0 + j * WAVE;
+                val[j] = (full || e < valid) ? vals_in[base + e] : 0u;
+            }
+        } else {                                                  // no values array: the value is the index itself
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) val[j] = (uint32_t)(base + e0 + j * WAVE);
+        }
+        if (PF > 0) lds_barrier(); else __syncthreads();
         stamp(2);      // value loads issued + barrier
         // ---- thread d: per-wave offsets, digit totals, carry bookkeeping ----
         uint32_t tot = 0;
@@ -883,7 +973,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
             }
         }
         uint32_t tile_total;
-        const uint32_t dbase = block_excl_sum<THREADS>(tot, scan_lds, &tile_total);
+        const uint32_t dbase = block_excl_sum_b<THREADS, (PF > 0)>(tot, scan_lds, &tile_total);
         if (tid < RADIX) {
             const uint32_t c1 = c0 + tot;
             const uint32_t fl = c1 & ~(uint32_t)(GR - 1);
@@ -896,7 +986,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
             c0 = c1;
             w0 = w1;
         }
-        __syncthreads();
+        if (PF > 0) lds_barrier(); else __syncthreads();
         stamp(3);      // per-digit prefix + carry bookkeeping
         // ---- keys: stage in sorted order ----
 #pragma unroll
@@ -912,7 +1002,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
             const uint32_t d = i / GR, k = i % GR;
             if (i < (uint32_t)(RADIX * GR) && k < apnd[d]) keys_out[aold[d] + k] = carry_k[i];
         }
-        __syncthreads();
+        if (PF > 0) lds_barrier(); else __syncthreads();     // stores stay in flight across the LDS-only barrier
         stamp(4);      // keys -> LDS, old carry out
         uint32_t dpack[ITEMS / 4];
 #pragma unroll
@@ -928,7 +1018,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
                 else carry_k[d * GR + (gp - lim)] = kx;
             }
         }
-        __syncthreads();
+        if (PF > 0) lds_barrier(); else __syncthreads();     // stores stay in flight across the LDS-only barrier
         stamp(5);      // keys LDS -> global
         // ---- values: the same through the same stage ----
 #pragma unroll
@@ -940,7 +1030,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
             const uint32_t d = i / GR, k = i % GR;
             if (i < (uint32_t)(RADIX * GR) && k < apnd[d]) vals_out[aold[d] + k] = carry_v[i];
         }
-        __syncthreads();
+        if (PF > 0) lds_barrier(); else __syncthreads();     // stores stay in flight across the LDS-only barrier
         stamp(6);      // values -> LDS, old carry out
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
