@@ -495,7 +495,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             if (rcs) return rcs;
             local.sort_passes += ss.passes; local.sorted_elements += (int64_t)ss.passes * S;
             HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
-            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, st,
+            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(64), dim3(256), 0, st,
                                                     (const uint64_t *)ss.keys, S, w.total));
             uint32_t dups = 0;
             HIP_TRY(hipMemcpyAsync(&dups, w.total, 4, hipMemcpyDeviceToHost, st));

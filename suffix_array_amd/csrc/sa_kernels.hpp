@@ -1149,18 +1149,26 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_count(const KeyT *__restrict_
     }
 }
 
-// one workgroup: tile_cnt -> exclusive sums (+ total), tile_head -> exclusive running max
+// one workgroup: tile_cnt -> exclusive sums (+ total), tile_head -> exclusive running max.
+// Every thread owns a contiguous run of entries (a multiple of 4, read and written as 16-byte vectors:
+// the run is a chain of dependent L2 accesses, so fewer, wider ones).
 __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict__ tile_cnt,
                                                             uint32_t *__restrict__ tile_head, int64_t tiles,
                                                             uint32_t *__restrict__ out_total)
 {
     __shared__ uint32_t lds[SPINE_THREADS / WAVE + 1];
-    const int64_t per = (tiles + SPINE_THREADS - 1) / SPINE_THREADS;
+    const int64_t per = ((tiles + SPINE_THREADS - 1) / SPINE_THREADS + 3) & ~(int64_t)3;
     int64_t b = (int64_t)threadIdx.x * per, e = b + per;
     if (b > tiles) b = tiles;
     if (e > tiles) e = tiles;
+    const int64_t ev = b + ((e - b) & ~(int64_t)3);           // end of the whole vectors
     uint32_t s = 0, mx = 0;
-    for (int64_t i = b; i < e; ++i) { s += tile_cnt[i]; uint32_t h = tile_head[i]; mx = mx > h ? mx : h; }
+    for (int64_t i = b; i < ev; i += 4) {
+        const uint4 c = *(const uint4 *)(tile_cnt + i), h = *(const uint4 *)(tile_head + i);
+        s += c.x + c.y + c.z + c.w;
+        mx = max(max(mx, max(h.x, h.y)), max(h.z, h.w));
+    }
+    for (int64_t i = ev; i < e; ++i) { s += tile_cnt[i]; mx = max(mx, tile_head[i]); }
     uint32_t tot, mtot;
     uint32_t off = block_excl_sum<SPINE_THREADS>(s, lds, &tot);
     uint32_t incm = block_incl_max<SPINE_THREADS>(mx, lds, &mtot);
@@ -1171,7 +1179,15 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict_
     __syncthreads();
     if (lane_id() == 0) prevm = wave_id() ? wlast[wave_id() - 1] : 0u;
     uint32_t run = prevm;
-    for (int64_t i = b; i < e; ++i) {
+    for (int64_t i = b; i < ev; i += 4) {
+        const uint4 c = *(const uint4 *)(tile_cnt + i), h = *(const uint4 *)(tile_head + i);
+        uint4 oc, oh;
+        oc.x = off; off += c.x; oc.y = off; off += c.y; oc.z = off; off += c.z; oc.w = off; off += c.w;
+        oh.x = run; run = max(run, h.x); oh.y = run; run = max(run, h.y); oh.z = run; run = max(run, h.z); oh.w = run; run = max(run, h.w);
+        *(uint4 *)(tile_cnt + i) = oc;
+        *(uint4 *)(tile_head + i) = oh;
+    }
+    for (int64_t i = ev; i < e; ++i) {
         uint32_t c = tile_cnt[i], h = tile_head[i];
         tile_cnt[i] = off; off += c;
         tile_head[i] = run; run = run > h ? run : h;
@@ -1488,11 +1504,15 @@ __global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__
     if (t == 0) s_end = cap + 1;
     __syncthreads();
     // end of the group: the first group start after the boundary, at most GS_CAP from `start`
-    for (int i = (int)span + 1 + t; i <= cap; i += GX_THREADS) {
+    // (searched 256 positions at a time: most groups end within the first few)
+    for (int i0 = (int)span + 1; i0 <= cap; i0 += GX_THREADS) {
+        const int i = i0 + t;
         const int64_t j = start + i;
-        if (j >= m || U[j] == G[j]) { atomicMin(&s_end, i); break; }
+        if (i <= cap && (j >= m || U[j] == G[j])) atomicMin(&s_end, i);
+        __syncthreads();
+        if (s_end <= cap) break;                                     // uniform: every thread reads the same value
+        __syncthreads();
     }
-    __syncthreads();
     const int size = s_end;
     if (size > cap) return;
     uint64_t key[GX_ITEMS]; uint32_t v[GX_ITEMS];
@@ -1582,11 +1602,20 @@ __global__ __launch_bounds__(GK_THREADS) void k_sample_keys(const uint8_t *__res
 
 __global__ __launch_bounds__(256) void k_count_sample_dups(const uint64_t *__restrict__ sorted, int64_t samples, uint32_t *__restrict__ dups)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool d = false;
-    if (i > 0 && i < samples) d = (sorted[i] >> 32) == (sorted[i - 1] >> 32) && (uint32_t)sorted[i] != (uint32_t)sorted[i - 1];
-    const uint64_t b = __ballot(d);
-    if (b && lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(dups, (uint32_t)__popcll(b));
+    // grid-stride, one atomic per workgroup (one per wave serialised 16 Ki atomics on one address: 190 us)
+    __shared__ uint32_t wsum[256 / WAVE];
+    uint32_t c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < samples; i += (int64_t)gridDim.x * 256)
+        if (i > 0) c += ((sorted[i] >> 32) == (sorted[i - 1] >> 32) && (uint32_t)sorted[i] != (uint32_t)sorted[i - 1]) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
+    if (lane_id() == 0) wsum[wave_id()] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 256 / WAVE; ++w) t += wsum[w];
+        if (t) atomicAdd(dups, t);
+    }
 }
 
 // Sparse rank lookup (few tied suffixes): no ISA is built.  rank(q) of suffix q under the current order:
