@@ -98,46 +98,18 @@ typedef void (*DownsweepFn)(const uint64_t *, const uint32_t *, uint64_t *, uint
                             const uint32_t *, int64_t, int, uint32_t, int64_t, int);
 struct SortVariant { int threads, items, wg_per_cu; DownsweepFn fn; const char *name; };
 static const SortVariant sort_variants[] = {
-    { 256, 16, 4, k_radix_downsweep<256, 16, 1>, "256x16" },
-    { 256, 16, 4, k_radix_downsweep<256, 16, 4>, "256x16 <=128 vgpr" },
-    { 512, 16, 1, k_radix_downsweep<512, 16, 1>, "512x16" },
-    { 512, 16, 2, k_radix_downsweep<512, 16, 4>, "512x16 <=128 vgpr" },
-    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8>, "1024x8 <=64 vgpr" },
-    { 256, 8, 4, k_radix_downsweep<256, 8, 4>, "256x8 <=128 vgpr" },
-    { 512, 8, 4, k_radix_downsweep<512, 8, 8>, "512x8 <=64 vgpr" },
-    { 256, 12, 4, k_radix_downsweep<256, 12, 4>, "256x12 <=128 vgpr" },
-    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 1>, "1024x8 ABLATION sequential stores (wrong results)" },
-    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 33>, "1024x8 ABLATION no ranking + sequential stores (wrong results)" },
-    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 16>, "1024x8 ABLATION no stores (wrong results)" },
-    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 49>, "1024x8 ABLATION no ranking, no stores (wrong results)" },
-    { 512, 16, 1, k_radix_downsweep<512, 16, 2, 1>, "512x16 ABLATION sequential stores" },
-    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 4>, "1024x8 nt loads" },
-    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 8>, "1024x8 nt stores" },
-    { 1024, 8, 2, k_radix_downsweep<1024, 8, 8, 12>, "1024x8 nt loads+stores" },
-    { 1024, 8, 1, k_radix_downsweep<1024, 8, 8, 0>, "1024x8, 256 workgroups" },
-    { 512, 12, 1, k_radix_downsweep_wc<512, 12>, "write-combined 512x12" },
-    { 512, 16, 1, k_radix_downsweep_wc<512, 16>, "write-combined 512x16" },
-    { 512, 16, 1, k_radix_downsweep_wc<512, 16, 16>, "write-combined 512x16 ABLATION no stores" },
-    { 512, 8, 1, k_radix_downsweep_wc<512, 8>, "write-combined 512x8" },
-    { 256, 16, 1, k_radix_downsweep_wc<256, 16>, "write-combined 256x16" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 16, 1, false, uint64_t, 4>, "carry-completed lines 1024x8 + LDS prefetch of half of the next tile's keys (default)" },
     { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 4>, "plain tile scatter 1024x8 (first generation)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 4, 1>, "plain 1024x8 ABLATION sequential stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 4, 33>, "plain 1024x8 ABLATION no ranking + sequential stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 4, 16>, "plain 1024x8 ABLATION no stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 4, 49>, "plain 1024x8 ABLATION no ranking, no stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 16, 1, true>, "carry 1024x8 DIAGNOSTIC phase stamps (tools/phase_stamps.py)" },
     { 512, 16, 1, k_radix_downsweep_wcl<512, 16>, "carry-completed lines 512x16" },
-    { 1024, 8, 1, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8, 256 workgroups" },
-    { 1024, 8, 4, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8, 1024 workgroups" },
-    { 1024, 12, 1, k_radix_downsweep_wcl<1024, 12>, "carry-completed lines 1024x12" },
-    { 512, 20, 1, k_radix_downsweep_wcl<512, 20>, "carry-completed lines 512x20" },
-    { 512, 8, 2, k_radix_downsweep_wcl<512, 8, 8>, "carry 512x8, granule 8, 2 workgroups per CU" },
-    { 256, 16, 2, k_radix_downsweep_wcl<256, 16, 8>, "carry 256x16, granule 8, 2 workgroups per CU" },
     { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 8>, "carry 1024x8, granule 8" },
-    { 512, 8, 4, k_radix_downsweep_wcl<512, 8, 4>, "carry 512x8, granule 4, 2-3 workgroups per CU" },
-    { 512, 12, 2, k_radix_downsweep_wcl<512, 12, 4, 4>, "carry 512x12, granule 4, <=128 vgpr, 2 workgroups per CU" },
-    { 512, 12, 2, k_radix_downsweep_wcl<512, 12, 8, 4>, "carry 512x12, granule 8, <=128 vgpr" },
-    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 16, 1, true>, "carry 1024x8 DIAGNOSTIC phase stamps" },
-    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 16, 1, false, uint64_t, 4>, "carry 1024x8 + LDS prefetch of 4/8 of the next tile's keys" },
-    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 8, 1, false, uint64_t, 4>, "carry 1024x8 granule 8 + LDS prefetch 4/8" },
-    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 8, 1, false, uint64_t, 6>, "carry 1024x8 granule 8 + LDS prefetch 6/8" },
 };
-constexpr int SORT_DEFAULT_VARIANT = 35;
+constexpr int SORT_DEFAULT_VARIANT = 0;
 static const SortVariant &sort_variant()
 {
     static int v = -1;
@@ -255,17 +227,17 @@ typedef void (*Downsweep32Fn)(const uint32_t *, const uint32_t *, uint32_t *, ui
                               uint32_t, int64_t, int);
 struct Sort32Variant { int items; Downsweep32Fn fn; };
 static const Sort32Variant sort32_variants[] = {
-    { 16, k_radix_downsweep_wcl<SORT32_THREADS, 16, 16, 1, false, uint32_t> },
+    { 12, k_radix_downsweep_wcl<SORT32_THREADS, 12, 16, 1, false, uint32_t, 12> },    // default: next tile's keys prefetched into LDS
     { 12, k_radix_downsweep_wcl<SORT32_THREADS, 12, 16, 1, false, uint32_t> },
     { 8, k_radix_downsweep_wcl<SORT32_THREADS, 8, 16, 1, false, uint32_t> },
-    { 12, k_radix_downsweep_wcl<SORT32_THREADS, 12, 16, 1, false, uint32_t, 12> },    // + next tile's keys prefetched into LDS
+    { 16, k_radix_downsweep_wcl<SORT32_THREADS, 16, 16, 1, false, uint32_t> },        // spills
     { 8, k_radix_downsweep_wcl<SORT32_THREADS, 8, 16, 1, false, uint32_t, 8> },
 };
 static const Sort32Variant &sort32_variant()
 {
     const char *e = getenv("SA_AMD_SORT32_VARIANT");
-    int v = e ? atoi(e) : 3;          // 1024 x 12 with the next tile's keys prefetched into LDS: measured best on C4 / C5
-    if (v < 0 || v > 4) v = 3;
+    int v = e ? atoi(e) : 0;          // 1024 x 12 with the next tile's keys prefetched into LDS: measured best on C4 / C5
+    if (v < 0 || v > 4) v = 0;
     return sort32_variants[v];
 }
 

@@ -574,243 +574,6 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep(
 }
 
 // ------------------------------------------------------------------------------------------
-// k_radix_downsweep_wc: the same pass with LDS write combining.
-//
-// Measured on MI355X (profiles/r01_ablation.txt): with the plain tile scatter above, a digit's run
-// leaves a tile as ~16-32 elements at an arbitrary offset, i.e. as partial 128-B lines that the
-// per-XCD L2 has to keep until the workgroup's next tile completes them; the same kernel with
-// sequential stores runs 1.8x faster.  Here every workgroup keeps, per digit, the (< 16) elements
-// that do not yet fill a 16-element granule in an LDS carry buffer and only ever stores whole,
-// 16-element-aligned granules (128 B of keys, 64 B of values), except once per (workgroup, digit)
-// at the two ends of its chunk.
-//
-// Per tile and digit d (thread d does the bookkeeping):
-//   cur[d]   next global position of digit d in this workgroup's chunk
-//   wr[d]    everything below has been stored; pending = cur - wr < 16 elements sit in carry[d]
-//   stream   = carry (pending) followed by the tile's elements of digit d in rank order
-//   new wr   = cur' rounded down to 16 if that is beyond wr; the span [wr, new wr) is stored as
-//              granules, 16 consecutive lanes per granule; the rest of the stream becomes the carry
-// ------------------------------------------------------------------------------------------
-constexpr int WC_GR = 16;   // granule, elements
-
-template <int THREADS, int ITEMS, int ABLATE = 0>
-__global__ __launch_bounds__(THREADS) void k_radix_downsweep_wc(
-    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
-    int64_t n, int shift, uint32_t dmask, int64_t tiles_per_wg, int G)
-{
-    constexpr int TILE = THREADS * ITEMS;
-    constexpr int NWAVES = THREADS / WAVE;
-    constexpr int WAVE_ELEMS = WAVE * ITEMS;
-    constexpr int MAXGROUPS = TILE / WC_GR + RADIX;
-    static_assert(THREADS >= RADIX, "one thread per digit is assumed");
-    static_assert(TILE < (1 << 14), "carry record packs a 14-bit stage index");
-    __shared__ __attribute__((aligned(16))) uint64_t stage_k[TILE];
-    __shared__ __attribute__((aligned(16))) uint64_t carry_k[RADIX * WC_GR];
-    __shared__ __attribute__((aligned(16))) uint32_t stage_v[TILE];
-    __shared__ __attribute__((aligned(16))) uint32_t carry_v[RADIX * WC_GR];
-    __shared__ uint32_t wave_hist[NWAVES][RADIX];
-    __shared__ __attribute__((aligned(16))) uint4 drec[RADIX];     // {A, first granule, o | pending << 8, digit_base}
-    __shared__ uint32_t crec[RADIX];                                // carry copy: src0 | dst0 << 14 | count << 18
-    __shared__ uint32_t gstart[RADIX + 1];                          // exclusive scan of the granule counts
-    __shared__ uint8_t group_digit[MAXGROUPS];
-    __shared__ uint32_t scan_lds[NWAVES + 1];
-
-    const int tid = threadIdx.x, l = lane_id(), w = wave_id();
-    uint32_t c0 = 0, w0 = 0;          // thread d: next global position of digit d / everything below is stored
-    {
-        uint32_t all;
-        const uint32_t t = tid < RADIX ? digit_tot[tid] : 0u;
-        const uint32_t gbase = block_excl_sum<THREADS>(t, scan_lds, &all);
-        if (tid < RADIX) c0 = w0 = gbase + spine[(int64_t)tid * G + blockIdx.x];
-    }
-    uint32_t *my_hist = wave_hist[w];
-    const int e0 = w * WAVE_ELEMS + l;
-    const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
-    uint64_t key[ITEMS];
-    uint32_t val[ITEMS];
-    auto load_tile = [&](int64_t tb) {     // keys and values of the tile starting at element tb
-        const int64_t rem = n - tb;
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int e = e0 + j * WAVE;
-            const bool in = e < rem;
-            key[j] = in ? keys_in[tb + e] : ~0ull;
-            val[j] = in ? (vals_in ? vals_in[tb + e] : (uint32_t)(tb + e)) : 0u;
-        }
-    };
-    if (tile0 * TILE < n) load_tile(tile0 * TILE);
-    for (int64_t t = 0; t < tiles_per_wg; ++t) {
-        const int64_t base = (tile0 + t) * TILE;
-        if (base >= n) break;
-        const int valid = (n - base) >= TILE ? TILE : (int)(n - base);
-        const bool full = valid == TILE;
-        uint32_t pos[ITEMS];
-        for (int i = tid; i < NWAVES * RADIX; i += THREADS) (&wave_hist[0][0])[i] = 0;
-        __syncthreads();
-        // Ranking.  For every item the lanes holding the same digit are found with 8 ballots (~x is the
-        // match mask).  The lowest matching lane adds the group size to the wave's LDS counter of that
-        // digit with ONE returning LDS atomic; a wave's LDS operations execute in issue order, so the
-        // counters see the items in tile order although all ITEMS atomics are in flight together.  The
-        // returned prior count is handed to the other lanes of the group by a shuffle afterwards.
-        uint32_t prior[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const bool ok = full || (e0 + j * WAVE) < valid;
-            const uint32_t d = digit_of(key[j], shift, dmask);
-            const uint64_t okm = __ballot(ok);
-            uint32_t xlo = ~(uint32_t)okm, xhi = ~(uint32_t)(okm >> 32);
-#pragma unroll
-            for (int b = 0; b < RADIX_BITS; ++b) {
-                const uint32_t sel = (uint32_t)((int32_t)(d << (31 - b)) >> 31);
-                const uint64_t bal = __ballot(sel != 0);
-                xlo |= (uint32_t)bal ^ sel;
-                xhi |= (uint32_t)(bal >> 32) ^ sel;
-            }
-            const uint32_t mlo = ~xlo, mhi = ~xhi;
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-            const uint32_t leader = mlo ? (uint32_t)__builtin_ctz(mlo) : 32u + (uint32_t)__builtin_ctz(mhi | 0x80000000u);
-            pos[j] = below | (leader << 8);
-            prior[j] = 0;
-            if (ok && below == 0)
-                prior[j] = __hip_atomic_fetch_add(&my_hist[d], (uint32_t)(__popc(mlo) + __popc(mhi)), __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const uint32_t p = (uint32_t)__shfl((int)prior[j], (int)(pos[j] >> 8), WAVE);
-            pos[j] = p + (pos[j] & 255u);
-        }
-        __syncthreads();
-        // ---- per-digit bookkeeping (thread d) ----
-        uint32_t tot = 0;
-        if (tid < RADIX) {
-#pragma unroll
-            for (int ww = 0; ww < NWAVES; ++ww) {
-                const uint32_t cnt = wave_hist[ww][tid];
-                wave_hist[ww][tid] = tot;
-                tot += cnt;
-            }
-        }
-        uint32_t tile_total;
-        const uint32_t dbase = block_excl_sum<THREADS>(tot, scan_lds, &tile_total);
-        uint32_t ng = 0, A = 0, o = 0, pending = 0, c1 = 0, w1 = 0, cr = 0;
-        if (tid < RADIX) {
-            pending = c0 - w0;
-            c1 = c0 + tot;
-            const uint32_t fl = c1 & ~(uint32_t)(WC_GR - 1);
-            w1 = fl > w0 ? fl : w0;
-            const uint32_t span = w1 - w0;
-            A = w0 & ~(uint32_t)(WC_GR - 1);
-            o = w0 - A;
-            ng = span ? (w1 - A) / WC_GR : 0u;
-            // what stays behind: stage[src0 + k] -> carry[dst0 + k], k < count
-            if (span) cr = (dbase + span - pending) | (0u << 14) | ((c1 - w1) << 18);
-            else cr = dbase | (pending << 14) | (tot << 18);
-        }
-        uint32_t ngroups;
-        const uint32_t gb = block_excl_sum<THREADS>(ng, scan_lds, &ngroups);
-        if (tid < RADIX) {
-            drec[tid] = make_uint4(A, gb, o | (pending << 8), dbase);
-            crec[tid] = cr;
-            gstart[tid] = gb;
-            c0 = c1;
-            w0 = w1;
-        }
-        if (tid == 0) gstart[RADIX] = ngroups;
-        __syncthreads();
-        // ---- keys and values into the stage in sorted order; granule -> digit table ----
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const uint32_t d = digit_of(key[j], shift, dmask);
-            if (full || (e0 + j * WAVE) < valid) {
-                const uint32_t p = pos[j] + drec[d].w + my_hist[d];
-                stage_k[p] = key[j];
-                stage_v[p] = val[j];
-            }
-        }
-        // the registers are free again: fetch the next tile now, its latency hides behind the stores
-        if (t + 1 < tiles_per_wg && base + TILE < n) load_tile(base + TILE);
-        for (uint32_t g = tid; g < ngroups; g += THREADS) {
-            // last digit whose first granule index is <= g (digits without granules share a start)
-            uint32_t lo = 0, hi = RADIX;
-#pragma unroll
-            for (int it = 0; it < RADIX_BITS; ++it) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (gstart[mid] <= g) lo = mid; else hi = mid;
-            }
-            group_digit[g] = (uint8_t)lo;
-        }
-        __syncthreads();
-        // ---- store whole granules: 16 consecutive lanes = one 128-B key line + one 64-B value block ----
-        // (four output slots per thread and step so that the dependent LDS reads of the slots overlap)
-        {
-            const uint32_t total = ngroups * WC_GR;
-            for (uint32_t idx0 = tid; idx0 < total; idx0 += 4 * THREADS) {
-                uint32_t gp[4], sidx[4];
-                bool live[4], from_carry[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t idx = idx0 + u * THREADS;
-                    const bool in = idx < total;
-                    const uint32_t g = in ? idx / WC_GR : 0u, k = idx % WC_GR;
-                    const uint32_t d = group_digit[g];
-                    const uint4 r = drec[d];
-                    const uint32_t tt = (g - r.y) * WC_GR + k;
-                    const uint32_t od = r.z & 255u, pd = r.z >> 8;
-                    const uint32_t q = tt - od;                      // index in the digit's stream
-                    live[u] = in && tt >= od;
-                    from_carry[u] = q < pd;
-                    gp[u] = r.x + tt;
-                    sidx[u] = from_carry[u] ? d * WC_GR + q : r.w + q - pd;
-                    if (!live[u]) { sidx[u] = 0; from_carry[u] = false; }
-                }
-                uint64_t kx[4]; uint32_t vx[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    kx[u] = from_carry[u] ? carry_k[sidx[u]] : stage_k[sidx[u]];
-                    vx[u] = from_carry[u] ? carry_v[sidx[u]] : stage_v[sidx[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if ((ABLATE & 16) && gp[u] != 0x7fffffffu) continue;      // timing-only build: no stores
-                    if (live[u]) { keys_out[gp[u]] = kx[u]; vals_out[gp[u]] = vx[u]; }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- new carry: the stream elements behind the stored span ----
-        {
-            constexpr int STEPS = RADIX * WC_GR / THREADS;
-            uint64_t ck[STEPS]; uint32_t cv[STEPS], dst[STEPS];
-            bool mv[STEPS];
-#pragma unroll
-            for (int u = 0; u < STEPS; ++u) {
-                const uint32_t i = (uint32_t)tid + (uint32_t)u * THREADS;
-                const uint32_t d = i / WC_GR, k = i % WC_GR;
-                const uint32_t c = crec[d];
-                mv[u] = k < (c >> 18);
-                const uint32_t src = mv[u] ? (c & 0x3fffu) + k : 0u;
-                dst[u] = d * WC_GR + ((c >> 14) & 15u) + k;
-                ck[u] = stage_k[src];
-                cv[u] = stage_v[src];
-            }
-#pragma unroll
-            for (int u = 0; u < STEPS; ++u)
-                if (mv[u]) { carry_k[dst[u]] = ck[u]; carry_v[dst[u]] = cv[u]; }
-        }
-        __syncthreads();
-    }
-    // ---- flush what is left in the carries (at most 15 elements per digit) ----
-    if (tid < RADIX) { drec[tid].x = w0; drec[tid].y = c0 - w0; }
-    __syncthreads();
-    for (int i = tid; i < RADIX * WC_GR; i += THREADS) {
-        const uint32_t d = (uint32_t)i / WC_GR, k = (uint32_t)i % WC_GR;
-        if (k < drec[d].y) { keys_out[drec[d].x + k] = carry_k[i]; vals_out[drec[d].x + k] = carry_v[i]; }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // k_radix_downsweep_wcl: the plain tile scatter of k_radix_downsweep plus a per-digit LDS carry, so
 // that every 128-byte line a tile touches is completed by that same tile (within microseconds,
 // from one CU) instead of by the workgroup's next tile (tens of microseconds later, after the

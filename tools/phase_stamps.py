@@ -1,6 +1,6 @@
 """Diagnostic: where a tile of the dominant kernel spends its cycles (in-kernel s_memtime stamps)."""
 import sys, os, ctypes
-os.environ["SA_AMD_SORT_VARIANT"] = sys.argv[1] if len(sys.argv) > 1 else "34"
+os.environ["SA_AMD_SORT_VARIANT"] = sys.argv[1] if len(sys.argv) > 1 else "7"
 os.environ["SA_AMD_TIMING_ONLY_INITIAL_SORT"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
