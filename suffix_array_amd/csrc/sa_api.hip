@@ -94,7 +94,7 @@ constexpr int SORT_MAX_WG = 1024;   // spine rows are scanned by one 1024-thread
 
 // downsweep configurations (threads, items per thread, min waves per SIMD); SA_AMD_SORT_VARIANT
 // selects one at run time for A/B measurements, the default is the fastest measured on MI355X
-typedef void (*DownsweepFn)(const uint64_t *, const uint32_t *, uint64_t *, uint32_t *, const uint32_t *,
+typedef void (*DownsweepFn)(const uint64_t *, const uint32_t *, uint64_t *, uint32_t *, uint32_t *,
                             const uint32_t *, int64_t, int, uint32_t, int64_t, int);
 struct SortVariant { int threads, items, wg_per_cu; DownsweepFn fn; const char *name; };
 static const SortVariant sort_variants[] = {
@@ -200,7 +200,8 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
             if (split < 1) split = 1;
             while (split > 1 && chunk / split < 4096) split /= 2;
             const int64_t sub = (ceil_div(chunk, split) + 1) & ~(int64_t)1;
-            if (split > 1) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * g.G * 4, st));
+            // (atomic accumulation needs a zeroed spine: once here, afterwards every downsweep zeroes what it consumed)
+            if (split > 1 && res->passes == 0) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * g.G * 4, st));
             PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.G * split), dim3(SORT_THREADS), 0, st, kin, spine,
                                                            count, shift, dmask, chunk, g.G, split, sub));
         }
@@ -208,7 +209,7 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
                                                                     spine, digit_tot, g.G));
         PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((sv.fn), dim3(g.G), dim3(sv.threads), 0, st,
                                                          (const uint64_t *)kin, (const uint32_t *)((iota && res->passes == 0) ? nullptr : vin), kout, vdst,
-                                                         (const uint32_t *)spine, (const uint32_t *)digit_tot, count, shift,
+                                                         spine, (const uint32_t *)digit_tot, count, shift,
                                                          dmask, g.tiles_per_wg, g.G));
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *free_v = vin;     // the values just consumed become the next scratch target
@@ -223,7 +224,7 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
 // 32-bit keys (two-stage initial sort): same three-kernel pass, 16 Ki-pair tiles (the 64 KiB stage holds twice the elements)
 struct SortResult32 { uint32_t *keys; uint32_t *vals; int passes; };
 constexpr int SORT32_THREADS = 1024;
-typedef void (*Downsweep32Fn)(const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint32_t *, int64_t, int,
+typedef void (*Downsweep32Fn)(const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, int64_t, int,
                               uint32_t, int64_t, int);
 struct Sort32Variant { int items; Downsweep32Fn fn; };
 static const Sort32Variant sort32_variants[] = {
@@ -265,7 +266,7 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
             if (split < 1) split = 1;
             while (split > 1 && chunk / split < 8192) split /= 2;
             const int64_t sub = (ceil_div(chunk, split) + 3) & ~(int64_t)3;
-            if (split > 1) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * G * 4, st));
+            if (split > 1 && res->passes == 0) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * G * 4, st));
             PROF(KC_UPSWEEP32, count, st, hipLaunchKernelGGL((k_radix_upsweep32), dim3(G * split), dim3(SORT_THREADS), 0, st,
                                                            (const uint32_t *)kin, spine, count, shift, dmask, chunk, G, split, sub));
         }
@@ -273,7 +274,7 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
         PROF(KC_DOWNSWEEP32, count, st, hipLaunchKernelGGL((sv.fn),
                                                          dim3(G), dim3(SORT32_THREADS), 0, st, (const uint32_t *)kin,
                                                          (const uint32_t *)((iota && res->passes == 0) ? nullptr : vin), kout,
-                                                         vdst, (const uint32_t *)spine, (const uint32_t *)digit_tot, count, shift, dmask,
+                                                         vdst, spine, (const uint32_t *)digit_tot, count, shift, dmask,
                                                          tiles_per_wg, G));
         uint32_t *tk = kin; kin = kout; kout = tk;
         uint32_t *free_v = vin;
@@ -320,6 +321,28 @@ static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out)
 }
 
 // binned ISA update pays off once the ISA is far larger than the caches and there is enough to write
+// Small device -> host read-backs (counts that steer the host loop) go through a pinned per-thread buffer:
+// a 4-byte hipMemcpyAsync into pageable memory costs ~50-90 us per round trip, into pinned memory ~10.
+struct PinnedWords {
+    uint32_t *p = nullptr;
+    ~PinnedWords() { if (p) (void)hipHostFree(p); }
+};
+static thread_local PinnedWords g_pinned;
+static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)     // bytes <= 1024; synchronises the stream
+{
+    if (!g_pinned.p && hipHostMalloc((void **)&g_pinned.p, 1024, hipHostMallocDefault) != hipSuccess) {
+        g_pinned.p = nullptr;
+        (void)hipGetLastError();
+        HIP_TRY(hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return SA_AMD_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(g_pinned.p, dsrc, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(dst, g_pinned.p, bytes);
+    return SA_AMD_OK;
+}
+
 static bool binned(int64_t n, int64_t count)
 {
     if (getenv("SA_AMD_NO_BINNED_ISA")) return false;
@@ -375,8 +398,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
                                                     (const uint8_t *)flags, m, w.tcnt));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
         uint32_t big32 = 0;
-        HIP_TRY(hipMemcpyAsync(&big32, w.total, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        { const int rcw = read_words(&big32, w.total, 4, st); if (rcw) return rcw; }
         const int64_t m_big = big32;
         const size_t half = (((size_t)n / 2 + 1) & ~(size_t)1);
         if ((size_t)m_big <= half) {
@@ -441,8 +463,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         PROF(KC_BYTE_HIST, n, st, hipLaunchKernelGGL((k_byte_hist), dim3((unsigned)blocks), dim3(BH_THREADS), 0, st, dT, n, w.hist));
     }
     uint32_t hist[256];
-    HIP_TRY(hipMemcpyAsync(hist, w.hist, sizeof(hist), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    { const int rcw = read_words(hist, w.hist, sizeof(hist), st); if (rcw) return rcw; }
     KeyParams P;
     int sigma;
     const int key_bits = make_key_params(hist, &P, &sigma);
@@ -470,8 +491,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(64), dim3(256), 0, st,
                                                     (const uint64_t *)ss.keys, S, w.total));
             uint32_t dups = 0;
-            HIP_TRY(hipMemcpyAsync(&dups, w.total, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
             // adjacent duplicates of a sorted sample under-count pairs only when runs are long, which is the
             // "do not" case anyway; expected number of other suffixes sharing the top bits with a given one:
             const double q = 2.0 * (double)dups / ((double)S * (double)S);
@@ -524,8 +544,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                     (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0));
     PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
     uint32_t m32 = 0;
-    HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
     int64_t m = m32;
     local.unresolved_after_initial = m;
     if (getenv("SA_AMD_TIMING_ONLY_INITIAL_SORT")) m = 0;   // ablation builds produce wrong orders; stop here
@@ -554,8 +573,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                     (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, rf.vnext, (uint32_t)n,
                                                     (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
                                                     (const uint32_t *)w.total, 0));
-        HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
         m = m32;
         uint32_t *t;
         t = Ucur; Ucur = Unext; Unext = t;
@@ -635,8 +653,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                         (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, Vnext,
                                                         (uint32_t)n, (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
                                                         (const uint32_t *)w.total, 0));
-            HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
             m = m32;
             uint32_t *t;
             t = Ucur; Ucur = Unext; Unext = t;
@@ -704,8 +721,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                         (uint32_t)n, (uint32_t *)nullptr, key2_bits, (uint64_t *)nullptr,
                                                         (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
         }
-        HIP_TRY(hipMemcpyAsync(&m32, w.total, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
         m = m32;
         uint32_t *t;
         t = Ucur; Ucur = Unext; Unext = t;

@@ -541,7 +541,7 @@ __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ keys_in, 
 template <int THREADS, int ITEMS, int MINW, int ABLATE = 0>
 __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
+    uint32_t *__restrict__ vals_out, uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
     int64_t n, int shift, uint32_t dmask, int64_t tiles_per_wg, int G)
 {
     constexpr int TILE = THREADS * ITEMS;
@@ -556,7 +556,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep(
         uint32_t all;
         const uint32_t t = threadIdx.x < RADIX ? digit_tot[threadIdx.x] : 0u;
         const uint32_t gbase = block_excl_sum<THREADS>(t, scan_lds, &all);
-        if (threadIdx.x < RADIX) run_off[threadIdx.x] = gbase + spine[(int64_t)threadIdx.x * G + blockIdx.x];
+        if (threadIdx.x < RADIX) {
+            run_off[threadIdx.x] = gbase + spine[(int64_t)threadIdx.x * G + blockIdx.x];
+            spine[(int64_t)threadIdx.x * G + blockIdx.x] = 0;      // consumed: the next pass's upsweep accumulates from zero again
+        }
     }
     __syncthreads();
     const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
@@ -593,7 +596,7 @@ __device__ unsigned long long g_phase_cycles[16];
 template <int THREADS, int ITEMS, int GR = 16, int MINW = 1, bool STAMP = false, typename KeyT = uint64_t, int PF = 0>
 __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
     const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KeyT *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
+    uint32_t *__restrict__ vals_out, uint32_t *__restrict__ spine, const uint32_t *__restrict__ digit_tot,
     int64_t n, int shift, uint32_t dmask, int64_t tiles_per_wg, int G)
 {
     constexpr int TILE = THREADS * ITEMS;
@@ -625,7 +628,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
         uint32_t all;
         const uint32_t t = tid < RADIX ? digit_tot[tid] : 0u;
         const uint32_t gbase = block_excl_sum<THREADS>(t, scan_lds, &all);
-        if (tid < RADIX) c0 = w0 = gbase + spine[(int64_t)tid * G + blockIdx.x];
+        if (tid < RADIX) {
+            c0 = w0 = gbase + spine[(int64_t)tid * G + blockIdx.x];
+            spine[(int64_t)tid * G + blockIdx.x] = 0;      // consumed: the next pass's upsweep accumulates from zero again
+        }
     }
     uint16_t *my_hist = wave_hist[w];
     uint32_t *lds_v = (uint32_t *)lds_kv;
