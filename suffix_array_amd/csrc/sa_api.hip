@@ -112,12 +112,9 @@ static const SortVariant sort_variants[] = {
 constexpr int SORT_DEFAULT_VARIANT = 0;
 static const SortVariant &sort_variant()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SA_AMD_SORT_VARIANT");
-        v = e ? atoi(e) : SORT_DEFAULT_VARIANT;
-        if (v < 0 || v >= (int)(sizeof(sort_variants) / sizeof(sort_variants[0]))) v = SORT_DEFAULT_VARIANT;
-    }
+    const char *e = getenv("SA_AMD_SORT_VARIANT");          // read per sort: the tests switch it inside one process
+    int v = e ? atoi(e) : SORT_DEFAULT_VARIANT;
+    if (v < 0 || v >= (int)(sizeof(sort_variants) / sizeof(sort_variants[0]))) v = SORT_DEFAULT_VARIANT;
     return sort_variants[v];
 }
 

@@ -294,6 +294,41 @@ def test_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed):
     assert sa.last_stats()["top32_first"] == 0
 
 
+@pytest.mark.parametrize("gen,n,seed", [("english", 700_000, 11), ("dna", 1 << 20, 12), ("sigma3", 300_000, 13),
+                                        ("dna_repeats", 500_000, 14)])
+@pytest.mark.parametrize("cap", ["2", "5", "64", "1024"])
+def test_group_sort_caps(oracle, monkeypatch, gen, n, seed, cap):
+    """fused gather + in-LDS group sort (k_group_sort): with a tiny cap most groups are 'big' and go through
+    the flag / global-sort / scatter-back path, groups cut by a 2048-element tile boundary go through
+    k_group_sort_straddle; with the largest cap nearly everything is ordered in LDS"""
+    text = corpus.sigma(n, seed, 3, 97) if gen == "sigma3" else getattr(corpus, gen)(n, seed)
+    exp = oracle.sais(text)
+    monkeypatch.setenv("SA_AMD_GROUP_CAP", cap)
+    for top32 in ("SA_AMD_FORCE_TOP32", "SA_AMD_NO_TOP32"):
+        monkeypatch.delenv("SA_AMD_FORCE_TOP32", raising=False)
+        monkeypatch.delenv("SA_AMD_NO_TOP32", raising=False)
+        monkeypatch.setenv(top32, "1")
+        assert np.array_equal(build(text), exp)
+        st = sa.last_stats()
+        if st["unresolved_after_initial"] > 0 and cap == "1024":
+            assert st["locally_sorted"] > 0
+
+
+@pytest.mark.parametrize("v64,v32", [("1", "1"), ("2", "2"), ("8", "3"), ("9", "4")])
+def test_sort_kernel_variants(oracle, monkeypatch, v64, v32):
+    """the non-default tile-scatter kernels (no prefetch, first-generation scatter, other shapes) give the same arrays"""
+    monkeypatch.setenv("SA_AMD_SORT_VARIANT", v64)
+    monkeypatch.setenv("SA_AMD_SORT32_VARIANT", v32)
+    for gen, n, seed in (("english", 400_000, 21), ("uniform", 300_000, 22)):
+        text = getattr(corpus, gen)(n, seed)
+        exp = oracle.sais(text)
+        for top32 in ("SA_AMD_FORCE_TOP32", "SA_AMD_NO_TOP32"):
+            monkeypatch.delenv("SA_AMD_FORCE_TOP32", raising=False)
+            monkeypatch.delenv("SA_AMD_NO_TOP32", raising=False)
+            monkeypatch.setenv(top32, "1")
+            assert np.array_equal(build(text), exp)
+
+
 def test_randomised_inputs_and_regimes(oracle, monkeypatch):
     """short form of tools/stress.py: random sizes, alphabets and structures with the regime switches
     toggled at random; every array equals the oracle's"""

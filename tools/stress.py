@@ -36,13 +36,15 @@ while time.time() - t0 < budget:
     else:
         s = corpus.dna_repeats(n, int(rng.integers(0, 1 << 30)), 0.4) if n > 5000 else rng.integers(65, 69, n, dtype=np.uint8)
     s = np.ascontiguousarray(s, dtype=np.uint8)
-    for k in ENV + ["SA_AMD_SPARSE_DIV"]:
+    for k in ENV + ["SA_AMD_SPARSE_DIV", "SA_AMD_GROUP_CAP"]:
         os.environ.pop(k, None)
     chosen = [k for k in ENV if rng.random() < 0.2]
     for k in chosen:
         os.environ[k] = "1"
     if rng.random() < 0.3:
         os.environ["SA_AMD_SPARSE_DIV"] = str(int(rng.choice([1, 4, 64, 10**9]))); chosen.append("DIV=" + os.environ["SA_AMD_SPARSE_DIV"])
+    if rng.random() < 0.3:
+        os.environ["SA_AMD_GROUP_CAP"] = str(int(rng.choice([2, 3, 7, 40, 300]))); chosen.append("CAP=" + os.environ["SA_AMD_GROUP_CAP"])
     try:
         got = sa.SuffixArray(s).into_parts()[1]
         ok = np.array_equal(got, orc.sais(s))
