@@ -533,6 +533,44 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     uint32_t *Ucur = w.U0, *Unext = w.U1, *Gcur = w.G0, *Gnext = w.G1;
     uint32_t *Vcur = w.valsA;
     int64_t tiles = ceil_div(n, RR_TILE);
+    uint32_t m32 = 0;
+    int64_t m = 0;
+    uint64_t *rkA = w.keysA, *rkB = w.keysB;          // key buffers of the refinement rounds
+    uint64_t *sorted0 = sr.keys;                      // the initial keys in SA order (kept for the rank look-ups)
+    bool lists_ready = false;                         // (Ucur, Gcur, Vcur) already hold the tied suffixes
+    bool finished32 = false;
+    if (top_shift && local_ok && !getenv("SA_AMD_NO_FUSED_FINISH") && !getenv("SA_AMD_TIMING_ONLY_INITIAL_SORT")) {
+        // fast finish of the 32-bit first stage: one pass orders every small group by its low key bits in place
+        // (k_finish_top32); only if some group is too large for it does the general path below run instead
+        int cap = GS_CAP;
+        if (const char *e = getenv("SA_AMD_GROUP_CAP")) { cap = atoi(e); if (cap < 2) cap = 2; if (cap > GS_CAP) cap = GS_CAP; }
+        uint32_t *surv_bits = Unext, *surv_head = Gnext;      // free until the first refinement round writes its lists
+        HIP_TRY(hipMemsetAsync(surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
+        HIP_TRY(hipMemsetAsync(w.tcnt, 0, (size_t)tiles * 4, st));
+        HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
+        HIP_TRY(hipMemsetAsync(w.total, 0, 16, st));
+        KeySrc K; K.mode = KS_LOWKEY; K.h = 0; K.s = 0; K.kb = top_shift;
+        PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_top32), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS), 0, st, sorted32, SA, dT, P,
+                                                 n, K, cap, surv_bits, surv_head, w.tcnt, w.total));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+        uint32_t cnt3[3] = { 0, 0, 0 };                       // still tied on 64 bits, members of groups nobody owned, tied on 32 bits
+        { const int rcw = read_words(cnt3, w.total, 12, st); if (rcw) return rcw; }
+        if (cnt3[1] == 0) {
+            finished32 = true;
+            m = cnt3[0];
+            local.locally_sorted += cnt3[2];
+            local.unresolved_after_initial = m;
+            if (m > 0) {
+                PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_surv_compact), dim3((unsigned)tiles), dim3(256), 0, st, (const uint32_t *)surv_bits,
+                                                            (const uint32_t *)surv_head, (const uint32_t *)SA, n, (const uint32_t *)w.tcnt,
+                                                            (const uint32_t *)w.total, Ucur, Gcur, Vcur));
+                rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+                rkB = w.keysC;
+                lists_ready = true;
+            }
+        }
+    }
+    if (!finished32) {
     if (top_shift)
         PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sorted32,
                                                     (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0));
@@ -540,15 +578,12 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)sr.keys,
                                                     (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0));
     PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-    uint32_t m32 = 0;
     { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
-    int64_t m = m32;
+    m = m32;
     local.unresolved_after_initial = m;
     if (getenv("SA_AMD_TIMING_ONLY_INITIAL_SORT")) m = 0;   // ablation builds produce wrong orders; stop here
-    uint64_t *rkA = w.keysA, *rkB = w.keysB;          // key buffers of the refinement rounds
-    uint64_t *sorted0 = sr.keys;                      // the initial keys in SA order (kept for the rank look-ups)
-    bool lists_ready = false;                         // (Ucur, Gcur, Vcur) already hold the tied suffixes
-    if (top_shift && m > 0) {
+    }
+    if (!finished32 && top_shift && m > 0) {
         // finish the initial sort: the suffixes tied on the top 32 bits are ordered by their low key bits
         rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
         rkB = w.keysC;

@@ -1308,6 +1308,215 @@ __global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_finish_top32: the round that finishes a top-32-bit initial sort, in ONE pass over the sorted
+// keys and SA -- no tied-suffix lists, no re-rank kernels.  The probe only allows the 32-bit first
+// stage when the suffixes tied on the top 32 bits are few and sit in tiny groups, so: a workgroup
+// takes 2048 slots (+ 256 of overhang), finds the groups (runs of equal 32-bit keys) from a bitmap of
+// run starts in LDS, and for every group that STARTS in its 2048 slots, ends inside the overhang
+// and has <= cap members: gathers the members' low key bits from the text (KS_LOWKEY), ranks them in
+// LDS (as k_group_sort does) and writes the suffixes back to their SA slots in the new order.
+// Members that are still tied afterwards (equal 64-bit keys; rare) are recorded -- bit in surv_bits,
+// slot of their subgroup's first member in surv_head, count per re-rank tile -- and k_surv_compact
+// turns that into the (slot, group head, suffix) list the later rounds expect.  A group it cannot
+// own (too large / longer overhang) only bumps counters[1]; the host then runs the general path
+// (k_rr_* + refine_list) over everything: correct on any input, fast on the inputs the probe admits.
+// Algorithmic traffic per slot: 4 B key + (tied: 4 B SA read, text gather, 4 B SA write).
+// ------------------------------------------------------------------------------------------
+constexpr int FT_THREADS = 256;
+constexpr int FT_TILE = 2048;
+constexpr int FT_XITEMS = FT_TILE / FT_THREADS + 1;         // 8 items + 1 of overhang
+constexpr int FT_SPAN = FT_THREADS * FT_XITEMS;             // 2304
+constexpr int FT_WORDS = FT_SPAN / 64;                      // 36
+
+__global__ __launch_bounds__(FT_THREADS) void k_finish_top32(const uint32_t *__restrict__ keys32, uint32_t *SA, const uint8_t *__restrict__ T,
+                                                              KeyParams P, int64_t n, KeySrc K, int cap, uint32_t *__restrict__ surv_bits,
+                                                              uint32_t *__restrict__ surv_head, uint32_t *__restrict__ tile_cnt,
+                                                              uint32_t *__restrict__ counters)
+{
+    constexpr int NW = FT_THREADS / WAVE;
+    __shared__ uint32_t s_key[FT_SPAN];           // low key bits: key_bits - 32 <= 32 of them
+    __shared__ uint32_t s_val[FT_SPAN];
+    __shared__ uint16_t s_list[FT_SPAN];          // local indices of the slots that are in a group of more than one (work list)
+    __shared__ uint64_t s_head[FT_WORDS + 1];
+    __shared__ uint8_t lcode[256];
+    __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_woff[FT_XITEMS * NW + 1];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
+    const int64_t base = (int64_t)blockIdx.x * FT_TILE;
+    const int t = threadIdx.x, l = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());       // wave-uniform values stay in scalar registers
+    const int valid_cnt = (int)(n - base < FT_SPAN ? n - base : FT_SPAN);
+    const uint32_t prev = base > 0 ? keys32[base - 1] : 0u;
+    // ---- phase 1, every slot, cheap: run starts -> bitmap; slots in runs longer than one -> work list ----
+    uint32_t k32[FT_XITEMS];
+#pragma unroll
+    for (int r = 0; r < FT_XITEMS; ++r) {
+        const int jl = r * FT_THREADS + t;
+        k32[r] = jl < valid_cnt ? keys32[base + jl] : 0u;
+        s_val[jl] = k32[r];
+    }
+    if (t == 0) s_head[FT_WORDS] = 0;              // beyond the span: unknown, treated as "the run goes on"
+    __syncthreads();
+    uint64_t hb[FT_XITEMS];
+#pragma unroll
+    for (int r = 0; r < FT_XITEMS; ++r) {
+        const int jl = r * FT_THREADS + t;
+        const uint32_t left = jl ? s_val[jl - 1] : prev;
+        const bool head = jl >= valid_cnt || k32[r] != left || (jl == 0 && base == 0);   // past the end counts as a run start
+        hb[r] = __ballot(head);
+        if (l == 0) s_head[jl >> 6] = hb[r];
+    }
+    __syncthreads();
+    uint64_t tied[FT_XITEMS];                      // wave-uniform: lanes whose slot is in a run of more than one element
+#pragma unroll
+    for (int r = 0; r < FT_XITEMS; ++r) {
+        const int wi = r * NW + w;                 // this wave's word of the bitmap
+        const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)s_head[wi + 1] & 1u));
+        const uint64_t nxt = (hb[r] >> 1) | ((uint64_t)nb << 63);
+        const int rem = valid_cnt - wi * 64;
+        const uint64_t valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+        tied[r] = valid & ~(hb[r] & nxt);
+        if (l == 0) s_woff[wi] = (uint32_t)__popcll(tied[r]);
+    }
+    __syncthreads();
+    if (w == 0) {
+        // exclusive offsets of the 36 words: one wave scan
+        const uint32_t c = l < FT_XITEMS * NW ? s_woff[l] : 0u;
+        const uint32_t inc = wave_incl_sum(c);
+        if (l < FT_XITEMS * NW) s_woff[l] = inc - c;
+        if (l == WAVE - 1) s_woff[FT_XITEMS * NW] = inc;
+    }
+    __syncthreads();
+    const uint32_t q_total = s_woff[FT_XITEMS * NW];
+#pragma unroll
+    for (int r = 0; r < FT_XITEMS; ++r) {
+        const uint32_t lo = (uint32_t)tied[r], hi = (uint32_t)(tied[r] >> 32);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+        if ((tied[r] >> l) & 1ull) s_list[s_woff[r * NW + w] + below] = (uint16_t)(r * FT_THREADS + t);
+    }
+    __syncthreads();
+    // ---- phase 2, work-list entries only (uniform early exit: with 12-22 % of the slots tied, two or three per thread) ----
+    int jl_[FT_XITEMS], start[FT_XITEMS], end[FT_XITEMS];
+    uint32_t mine_mask = 0, n_unowned = 0, n_tied = 0;
+    const int wspan = cap / 64 + 2;
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        jl_[i] = 0; start[i] = -1; end[i] = -1;
+        const uint32_t q = (uint32_t)(i * FT_THREADS + t);
+        if ((uint32_t)(i * FT_THREADS) < q_total && q < q_total) {             // (first test: uniform, skips the unused rounds)
+        const int jl = s_list[q];
+        jl_[i] = jl;
+        {
+            int wi = jl >> 6;
+            uint64_t wb = s_head[wi] & ((jl & 63) == 63 ? ~0ull : ((2ull << (jl & 63)) - 1ull));
+            const int wlow = max(0, wi - wspan);
+            while (!wb && wi > wlow) wb = s_head[--wi];
+            if (wb) start[i] = wi * 64 + 63 - __builtin_clzll(wb);
+        }
+        {
+            int wi = jl >> 6;
+            uint64_t wb = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
+            const int whigh = min(FT_WORDS - 1, wi + wspan);
+            while (!wb && wi < whigh) wb = s_head[++wi];
+            if (wb) end[i] = wi * 64 + __builtin_ctzll(wb);
+        }
+        const bool in_main = start[i] >= 0 && start[i] < FT_TILE;              // the group is this workgroup's to handle
+        const bool mine = in_main && end[i] > 0 && end[i] - start[i] <= cap;
+        if (mine) mine_mask |= 1u << i;
+        if (jl < FT_TILE && (in_main || start[i] < 0)) ++n_tied;               // (statistics; counted by the slot's own workgroup)
+        if (in_main && !mine && jl < FT_TILE) ++n_unowned;                     // whoever holds a group's first slot owns or reports it
+        }
+    }
+    uint32_t v[FT_XITEMS], key[FT_XITEMS];
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        v[i] = 0; key[i] = 0;
+        if ((mine_mask >> i) & 1u) v[i] = SA[base + jl_[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        if ((mine_mask >> i) & 1u) {
+            key[i] = (uint32_t)text_key2<KS_LOWKEY>(T, lcode, P, n, K, v[i], aligned8);
+            s_key[jl_[i]] = key[i];
+        }
+    }
+    __syncthreads();
+    // ---- rank inside the group = place ----
+    int dest[FT_XITEMS];
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        dest[i] = 0;
+        if ((mine_mask >> i) & 1u) {
+            int rank = 0;
+            const uint32_t me = key[i];
+            const int jl = jl_[i];
+            for (int p = start[i]; p < end[i]; ++p) {
+                const uint32_t k = s_key[p];
+                rank += (k < me || (k == me && p < jl)) ? 1 : 0;
+            }
+            dest[i] = start[i] + rank;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        if ((mine_mask >> i) & 1u) { s_key[dest[i]] = key[i]; s_val[dest[i]] = v[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        if (!((mine_mask >> i) & 1u)) continue;
+        const int jl = jl_[i];                                                 // now: the POSITION this thread finishes
+        const int64_t j = base + jl;
+        SA[j] = s_val[jl];
+        const uint32_t kk = s_key[jl];
+        const bool tl = jl > start[i] && s_key[jl - 1] == kk, tr = jl + 1 < end[i] && s_key[jl + 1] == kk;
+        if (tl || tr) {                                                        // still tied on the whole 64-bit key
+            int p = jl;
+            while (p > start[i] && s_key[p - 1] == kk) --p;
+            surv_head[j] = (uint32_t)(base + p);
+            atomicOr(&surv_bits[j >> 5], 1u << (j & 31));
+            atomicAdd(&tile_cnt[j / RR_TILE], 1u);
+        }
+    }
+    if (n_unowned) atomicAdd(&s_cnt[0], n_unowned);
+    if (n_tied) atomicAdd(&s_cnt[1], n_tied);
+    __syncthreads();
+    if (t == 0) {
+        if (s_cnt[0]) atomicAdd(&counters[1], s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&counters[2], s_cnt[1]);
+    }
+}
+
+// survivors of k_finish_top32 -> (slot, group head, suffix) lists in slot order; tile_cnt holds the exclusive
+// offsets of the re-rank tiles (k_rr_scan), one workgroup per tile, one bitmap word per thread
+__global__ __launch_bounds__(256) void k_surv_compact(const uint32_t *__restrict__ surv_bits, const uint32_t *__restrict__ surv_head,
+                                                       const uint32_t *__restrict__ SA, int64_t n, const uint32_t *__restrict__ tile_cnt,
+                                                       const uint32_t *__restrict__ tile_total, uint32_t *__restrict__ Uo,
+                                                       uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo)
+{
+    static_assert(RR_TILE == 256 * 32, "one bitmap word per thread");
+    __shared__ uint32_t lds[256 / WAVE + 1];
+    const uint32_t here = tile_cnt[blockIdx.x];
+    const uint32_t next = (blockIdx.x + 1 < gridDim.x) ? tile_cnt[blockIdx.x + 1] : *tile_total;
+    if (next == here) return;
+    const int64_t widx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nwords = (n + 31) / 32;
+    uint32_t bits = widx < nwords ? surv_bits[widx] : 0u;
+    uint32_t tot;
+    uint32_t off = here + block_excl_sum<256>((uint32_t)__popc(bits), lds, &tot);
+    while (bits) {
+        const int b = __builtin_ctz(bits);
+        bits &= bits - 1;
+        const uint32_t slot = (uint32_t)(widx * 32 + b);
+        Uo[off] = slot; Go[off] = surv_head[slot]; Vo[off] = SA[slot];
+        ++off;
+    }
+}
+
 // ---- ordered compaction of the flagged elements (those the local pass could not own) ----
 __global__ __launch_bounds__(RR_THREADS) void k_flag_count(const uint8_t *__restrict__ flag, int64_t m, uint32_t *__restrict__ tile_cnt)
 {
