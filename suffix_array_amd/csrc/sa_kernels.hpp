@@ -1194,13 +1194,16 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         const int64_t j = base + r * GS_THREADS + t;
         key[r] = j < m ? text_key2<MODE>(T, lcode, P, n, K, v[r], aligned8) : 0ull;
     }
+    // keys of at most 53 bits are ranked as (key << 11 | tile position): unique, so one compare per member
+    static_assert(GS_TILE <= 2048, "11 bits of tile position");
+    const bool packed = K.kb <= 53;
 #pragma unroll
     for (int r = 0; r < GS_ITEMS; ++r) {
         const int jl = r * GS_THREADS + t;
         const bool head = (base + jl >= m) || u[r] == g[r];       // past the end counts as a group start
         const uint64_t hb = __ballot(head);
         if (lane_id() == 0) s_head[jl >> 6] = hb;
-        s_key[jl] = key[r];
+        s_key[jl] = packed ? ((key[r] << 11) | (uint64_t)jl) : key[r];
     }
     if (t == 0) {
         // does a group start exactly at the first element after the tile?
@@ -1226,7 +1229,10 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         }
         const bool owned = valid && start >= 0 && end >= 0 && end - start <= cap;
         int rank = 0;
-        if (owned) {
+        if (owned && packed) {
+            const uint64_t mine = (key[r] << 11) | (uint64_t)jl;
+            for (int i = start; i < end; ++i) rank += s_key[i] < mine ? 1 : 0;
+        } else if (owned) {
             const uint64_t mine = key[r];
             for (int i = start; i < end; ++i) {
                 const uint64_t k = s_key[i];
