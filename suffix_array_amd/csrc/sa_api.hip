@@ -294,10 +294,12 @@ static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out)
     *sigma_out = sigma;
     const uint64_t se = sigma > 2 ? (uint64_t)sigma : 2u;      // effective radix (a unary text still needs one bit)
     P->sigma = se;
+    int kb_max = 64;                                           // A/B: fewer key bits = fewer radix passes, more left to the rounds
+    if (const char *e = getenv("SA_AMD_KEY_BITS")) { kb_max = atoi(e); if (kb_max < 16) kb_max = 16; if (kb_max > 64) kb_max = 64; }
     if ((se & (se - 1)) == 0) {                                // power of two: plain bit fields
         const int bits = bit_length(se - 1);
         P->bits = bits;
-        P->k = 64 / bits;
+        P->k = kb_max / bits;
         const int used = P->k * bits;
         P->mask = used >= 64 ? ~0ull : ((1ull << used) - 1ull);
         P->top = 0;
@@ -306,7 +308,7 @@ static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out)
     // otherwise pack as a base-sigma number: the largest k with sigma^k <= 2^64
     unsigned __int128 pw = 1;
     int k = 0;
-    while (pw * se <= ((unsigned __int128)1 << 64)) { pw *= se; ++k; }
+    while (pw * se <= ((unsigned __int128)1 << kb_max)) { pw *= se; ++k; }
     P->bits = 0;
     P->k = k;
     P->mask = ~0ull;
@@ -317,7 +319,6 @@ static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out)
     return bit_length((uint64_t)maxkey);
 }
 
-// binned ISA update pays off once the ISA is far larger than the caches and there is enough to write
 // Small device -> host read-backs (counts that steer the host loop) go through a pinned per-thread buffer:
 // a 4-byte hipMemcpyAsync into pageable memory costs ~50-90 us per round trip, into pinned memory ~10.
 struct PinnedWords {
@@ -340,6 +341,7 @@ static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)
     return SA_AMD_OK;
 }
 
+// binned ISA update pays off once the ISA is far larger than the caches and there is enough to write
 static bool binned(int64_t n, int64_t count)
 {
     if (getenv("SA_AMD_NO_BINNED_ISA")) return false;
