@@ -1042,27 +1042,14 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
 }
 
 // ------------------------------------------------------------------------------------------
-// k_gather_key2: secondary key of prefix doubling.  For suffix v with offset h:
+// Secondary key of prefix doubling.  For suffix v with offset h:
 //   v + h <  n : n + ISA[v + h]     (rank of the suffix h symbols further on; ranks start at 1)
 //   v + h >= n : n - 1 - v          (text ended inside the compared prefix: the shorter suffix,
 //                                    i.e. the larger v, is smaller; all below every real rank)
-// key = (group head << key2_bits) | key2, so one sort by key refines every group at once.
-// Algorithmic traffic: 8 B read + 4 B random ISA read + 8 B written per element.
+// key = (group head << key2_bits) | key2, so one sort by key refines every group at once
+// (text_key2<KS_RANK> below; the sparse variant without an ISA is k_gather_key2_sparse).
 // ------------------------------------------------------------------------------------------
 constexpr int GK_THREADS = 256;
-__global__ __launch_bounds__(GK_THREADS) void k_gather_key2(const uint32_t *__restrict__ V,
-                                                             const uint32_t *__restrict__ G,
-                                                             const uint32_t *__restrict__ ISA, int64_t m, int64_t n,
-                                                             int64_t h, int key2_bits, uint64_t *__restrict__ keys)
-{
-    const int64_t stride = (int64_t)gridDim.x * GK_THREADS;
-    for (int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x; j < m; j += stride) {
-        const uint32_t v = V[j];
-        const int64_t p = (int64_t)v + h;
-        const uint64_t key2 = (p < n) ? (uint64_t)n + (uint64_t)ISA[p] : (uint64_t)(n - 1 - (int64_t)v);
-        keys[j] = ((uint64_t)G[j] << key2_bits) | key2;
-    }
-}
 
 // symbol code of text position pos (0 past the end: the same padding the initial keys use)
 __device__ __forceinline__ uint64_t code_at(const uint8_t *__restrict__ T, const uint8_t *lcode, int64_t n, int64_t pos)
@@ -1105,18 +1092,25 @@ __device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ T, cons
 // order after the round is by h + s symbols; depth grows additively, but no rank array exists yet.
 // The round that finishes a top-32-bit initial sort is the same thing with the low `kb` bits of the
 // suffix's own 64-bit key as the secondary key (KS_LOWKEY).
-enum { KS_TEXT = 0, KS_LOWKEY = 1 };
+// KS_RANK is the secondary key of a prefix-doubling round with a full ISA (step 7, dense): the rank of the suffix h
+// symbols further on, n + ISA[v + h], or n - 1 - v when the text ends inside the compared prefix.
+enum { KS_TEXT = 0, KS_LOWKEY = 1, KS_RANK = 2 };
 struct KeySrc {
-    int mode;          // KS_TEXT / KS_LOWKEY
-    int64_t h;         // KS_TEXT: symbols already sorted (offset of the first symbol of the secondary key)
+    int mode;          // KS_TEXT / KS_LOWKEY / KS_RANK
+    int64_t h;         // KS_TEXT, KS_RANK: symbols already sorted (offset of the secondary key)
     int s;             // KS_TEXT: symbols per secondary key
     int kb;            // bits of the secondary key
+    const uint32_t *isa;   // KS_RANK
 };
 
 template <int MODE>
 __device__ __forceinline__ uint64_t text_key2(const uint8_t *__restrict__ T, const uint8_t *lcode, const KeyParams &P, int64_t n,
                                               const KeySrc &K, uint32_t v, bool aligned8)
 {
+    if (MODE == KS_RANK) {
+        const int64_t p = (int64_t)v + K.h;
+        return p < n ? (uint64_t)n + (uint64_t)K.isa[p] : (uint64_t)(n - 1 - (int64_t)v);
+    }
     if (MODE == KS_TEXT) return text_key(T, lcode, P, n, (int64_t)v + K.h, K.s, aligned8);
     if (P.bits > 0 && K.kb % P.bits == 0) {
         // bit-field keys: the low bits ARE the last kb / bits symbols of the key
