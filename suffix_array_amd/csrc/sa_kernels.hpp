@@ -3,13 +3,20 @@
 // none is GEMM-shaped, so there is no MFMA anywhere.
 //
 // Pipeline, replacing the arithmetic behind reference src/saca.rs:14:
-//   k_byte_hist      sigma=256 histogram of the text, per-wave counters in LDS
-//   k_build_keys     packed-symbol 64-bit key of every suffix, text tile staged in LDS
-//   radix sort       stable LSD, 8-bit digits: k_radix_upsweep / k_radix_spine / k_radix_downsweep
+//   k_byte_hist        which byte values occur -> symbol codes, key geometry
+//   k_sample_keys / k_count_sample_dups
+//                      entropy probe: may the initial sort run on the top 32 key bits only?
+//   k_build_keys       packed-symbol key of every suffix (64-bit, or its top 32 bits), text tile staged in LDS
+//   radix sort         stable LSD, 8-bit digits: k_radix_upsweep(32) / k_spine_rows / k_radix_downsweep_wcl<u64 | u32>
+//   k_finish_top32 / k_surv_compact
+//                      32-bit first stage: small groups ordered by their low key bits in place, one pass
 //   k_rr_count / k_rr_scan / k_rr_apply
-//                    group heads -> ranks (ISA scatter), SA write-back, compaction of the
-//                    suffixes still tied with a neighbour
-//   k_gather_key2    prefix-doubling secondary key ISA[i+h] with the end-of-text rule
+//                      group heads -> ranks, SA write-back, compaction of the suffixes still tied with a neighbour
+//   k_group_sort (+ _straddle), k_flag_count / k_flag_gather / k_scatter_back
+//                      one refinement round: gather of the secondary key (text symbols, low key bits or ranks) fused
+//                      with an in-LDS sort of the small groups; large groups through the global radix sort
+//   k_gather_key2_sparse, k_isa_from_sa / k_isa_tied / k_scatter_pairs
+//                      prefix doubling: rank look-up without an ISA (few ties) or ISA maintenance (many)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
