@@ -139,6 +139,7 @@ struct Workspace {
     uint64_t *keysA, *keysB, *keysC;
     uint32_t *valsA, *valsB, *isa, *U0, *U1, *G0, *G1;
     uint32_t *spine, *digit_tot, *tcnt, *thead, *hist, *total, *has_isa;
+    uint8_t *packed;           // bit-packed text (alphabets of 2, 4 or 16 symbols): n / 2 + 64 bytes
     size_t bytes;
 };
 
@@ -166,6 +167,7 @@ static Workspace carve(void *base, int64_t n)
     w.hist = (uint32_t *)take(256 * 4);
     w.total = (uint32_t *)take(256);
     w.has_isa = (uint32_t *)take((N + 31) / 32 * 4);
+    w.packed = (uint8_t *)take(N / 2 + 64);
     w.bytes = off;
     return w;
 }
@@ -292,6 +294,7 @@ static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out)
         else P->code[c] = 0;
     }
     *sigma_out = sigma;
+    P->packed = nullptr;
     const uint64_t se = sigma > 2 ? (uint64_t)sigma : 2u;      // effective radix (a unary text still needs one bit)
     P->sigma = se;
     int kb_max = 64;                                           // A/B: fewer key bits = fewer radix passes, more left to the rounds
@@ -515,10 +518,17 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     // value of pair i = i: not stored by k_build_keys, the first sort pass takes the index (saves 8 B / suffix)
     const bool iota = n >= 2 && key_bits > 0;
     uint32_t *vals0 = iota ? (uint32_t *)nullptr : w.valsA;
+    // alphabets of 2, 4 or 16 symbols: k_build_keys also writes the text as bit-packed codes, which every later random
+    // read of the text uses instead (a key becomes a bit field of two words; DNA shrinks to a quarter: cache-resident)
+    uint8_t *packed_out = nullptr;
+    if ((P.bits == 1 || P.bits == 2 || P.bits == 4) && n >= 64 && !getenv("SA_AMD_NO_PACKED_TEXT")) {
+        packed_out = w.packed;
+        HIP_TRY(hipMemsetAsync(packed_out + (size_t)(n >> 3) * P.bits, 0, 64, st));     // the padding behind the last whole group
+    }
     if (top_shift) {
         uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
         PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P,
-                                                      (uint64_t *)nullptr, vals0, k32a, top_shift));
+                                                      (uint64_t *)nullptr, vals0, k32a, top_shift, packed_out));
         SortResult32 s32;
         rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.spine, w.digit_tot, SA, st, &s32, iota);
         if (rc) return rc;
@@ -528,11 +538,12 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         sr.keys = (s32.keys == k32a) ? w.keysA : w.keysB;      // the 8n-byte buffer that now holds the sorted 32-bit keys
     } else {
         PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P,
-                                                      w.keysA, vals0, (uint32_t *)nullptr, 0));
+                                                      w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out));
         rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr, iota);
         if (rc) return rc;
         local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
     }
+    P.packed = packed_out;
     if (sr.vals != SA) {   // n == 1: no pass ran, the values are still in the input buffer
         PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_copy_u32), dim3(1), dim3(256), 0, st, sr.vals, SA, n));
     }
@@ -1338,7 +1349,7 @@ SA_EXPORT int32_t sa_amd_test_build_keys(const uint8_t *T, int32_t n, uint64_t *
     KeyParams P; int sigma;
     make_key_params(hist, &P, &sigma);
     hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div((int64_t)n, KB_TILE)), dim3(KB_THREADS), 0, nullptr, dT,
-                       (int64_t)n, P, dk, dv, (uint32_t *)nullptr, 0);
+                       (int64_t)n, P, dk, dv, (uint32_t *)nullptr, 0, (uint8_t *)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(keys, dk, (size_t)n * 8, hipMemcpyDeviceToHost));

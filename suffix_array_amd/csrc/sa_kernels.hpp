@@ -195,6 +195,9 @@ struct KeyParams {
     uint64_t mask;     // shift path: the k * bits low bits
     uint64_t sigma;    // multiply path (bits == 0): key = sum code_i * sigma^(k-1-i), an order-preserving
     uint64_t top;      //   base-sigma number; top = sigma^(k-1).  sigma = 56 packs 11 symbols, not 10.
+    const uint8_t *packed;   // bits in {1, 2, 4}: the text as bit-packed codes, first symbol in the top bits of byte 0
+                             // (written by k_build_keys; 4x smaller than DNA bytes, so the rounds' random reads stay in
+                             // the 256 MB Infinity Cache), zero-padded by >= 24 bytes; nullptr: read the text itself
 };
 
 // TOP32: only the top 32 bits of every key are stored (keys32), for the two-stage initial sort
@@ -202,7 +205,7 @@ template <bool TOP32>
 __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__restrict__ T, int64_t n,
                                                             KeyParams P, uint64_t *__restrict__ keys,
                                                             uint32_t *__restrict__ vals, uint32_t *__restrict__ keys32,
-                                                            int top_shift)
+                                                            int top_shift, uint8_t *__restrict__ packed_out)
 {
     __shared__ uint8_t lcode[256];
     __shared__ __attribute__((aligned(16))) uint8_t c[KB_TILE + KB_HALO];
@@ -254,6 +257,14 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
         }
     }
     const int64_t g0 = base + p0;
+    if (packed_out && g0 < n) {
+        // this thread's 8 codes -> `bits` bytes of the packed text (codes past the end are 0)
+        uint32_t val = 0;
+#pragma unroll
+        for (int r = 0; r < KB_ITEMS; ++r) val = (val << bits) | (uint32_t)c[p0 + r];
+        uint8_t *po = packed_out + (g0 >> 3) * bits;
+        for (int b = 0; b < bits; ++b) po[b] = (uint8_t)(val >> (8 * (bits - 1 - b)));
+    }
     if (g0 + KB_ITEMS <= n) {
         if (TOP32) {
             uint4 *ko = (uint4 *)(keys32 + g0);
@@ -1070,6 +1081,17 @@ __device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ T, cons
                                              int64_t p, int nsym, bool aligned8)
 {
     uint64_t tk = 0;
+    if (P.packed) {
+        // bit-packed codes: the key is a bit field of the packed text (two aligned big-endian 64-bit words)
+        const int64_t bo = p * P.bits;
+        const int nb = nsym * P.bits;                                    // <= 64
+        if (nb == 0 || p >= n) return 0;
+        const uint64_t *W = (const uint64_t *)P.packed + (bo >> 6);
+        const uint64_t w0 = __builtin_bswap64(W[0]), w1 = __builtin_bswap64(W[1]);
+        const int sh = (int)(bo & 63);
+        const uint64_t val = sh ? ((w0 << sh) | (w1 >> (64 - sh))) : w0;
+        return val >> (64 - nb);
+    }
     if (aligned8 && p + nsym + 16 <= n) {
         const uint64_t *W = (const uint64_t *)(T + (p & ~(int64_t)7));
         const int sh = (int)(p & 7) * 8;
