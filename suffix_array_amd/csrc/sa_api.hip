@@ -140,6 +140,7 @@ struct Workspace {
     uint32_t *valsA, *valsB, *isa, *U0, *U1, *G0, *G1;
     uint32_t *spine, *digit_tot, *tcnt, *thead, *hist, *total, *has_isa;
     uint8_t *packed;           // bit-packed text (alphabets of 2, 4 or 16 symbols): n / 2 + 64 bytes
+    uint32_t *surv_bits, *surv_cnt, *todo_bits, *ft_cnt, *ft_head;   // first refinement round straight from the sorted keys (k_finish_sorted)
     size_t bytes;
 };
 
@@ -168,6 +169,12 @@ static Workspace carve(void *base, int64_t n)
     w.total = (uint32_t *)take(256);
     w.has_isa = (uint32_t *)take((N + 31) / 32 * 4);
     w.packed = (uint8_t *)take(N / 2 + 64);
+    w.surv_bits = (uint32_t *)take((N + 31) / 32 * 4);
+    w.surv_cnt = (uint32_t *)take(rr_tiles * 4);          // (not tcnt: refine_list uses that one for its own compaction)
+    w.todo_bits = (uint32_t *)take((N + 31) / 32 * 4);
+    const size_t ft_tiles = (size_t)ceil_div((int64_t)N, FT_TILE) + 1;
+    w.ft_cnt = (uint32_t *)take(ft_tiles * 4);
+    w.ft_head = (uint32_t *)take(ft_tiles * 4);
     w.bytes = off;
     return w;
 }
@@ -557,20 +564,33 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     uint64_t *rkA = w.keysA, *rkB = w.keysB;          // key buffers of the refinement rounds
     uint64_t *sorted0 = sr.keys;                      // the initial keys in SA order (kept for the rank look-ups)
     bool lists_ready = false;                         // (Ucur, Gcur, Vcur) already hold the tied suffixes
-    bool finished32 = false;
+    int64_t depth = P.k;                               // symbols the current order is sorted by
+    int s_sym = 0, tkb = 0;                            // text-keyed rounds: symbols per round, bits of their packed key
+    {
+        const int room = 64 - g_bits;                   // bits left below the group head
+        if (P.bits > 0) { s_sym = room / P.bits; tkb = s_sym * P.bits; }
+        else {
+            unsigned __int128 pw = 1;
+            while (pw * P.sigma <= ((unsigned __int128)1 << room)) { pw *= P.sigma; ++s_sym; }
+            tkb = bit_length((uint64_t)(pw - 1));
+        }
+        if (s_sym > 64) s_sym = 64;
+    }
+    bool finished32 = false, fused64 = false;
     if (top_shift && local_ok && !getenv("SA_AMD_NO_FUSED_FINISH") && !getenv("SA_AMD_TIMING_ONLY_INITIAL_SORT")) {
         // fast finish of the 32-bit first stage: one pass orders every small group by its low key bits in place
-        // (k_finish_top32); only if some group is too large for it does the general path below run instead
+        // (k_finish_sorted); only if some group is too large for it does the general path below run instead
         int cap = GS_CAP;
         if (const char *e = getenv("SA_AMD_GROUP_CAP")) { cap = atoi(e); if (cap < 2) cap = 2; if (cap > GS_CAP) cap = GS_CAP; }
-        uint32_t *surv_bits = Unext, *surv_head = Gnext;      // free until the first refinement round writes its lists
+        uint32_t *surv_bits = w.surv_bits, *surv_head = w.isa;  // (the ISA is not in use before the doubling rounds)
         HIP_TRY(hipMemsetAsync(surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
         HIP_TRY(hipMemsetAsync(w.tcnt, 0, (size_t)tiles * 4, st));
         HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
         HIP_TRY(hipMemsetAsync(w.total, 0, 16, st));
         KeySrc K; K.mode = KS_LOWKEY; K.h = 0; K.s = 0; K.kb = top_shift; K.isa = nullptr;
-        PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_top32), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS), 0, st, sorted32, SA, dT, P,
-                                                 n, K, cap, surv_bits, surv_head, w.tcnt, w.total));
+        PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint32_t, KS_LOWKEY, false>), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS),
+                                                 0, st, sorted32, SA, dT, P, n, K, cap, surv_bits, surv_head, w.tcnt, w.total, (uint32_t *)nullptr,
+                                                 (uint32_t *)nullptr, (uint32_t *)nullptr));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
         uint32_t cnt3[3] = { 0, 0, 0 };                       // still tied on 64 bits, members of groups nobody owned, tied on 32 bits
         { const int rcw = read_words(cnt3, w.total, 12, st); if (rcw) return rcw; }
@@ -589,7 +609,73 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             }
         }
     }
-    if (!finished32) {
+    // (SA_AMD_SPARSE_DIV moves the text-round / doubling boundary for the tests: then the general route decides, as before)
+    // Opt-in (SA_AMD_FUSED64=1): measured on C3 the one-pass round costs 8.2 ms against the 4.3 ms of k_group_sort on the tied
+    // list -- with 68 % of the slots tied the work list is six entries per thread -- and the whole build 31.0 instead of 28.8 ms.
+    if (!top_shift && text_ok && local_ok && s_sym > 0 && getenv("SA_AMD_FUSED64") && !getenv("SA_AMD_NO_FUSED_FINISH") &&
+        !getenv("SA_AMD_SPARSE_DIV") &&
+        !getenv("SA_AMD_TIMING_ONLY_INITIAL_SORT")) {
+        // the first text-keyed round straight from the sorted keys (k_finish_sorted): groups of up to `cap` members are
+        // ordered in place by the next s_sym symbols, their still-tied members recorded by slot; the members of larger
+        // groups are listed (k_todo_compact) and take the general route (refine_list + re-rank), joining the same record;
+        // k_surv_compact then lists everything that is still tied, in slot order, for the second round
+        int cap = GS_CAP;
+        if (const char *e = getenv("SA_AMD_GROUP_CAP")) { cap = atoi(e); if (cap < 2) cap = 2; if (cap > GS_CAP) cap = GS_CAP; }
+        const int64_t ft_tiles = ceil_div(n, FT_TILE);
+        uint32_t *surv_head = w.isa;
+        HIP_TRY(hipMemsetAsync(w.surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
+        HIP_TRY(hipMemsetAsync(w.todo_bits, 0, ((size_t)n + 31) / 32 * 4, st));
+        HIP_TRY(hipMemsetAsync(w.ft_cnt, 0, (size_t)(ft_tiles + 1) * 4, st));
+        HIP_TRY(hipMemsetAsync(w.ft_head, 0, (size_t)(ft_tiles + 1) * 4, st));
+        HIP_TRY(hipMemsetAsync(w.surv_cnt, 0, (size_t)tiles * 4, st));
+        HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
+        HIP_TRY(hipMemsetAsync(w.total, 0, 32, st));
+        KeySrc K; K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb; K.isa = nullptr;
+        PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint64_t, KS_TEXT, true>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
+                                                 (const uint64_t *)sorted0, SA, dT, P, n, K, cap, w.surv_bits, surv_head, w.surv_cnt, w.total,
+                                                 w.todo_bits, w.ft_cnt, w.ft_head));
+        PROF(KC_RR_SCAN, ft_tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, ft_tiles, w.total + 3));
+        uint32_t cnt4[4] = { 0, 0, 0, 0 };                    // [2] tied after the initial sort, [3] members left to the general route
+        { const int rcw = read_words(cnt4, w.total, 16, st); if (rcw) return rcw; }
+        local.unresolved_after_initial = cnt4[2];
+        const int64_t m_todo = cnt4[3];
+        local.locally_sorted += (int64_t)cnt4[2] - m_todo;
+        rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+        rkB = w.keysC;
+        if (m_todo > 0) {
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_todo_compact<uint64_t>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
+                                                        (const uint64_t *)sorted0, (const uint32_t *)SA, n, (const uint32_t *)w.todo_bits,
+                                                        (const uint32_t *)w.ft_cnt, (const uint32_t *)w.ft_head, (const uint32_t *)(w.total + 3),
+                                                        Ucur, Gcur, Vcur));
+            uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+            Refined rf;
+            bool big_local = true;                             // (large groups: the global sort does the work either way)
+            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m_todo, n, dT, P, K, g_bits, &big_local, w, st, &local, &rf);
+            if (rc) return rc;
+            const int64_t tt = ceil_div(m_todo, RR_TILE);
+            PROF(KC_RR_COUNT, m_todo, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st, rf.keys,
+                                                        (const uint32_t *)Ucur, m_todo, w.ft_cnt, w.ft_head, 0));
+            PROF(KC_RR_SCAN, tt, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, tt, w.total + 4));
+            PROF(KC_RR_APPLY, m_todo, st, hipLaunchKernelGGL((k_rr_apply<false, true, 4>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st,
+                                                        rf.keys, rf.vals, (const uint32_t *)Ucur, m_todo, (const uint32_t *)w.ft_cnt,
+                                                        (const uint32_t *)w.ft_head, SA, surv_head, Unext, Gnext, rf.vnext, (uint32_t)n,
+                                                        w.surv_bits, 0, (uint64_t *)nullptr, w.surv_cnt, (const uint32_t *)(w.total + 4), 0));
+        }
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.surv_cnt, w.thead, tiles, w.total));
+        { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+        m = m32;
+        Ucur = w.U0; Gcur = w.G0; Vcur = w.valsA; Unext = w.U1; Gnext = w.G1;
+        if (m > 0)
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_surv_compact), dim3((unsigned)tiles), dim3(256), 0, st, (const uint32_t *)w.surv_bits,
+                                                        (const uint32_t *)surv_head, (const uint32_t *)SA, n, (const uint32_t *)w.surv_cnt,
+                                                        (const uint32_t *)w.total, Ucur, Gcur, Vcur));
+        fused64 = true;
+        lists_ready = true;
+        depth += s_sym;
+        local.text_rounds++;
+        local.rounds++;
+    }
+    if (!finished32 && !fused64) {
     if (top_shift)
         PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sorted32,
                                                     (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0));
@@ -643,7 +729,6 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     if (const char *e = getenv("SA_AMD_SPARSE_DIV")) { sparse_div = atoll(e); if (sparse_div < 1) sparse_div = 1; }   // tests / A-B
     const int64_t sparse_limit = n / sparse_div;
     bool sparse = false;
-    int64_t depth = P.k;                               // symbols the current order is sorted by
     const bool dense_first = m > 0 && !lists_ready && (force_dense || (!text_ok && m > sparse_limit));
     if (m > 0 && dense_first) {
         // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
@@ -672,17 +757,6 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                         w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
         }
         // ---- text-keyed rounds ----
-        int s_sym = 0, tkb = 0;
-        {
-            const int room = 64 - g_bits;                   // bits left below the group head
-            if (P.bits > 0) { s_sym = room / P.bits; tkb = s_sym * P.bits; }
-            else {
-                unsigned __int128 pw = 1;
-                while (pw * P.sigma <= ((unsigned __int128)1 << room)) { pw *= P.sigma; ++s_sym; }
-                tkb = bit_length((uint64_t)(pw - 1));
-            }
-            if (s_sym > 64) s_sym = 64;
-        }
         bool progressing = true;     // a text round that resolves little (runs, long repeats) is the last one
 
         while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < MAX_TEXT_ROUNDS && progressing) {

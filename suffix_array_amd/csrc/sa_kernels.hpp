@@ -8,8 +8,8 @@
 //                      entropy probe: may the initial sort run on the top 32 key bits only?
 //   k_build_keys       packed-symbol key of every suffix (64-bit, or its top 32 bits), text tile staged in LDS
 //   radix sort         stable LSD, 8-bit digits: k_radix_upsweep(32) / k_spine_rows / k_radix_downsweep_wcl<u64 | u32>
-//   k_finish_top32 / k_surv_compact
-//                      32-bit first stage: small groups ordered by their low key bits in place, one pass
+//   k_finish_sorted / k_surv_compact / k_todo_compact
+//                      first refinement round straight from the sorted keys: small groups ordered in place, one pass
 //   k_rr_count / k_rr_scan / k_rr_apply
 //                      group heads -> ranks, SA write-back, compaction of the suffixes still tied with a neighbour
 //   k_group_sort (+ _straddle), k_flag_count / k_flag_gather / k_scatter_back
@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace sa {
 
@@ -983,7 +984,8 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict_
 }
 
 // ISA_MODE: 0 = scatter ISA[suffix] = rank directly, 1 = the same plus the has_isa bitmap (sparse
-// refinement), 3 = no rank output at all (text-keyed rounds), 2 = write (suffix, rank) pairs in slot order; the host bins them by suffix position
+// refinement), 3 = no rank output at all (text-keyed rounds), 4 = like 3, but the still-tied suffixes are recorded by slot
+// (ISA = group heads, has_isa = bitmap, pair_v = counts per tile) instead of being listed, 2 = write (suffix, rank) pairs in slot order; the host bins them by suffix position
 // with one radix pass and k_scatter_pairs then writes the ISA window by window (a random 4-byte
 // store costs a whole 64-byte memory transaction, a binned one is merged in the caches).
 template <bool FIRST, bool WRITE_SA, int ISA_MODE, typename KeyT = uint64_t>
@@ -1043,7 +1045,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
             if (ISA_MODE == 2) {
                 pair_k[i] = (uint64_t)v[r];
                 pair_v[i] = run;
-            } else if (ISA_MODE != 3 && v[r] < n_text) {
+            } else if (ISA_MODE != 3 && ISA_MODE != 4 && v[r] < n_text) {
                 // refinement rounds: the key's high part is the old group head, i.e. the rank already in ISA;
                 // the first subgroup of a split group keeps its rank and is not rewritten
                 const uint32_t oldrank = (FIRST || ISA_MODE != 0) ? 0u : (uint32_t)((uint64_t)keys[i] >> g_shift) + 1u;
@@ -1052,7 +1054,16 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
                     if (SPARSE) atomicOr(&has_isa[v[r] >> 5], 1u << (v[r] & 31u));   // this rank overrides the initial one
                 }
             }
-            if ((g.tied[r] >> l) & 1ull) { Uo[off] = slot[r]; Go[off] = run - 1u; Vo[off] = v[r]; }
+            if ((g.tied[r] >> l) & 1ull) {
+                if (ISA_MODE == 4) {
+                    // survivors join those of k_finish_sorted: bitmap + group head by slot (k_surv_compact lists them in slot order)
+                    ISA[slot[r]] = run - 1u;
+                    atomicOr(&has_isa[slot[r] >> 5], 1u << (slot[r] & 31u));
+                    atomicAdd(&pair_v[slot[r] / RR_TILE], 1u);
+                } else {
+                    Uo[off] = slot[r]; Go[off] = run - 1u; Vo[off] = v[r];
+                }
+            }
         }
         run_cnt += (uint32_t)__popcll(g.tied[r]);
         if (g.head[r]) run_head = (uint32_t)__shfl((int)slot[r], 63 - __builtin_clzll(g.head[r]), WAVE) + 1u;
@@ -1196,6 +1207,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
     __shared__ uint64_t s_key[GS_TILE];
     __shared__ uint32_t s_val[GS_TILE];
     __shared__ uint64_t s_head[GS_WORDS + 1];
+    __shared__ int s_nextH[GS_WORDS + 2];          // first group start in words >= w (-1: none): a group's end is one look-up
     __shared__ uint8_t lcode[256];
     lcode[threadIdx.x] = P.code[threadIdx.x];
     __syncthreads();
@@ -1234,6 +1246,19 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         s_head[GS_WORDS] = (jx >= m || U[jx] == G[jx]) ? 1ull : 0ull;
     }
     __syncthreads();
+    if (wave_id() == 0) {
+        const int l = lane_id();
+        const uint64_t hw = l <= GS_WORDS ? s_head[l] : 0ull;
+        int first = hw ? l * 64 + __builtin_ctzll(hw) : 0x7fffffff;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int bb = __shfl_down(first, o, WAVE);
+            if (l + o < WAVE) first = min(first, bb);
+        }
+        if (l <= GS_WORDS) s_nextH[l] = first == 0x7fffffff ? -1 : first;
+        if (l == 0) s_nextH[GS_WORDS + 1] = -1;
+    }
+    __syncthreads();
     int dest[GS_ITEMS];
     bool big[GS_ITEMS];
 #pragma unroll
@@ -1242,13 +1267,11 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         const bool valid = base + jl < m;
         const int start = jl - (int)(u[r] - g[r]);               // negative: the group starts before the tile
         // end of the group = next group start after jl (GS_TILE: the tile ends with the group)
-        int end = -1;
+        int end;
         {
-            int wi = jl >> 6;
-            uint64_t wbits = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
-            const int wlast = min(GS_WORDS, wi + cap / 64 + 1);
-            while (!wbits && wi < wlast) wbits = s_head[++wi];
-            if (wbits) end = wi * 64 + __builtin_ctzll(wbits);
+            const int wi = jl >> 6;
+            const uint64_t wbits = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
+            end = wbits ? wi * 64 + __builtin_ctzll(wbits) : s_nextH[wi + 1];
         }
         const bool owned = valid && start >= 0 && end >= 0 && end - start <= cap;
         int rank = 0;
@@ -1338,7 +1361,7 @@ __global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__
 }
 
 // ------------------------------------------------------------------------------------------
-// k_finish_top32: the round that finishes a top-32-bit initial sort, in ONE pass over the sorted
+// k_finish_sorted: the round that finishes a top-32-bit initial sort, in ONE pass over the sorted
 // keys and SA -- no tied-suffix lists, no re-rank kernels.  The probe only allows the 32-bit first
 // stage when the suffixes tied on the top 32 bits are few and sit in tiny groups, so: a workgroup
 // takes 2048 slots (+ 256 of overhang), finds the groups (runs of equal 32-bit keys) from a bitmap of
@@ -1358,34 +1381,47 @@ constexpr int FT_XITEMS = FT_TILE / FT_THREADS + 1;         // 8 items + 1 of ov
 constexpr int FT_SPAN = FT_THREADS * FT_XITEMS;             // 2304
 constexpr int FT_WORDS = FT_SPAN / 64;                      // 36
 
-__global__ __launch_bounds__(FT_THREADS) void k_finish_top32(const uint32_t *__restrict__ keys32, uint32_t *SA, const uint8_t *__restrict__ T,
-                                                              KeyParams P, int64_t n, KeySrc K, int cap, uint32_t *__restrict__ surv_bits,
-                                                              uint32_t *__restrict__ surv_head, uint32_t *__restrict__ tile_cnt,
-                                                              uint32_t *__restrict__ counters)
+// KeyT / MODE: uint32_t keys + KS_LOWKEY (finish of the 32-bit first stage) or uint64_t keys + KS_TEXT (the first
+// text-keyed round straight from the fully sorted keys).  TODO = false: a group nobody can own only bumps
+// counters[1] (the host then runs the general path over everything).  TODO = true: its members are flagged in
+// todo_bits (todo_cnt per 2048-slot tile, ft_head = last run start + 1 of every tile for the group-head carry);
+// k_todo_compact turns them into a tied list for the general path, whose survivors join surv_bits.
+template <typename KeyT, int MODE, bool TODO>
+__global__ __launch_bounds__(FT_THREADS) void k_finish_sorted(const KeyT *__restrict__ skeys, uint32_t *SA, const uint8_t *__restrict__ T,
+                                                               KeyParams P, int64_t n, KeySrc K, int cap, uint32_t *__restrict__ surv_bits,
+                                                               uint32_t *__restrict__ surv_head, uint32_t *__restrict__ tile_cnt,
+                                                               uint32_t *__restrict__ counters, uint32_t *__restrict__ todo_bits,
+                                                               uint32_t *__restrict__ todo_cnt, uint32_t *__restrict__ ft_head)
 {
+    typedef typename std::conditional<MODE == KS_LOWKEY, uint32_t, uint64_t>::type Key2T;   // low key bits: key_bits - 32 <= 32
+    static_assert(sizeof(KeyT) == 4 || sizeof(Key2T) == 8, "64-bit keys are staged in the 64-bit key buffer");
     constexpr int NW = FT_THREADS / WAVE;
-    __shared__ uint32_t s_key[FT_SPAN];           // low key bits: key_bits - 32 <= 32 of them
+    __shared__ Key2T s_key[FT_SPAN];
     __shared__ uint32_t s_val[FT_SPAN];
     __shared__ uint16_t s_list[FT_SPAN];          // local indices of the slots that are in a group of more than one (work list)
     __shared__ uint64_t s_head[FT_WORDS + 1];
     __shared__ uint8_t lcode[256];
     __shared__ uint32_t s_cnt[2];
     __shared__ uint32_t s_woff[FT_XITEMS * NW + 1];
+    __shared__ uint32_t s_surv[FT_SPAN / 32], s_todo[FT_SPAN / 32];   // this tile's survivor / todo bits, merged into the global bitmaps once
+    __shared__ int s_lastH[FT_WORDS], s_nextH[FT_WORDS + 1];   // last run start in words <= w / first one in words >= w (-1: none)
+    KeyT *s_nb = sizeof(KeyT) == 8 ? (KeyT *)(void *)s_key : (KeyT *)(void *)s_val;   // neighbour keys, before either is needed
     lcode[threadIdx.x] = P.code[threadIdx.x];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < FT_SPAN / 32) { s_surv[threadIdx.x] = 0; s_todo[threadIdx.x] = 0; }
     const bool aligned8 = (((uintptr_t)T) & 7) == 0;
     const int64_t base = (int64_t)blockIdx.x * FT_TILE;
     const int t = threadIdx.x, l = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(wave_id());       // wave-uniform values stay in scalar registers
     const int valid_cnt = (int)(n - base < FT_SPAN ? n - base : FT_SPAN);
-    const uint32_t prev = base > 0 ? keys32[base - 1] : 0u;
+    const KeyT prev = base > 0 ? skeys[base - 1] : (KeyT)0;
     // ---- phase 1, every slot, cheap: run starts -> bitmap; slots in runs longer than one -> work list ----
-    uint32_t k32[FT_XITEMS];
+    KeyT k32[FT_XITEMS];
 #pragma unroll
     for (int r = 0; r < FT_XITEMS; ++r) {
         const int jl = r * FT_THREADS + t;
-        k32[r] = jl < valid_cnt ? keys32[base + jl] : 0u;
-        s_val[jl] = k32[r];
+        k32[r] = jl < valid_cnt ? skeys[base + jl] : (KeyT)0;
+        s_nb[jl] = k32[r];
     }
     if (t == 0) s_head[FT_WORDS] = 0;              // beyond the span: unknown, treated as "the run goes on"
     __syncthreads();
@@ -1393,7 +1429,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_top32(const uint32_t *__r
 #pragma unroll
     for (int r = 0; r < FT_XITEMS; ++r) {
         const int jl = r * FT_THREADS + t;
-        const uint32_t left = jl ? s_val[jl - 1] : prev;
+        const KeyT left = jl ? s_nb[jl - 1] : prev;
         const bool head = jl >= valid_cnt || k32[r] != left || (jl == 0 && base == 0);   // past the end counts as a run start
         hb[r] = __ballot(head);
         if (l == 0) s_head[jl >> 6] = hb[r];
@@ -1417,6 +1453,31 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_top32(const uint32_t *__r
         const uint32_t inc = wave_incl_sum(c);
         if (l < FT_XITEMS * NW) s_woff[l] = inc - c;
         if (l == WAVE - 1) s_woff[FT_XITEMS * NW] = inc;
+    } else if (w == 1) {
+        // per word: the last run start at or before its end, the first one at or after its beginning (so that the
+        // extent of any group is two look-ups, however long the group)
+        const uint64_t hw = l < FT_WORDS ? s_head[l] : 0ull;
+        int last = hw ? l * 64 + 63 - __builtin_clzll(hw) : -1;
+        int first = hw ? l * 64 + __builtin_ctzll(hw) : 0x7fffffff;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int a = __shfl_up(last, o, WAVE), bb = __shfl_down(first, o, WAVE);
+            if (l >= o) last = max(last, a);
+            if (l + o < WAVE) first = min(first, bb);
+        }
+        if (l < FT_WORDS) { s_lastH[l] = last; s_nextH[l] = first == 0x7fffffff ? -1 : first; }
+        if (l == 0) s_nextH[FT_WORDS] = -1;
+    }
+    if (TODO && t == 0) {
+        // last real run start of this tile's own 2048 slots (+1; 0: none): the group-head carry of k_todo_compact
+        uint32_t lh = 0;
+        const int lim = valid_cnt < FT_TILE ? valid_cnt : FT_TILE;
+        for (int wi = (lim - 1) >> 6; wi >= 0 && lim > 0; --wi) {
+            const int rem = lim - wi * 64;
+            const uint64_t wb = s_head[wi] & (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull));
+            if (wb) { lh = (uint32_t)(base + wi * 64 + 63 - __builtin_clzll(wb)) + 1u; break; }
+        }
+        ft_head[blockIdx.x] = lh;
     }
     __syncthreads();
     const uint32_t q_total = s_woff[FT_XITEMS * NW];
@@ -1430,7 +1491,6 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_top32(const uint32_t *__r
     // ---- phase 2, work-list entries only (uniform early exit: with 12-22 % of the slots tied, two or three per thread) ----
     int jl_[FT_XITEMS], start[FT_XITEMS], end[FT_XITEMS];
     uint32_t mine_mask = 0, n_unowned = 0, n_tied = 0;
-    const int wspan = cap / 64 + 2;
 #pragma unroll
     for (int i = 0; i < FT_XITEMS; ++i) {
         jl_[i] = 0; start[i] = -1; end[i] = -1;
@@ -1439,27 +1499,32 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_top32(const uint32_t *__r
         const int jl = s_list[q];
         jl_[i] = jl;
         {
-            int wi = jl >> 6;
-            uint64_t wb = s_head[wi] & ((jl & 63) == 63 ? ~0ull : ((2ull << (jl & 63)) - 1ull));
-            const int wlow = max(0, wi - wspan);
-            while (!wb && wi > wlow) wb = s_head[--wi];
-            if (wb) start[i] = wi * 64 + 63 - __builtin_clzll(wb);
-        }
-        {
-            int wi = jl >> 6;
-            uint64_t wb = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
-            const int whigh = min(FT_WORDS - 1, wi + wspan);
-            while (!wb && wi < whigh) wb = s_head[++wi];
-            if (wb) end[i] = wi * 64 + __builtin_ctzll(wb);
+            const int wi = jl >> 6;
+            const uint64_t wb = s_head[wi] & ((jl & 63) == 63 ? ~0ull : ((2ull << (jl & 63)) - 1ull));
+            start[i] = wb ? wi * 64 + 63 - __builtin_clzll(wb) : (wi ? s_lastH[wi - 1] : -1);    // -1: the run started before this tile
+            const uint64_t wa = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
+            end[i] = wa ? wi * 64 + __builtin_ctzll(wa) : s_nextH[wi + 1];                        // -1: it goes on beyond the span
         }
         const bool in_main = start[i] >= 0 && start[i] < FT_TILE;              // the group is this workgroup's to handle
         const bool mine = in_main && end[i] > 0 && end[i] - start[i] <= cap;
         if (mine) mine_mask |= 1u << i;
         if (jl < FT_TILE && (in_main || start[i] < 0)) ++n_tied;               // (statistics; counted by the slot's own workgroup)
         if (in_main && !mine && jl < FT_TILE) ++n_unowned;                     // whoever holds a group's first slot owns or reports it
+        if (TODO) {
+            // every member of a group nobody owns must be flagged by SOME workgroup that sees it:
+            //  - the group starts in my slots and I cannot own it: I flag all of it that I see (overhang included);
+            //  - it started before my slots: its owner sees at most my first 256 slots, so a member beyond them, or one of a
+            //    group that goes on beyond them, is nobody's; one of a group that ends inside them is the earlier workgroup's call
+            bool todo;
+            if (in_main) todo = !mine;
+            else if (start[i] >= FT_TILE) todo = false;
+            else todo = jl >= FT_SPAN - FT_TILE || end[i] < 0 || end[i] > FT_SPAN - FT_TILE;
+            if (todo) atomicOr(&s_todo[jl >> 5], 1u << (jl & 31));
+        }
         }
     }
-    uint32_t v[FT_XITEMS], key[FT_XITEMS];
+    uint32_t v[FT_XITEMS];
+    Key2T key[FT_XITEMS];
 #pragma unroll
     for (int i = 0; i < FT_XITEMS; ++i) {
         v[i] = 0; key[i] = 0;
@@ -1468,7 +1533,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_top32(const uint32_t *__r
 #pragma unroll
     for (int i = 0; i < FT_XITEMS; ++i) {
         if ((mine_mask >> i) & 1u) {
-            key[i] = (uint32_t)text_key2<KS_LOWKEY>(T, lcode, P, n, K, v[i], aligned8);
+            key[i] = (Key2T)text_key2<MODE>(T, lcode, P, n, K, v[i], aligned8);
             s_key[jl_[i]] = key[i];
         }
     }
@@ -1480,10 +1545,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_top32(const uint32_t *__r
         dest[i] = 0;
         if ((mine_mask >> i) & 1u) {
             int rank = 0;
-            const uint32_t me = key[i];
+            const Key2T me = key[i];
             const int jl = jl_[i];
             for (int p = start[i]; p < end[i]; ++p) {
-                const uint32_t k = s_key[p];
+                const Key2T k = s_key[p];
                 rank += (k < me || (k == me && p < jl)) ? 1 : 0;
             }
             dest[i] = start[i] + rank;
@@ -1501,14 +1566,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_top32(const uint32_t *__r
         const int jl = jl_[i];                                                 // now: the POSITION this thread finishes
         const int64_t j = base + jl;
         SA[j] = s_val[jl];
-        const uint32_t kk = s_key[jl];
+        const Key2T kk = s_key[jl];
         const bool tl = jl > start[i] && s_key[jl - 1] == kk, tr = jl + 1 < end[i] && s_key[jl + 1] == kk;
-        if (tl || tr) {                                                        // still tied on the whole 64-bit key
+        if (tl || tr) {                                                        // still tied after this round's key
             int p = jl;
             while (p > start[i] && s_key[p - 1] == kk) --p;
             surv_head[j] = (uint32_t)(base + p);
-            atomicOr(&surv_bits[j >> 5], 1u << (j & 31));
-            atomicAdd(&tile_cnt[j / RR_TILE], 1u);
+            atomicOr(&s_surv[jl >> 5], 1u << (jl & 31));
         }
     }
     if (n_unowned) atomicAdd(&s_cnt[0], n_unowned);
@@ -1518,9 +1582,86 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_top32(const uint32_t *__r
         if (s_cnt[0]) atomicAdd(&counters[1], s_cnt[0]);
         if (s_cnt[1]) atomicAdd(&counters[2], s_cnt[1]);
     }
+    if (t < FT_SPAN / 32) {
+        // one atomic per non-empty 32-slot word (base is a multiple of 2048, so words are aligned in the global bitmaps)
+        const int64_t j0 = base + 32 * t;
+        const uint32_t sw = s_surv[t];
+        if (sw) { atomicOr(&surv_bits[j0 >> 5], sw); atomicAdd(&tile_cnt[j0 / RR_TILE], (uint32_t)__popc(sw)); }
+        if (TODO) {
+            const uint32_t tw = s_todo[t];
+            if (tw) {
+                const uint32_t fresh = tw & ~atomicOr(&todo_bits[j0 >> 5], tw);      // (a neighbour may have flagged some already)
+                if (fresh) atomicAdd(&todo_cnt[j0 / FT_TILE], (uint32_t)__popc(fresh));
+            }
+        }
+    }
 }
 
-// survivors of k_finish_top32 -> (slot, group head, suffix) lists in slot order; tile_cnt holds the exclusive
+// Members of the groups k_finish_sorted<.., TODO = true> left to the general path -> (slot, group head, suffix) list in
+// slot order.  One workgroup per 2048-slot tile (those without flagged members leave at once); todo_cnt / ft_head
+// hold the exclusive sums / running maxima of k_rr_scan.  The group head of a member is the last run start at or
+// before it: found in the tile's own run-start bitmap (recomputed from the keys), else carried in.
+template <typename KeyT>
+__global__ __launch_bounds__(FT_THREADS) void k_todo_compact(const KeyT *__restrict__ skeys, const uint32_t *__restrict__ SA, int64_t n,
+                                                              const uint32_t *__restrict__ todo_bits, const uint32_t *__restrict__ todo_cnt,
+                                                              const uint32_t *__restrict__ ft_head, const uint32_t *__restrict__ todo_total,
+                                                              uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo)
+{
+    constexpr int ITEMS = FT_TILE / FT_THREADS;
+    constexpr int BW = FT_TILE / 32;                                          // 64 bitmap words of 32 slots
+    __shared__ KeyT s_nb[FT_TILE];
+    __shared__ uint64_t s_head[FT_TILE / 64];
+    __shared__ uint32_t s_bits[BW], s_off[BW];
+    const uint32_t here = todo_cnt[blockIdx.x];
+    const uint32_t next = (blockIdx.x + 1 < gridDim.x) ? todo_cnt[blockIdx.x + 1] : *todo_total;
+    if (next == here) return;
+    const uint32_t carry = ft_head[blockIdx.x];                              // (last run start before this tile) + 1
+    const int64_t base = (int64_t)blockIdx.x * FT_TILE;
+    const int t = threadIdx.x, l = lane_id();
+    const int valid_cnt = (int)(n - base < FT_TILE ? n - base : FT_TILE);
+    const KeyT prev = base > 0 ? skeys[base - 1] : (KeyT)0;
+    KeyT k[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int jl = r * FT_THREADS + t;
+        k[r] = jl < valid_cnt ? skeys[base + jl] : (KeyT)0;
+        s_nb[jl] = k[r];
+    }
+    if (t < BW) {
+        const int64_t wi = base / 32 + t;
+        const uint32_t b = wi < (n + 31) / 32 ? todo_bits[wi] : 0u;
+        s_bits[t] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int jl = r * FT_THREADS + t;
+        const bool head = jl < valid_cnt && (k[r] != (jl ? s_nb[jl - 1] : prev) || (jl == 0 && base == 0));
+        const uint64_t hb = __ballot(head);
+        if (l == 0) s_head[jl >> 6] = hb;
+    }
+    if (t < WAVE) {                                                           // wave 0: exclusive offsets of the 64 words
+        const uint32_t c = (uint32_t)__popc(s_bits[t]);
+        const uint32_t inc = wave_incl_sum(c);
+        s_off[t] = inc - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int jl = r * FT_THREADS + t;
+        const uint32_t bits = s_bits[jl >> 5];
+        if (!((bits >> (jl & 31)) & 1u)) continue;
+        int wi = jl >> 6;
+        uint64_t wb = s_head[wi] & ((jl & 63) == 63 ? ~0ull : ((2ull << (jl & 63)) - 1ull));
+        while (!wb && wi > 0) wb = s_head[--wi];
+        const uint32_t g = wb ? (uint32_t)(base + wi * 64 + 63 - __builtin_clzll(wb)) : carry - 1u;
+        const uint32_t pos = here + s_off[jl >> 5] + (uint32_t)__popc(bits & ((1u << (jl & 31)) - 1u));
+        const uint32_t slot = (uint32_t)(base + jl);
+        Uo[pos] = slot; Go[pos] = g; Vo[pos] = SA[slot];
+    }
+}
+
+// survivors of k_finish_sorted -> (slot, group head, suffix) lists in slot order; tile_cnt holds the exclusive
 // offsets of the re-rank tiles (k_rr_scan), one workgroup per tile, one bitmap word per thread
 __global__ __launch_bounds__(256) void k_surv_compact(const uint32_t *__restrict__ surv_bits, const uint32_t *__restrict__ surv_head,
                                                        const uint32_t *__restrict__ SA, int64_t n, const uint32_t *__restrict__ tile_cnt,

@@ -314,6 +314,34 @@ def test_group_sort_caps(oracle, monkeypatch, gen, n, seed, cap):
             assert st["locally_sorted"] > 0
 
 
+@pytest.mark.parametrize("gen,n,seed", [("english", 900_000, 31), ("sigma3", 400_000, 32), ("dna_repeats", 600_000, 33),
+                                        ("periodic", 200_003, 34), ("unary", 50_000, 35)])
+@pytest.mark.parametrize("cap", ["3", "100", "1024"])
+def test_first_round_from_sorted_keys(oracle, monkeypatch, gen, n, seed, cap):
+    """k_finish_sorted on 64-bit keys (opt-in SA_AMD_FUSED64): the first text-keyed round in one pass over the sorted keys,
+    groups too large for a tile listed by k_todo_compact for the general route, survivors of both merged by k_surv_compact;
+    and the same kernel finishing the 32-bit first stage (forced), with its fall-back to the general route"""
+    if gen == "periodic":
+        text = np.resize(np.frombuffer(b"abcabcabd", dtype=np.uint8), n)
+    elif gen == "unary":
+        text = np.full(n, 7, dtype=np.uint8)
+    elif gen == "sigma3":
+        text = corpus.sigma(n, seed, 3, 97)
+    else:
+        text = getattr(corpus, gen)(n, seed)
+    exp = oracle.sais(text)
+    monkeypatch.setenv("SA_AMD_GROUP_CAP", cap)
+    monkeypatch.setenv("SA_AMD_FUSED64", "1")
+    monkeypatch.setenv("SA_AMD_NO_TOP32", "1")
+    assert np.array_equal(build(text), exp)
+    assert sa.last_stats()["text_rounds"] >= 1
+    monkeypatch.delenv("SA_AMD_NO_TOP32")
+    monkeypatch.setenv("SA_AMD_FORCE_TOP32", "1")
+    assert np.array_equal(build(text), exp)
+    monkeypatch.setenv("SA_AMD_NO_FUSED_FINISH", "1")
+    assert np.array_equal(build(text), exp)
+
+
 @pytest.mark.parametrize("v64,v32", [("1", "1"), ("2", "2"), ("8", "3"), ("9", "4")])
 def test_sort_kernel_variants(oracle, monkeypatch, v64, v32):
     """the non-default tile-scatter kernels (no prefetch, first-generation scatter, other shapes) give the same arrays"""

@@ -13,7 +13,7 @@ orc = Oracle()
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 BIG = int(sys.argv[3]) if len(sys.argv) > 3 else 400000
 ENV = ["SA_AMD_FORCE_TOP32", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TEXT_ROUNDS", "SA_AMD_FORCE_DENSE", "SA_AMD_BINNED_ISA_ALWAYS",
-       "SA_AMD_NO_TOP32"]
+       "SA_AMD_NO_TOP32", "SA_AMD_FUSED64", "SA_AMD_NO_FUSED_FINISH", "SA_AMD_NO_PACKED_TEXT"]
 t0 = time.time(); cases = 0; fails = 0
 while time.time() - t0 < budget:
     n = int(rng.choice([rng.integers(0, 300), rng.integers(300, 20000), rng.integers(20000, BIG)]))
