@@ -1404,8 +1404,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_sorted(const KeyT *__rest
     __shared__ uint32_t s_cnt[2];
     __shared__ uint32_t s_woff[FT_XITEMS * NW + 1];
     __shared__ uint32_t s_surv[FT_SPAN / 32], s_todo[FT_SPAN / 32];   // this tile's survivor / todo bits, merged into the global bitmaps once
+    __shared__ KeyT s_last[FT_SPAN / 8];            // last key of every group of 8 slots (the next group's left neighbour)
     __shared__ int s_lastH[FT_WORDS], s_nextH[FT_WORDS + 1];   // last run start in words <= w / first one in words >= w (-1: none)
-    KeyT *s_nb = sizeof(KeyT) == 8 ? (KeyT *)(void *)s_key : (KeyT *)(void *)s_val;   // neighbour keys, before either is needed
     lcode[threadIdx.x] = P.code[threadIdx.x];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x < FT_SPAN / 32) { s_surv[threadIdx.x] = 0; s_todo[threadIdx.x] = 0; }
@@ -1416,43 +1416,82 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_sorted(const KeyT *__rest
     const int valid_cnt = (int)(n - base < FT_SPAN ? n - base : FT_SPAN);
     const KeyT prev = base > 0 ? skeys[base - 1] : (KeyT)0;
     // ---- phase 1, every slot, cheap: run starts -> bitmap; slots in runs longer than one -> work list ----
-    KeyT k32[FT_XITEMS];
+    // A thread takes 8 CONSECUTIVE slots (16-byte loads, neighbours in registers): group t of the tile's own 2048 slots,
+    // and threads 0..31 also group 256 + t of the overhang.  Its 8 run-start bits are one byte of the bitmap.
+    constexpr int NG = FT_SPAN / 8;                // 288 groups of 8 slots
+    uint8_t *s_hbyte = (uint8_t *)s_head;
+    uint32_t tied8[2] = { 0, 0 };
+    KeyT kq[2][8];
 #pragma unroll
-    for (int r = 0; r < FT_XITEMS; ++r) {
-        const int jl = r * FT_THREADS + t;
-        k32[r] = jl < valid_cnt ? skeys[base + jl] : (KeyT)0;
-        s_nb[jl] = k32[r];
+    for (int part = 0; part < 2; ++part) {
+        const int g = part ? FT_THREADS + t : t;
+        const int s0 = 8 * g;
+        if (part && t >= NG - FT_THREADS) {
+            // (only 32 groups of overhang)
+        } else if (s0 + 8 <= valid_cnt) {
+            const uint4 *src = (const uint4 *)(skeys + base + s0);
+            if (sizeof(KeyT) == 4) {
+                const uint4 a = src[0], c = src[1];
+                const uint32_t tmp[8] = { a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w };
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kq[part][i] = (KeyT)tmp[i];
+            } else {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const uint4 a = src[h];
+                    kq[part][2 * h] = (KeyT)(((uint64_t)a.y << 32) | a.x);
+                    kq[part][2 * h + 1] = (KeyT)(((uint64_t)a.w << 32) | a.z);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kq[part][i] = s0 + i < valid_cnt ? skeys[base + s0 + i] : (KeyT)0;
+        }
+        if (!part || t < NG - FT_THREADS) s_last[g] = kq[part][7];
     }
     if (t == 0) s_head[FT_WORDS] = 0;              // beyond the span: unknown, treated as "the run goes on"
     __syncthreads();
-    uint64_t hb[FT_XITEMS];
+    uint32_t head8[2] = { 0, 0 };
 #pragma unroll
-    for (int r = 0; r < FT_XITEMS; ++r) {
-        const int jl = r * FT_THREADS + t;
-        const KeyT left = jl ? s_nb[jl - 1] : prev;
-        const bool head = jl >= valid_cnt || k32[r] != left || (jl == 0 && base == 0);   // past the end counts as a run start
-        hb[r] = __ballot(head);
-        if (l == 0) s_head[jl >> 6] = hb[r];
+    for (int part = 0; part < 2; ++part) {
+        const int g = part ? FT_THREADS + t : t;
+        const int s0 = 8 * g;
+        if (!part || t < NG - FT_THREADS) {
+            KeyT left = g ? s_last[g - 1] : prev;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool head = s0 + i >= valid_cnt || kq[part][i] != left || (s0 + i == 0 && base == 0);   // past the end: a run start
+                head8[part] |= (head ? 1u : 0u) << i;
+                left = kq[part][i];
+            }
+            s_hbyte[g] = (uint8_t)head8[part];
+        }
     }
     __syncthreads();
-    uint64_t tied[FT_XITEMS];                      // wave-uniform: lanes whose slot is in a run of more than one element
+    uint32_t cnt_main = 0, cnt_over = 0;
 #pragma unroll
-    for (int r = 0; r < FT_XITEMS; ++r) {
-        const int wi = r * NW + w;                 // this wave's word of the bitmap
-        const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)s_head[wi + 1] & 1u));
-        const uint64_t nxt = (hb[r] >> 1) | ((uint64_t)nb << 63);
-        const int rem = valid_cnt - wi * 64;
-        const uint64_t valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-        tied[r] = valid & ~(hb[r] & nxt);
-        if (l == 0) s_woff[wi] = (uint32_t)__popcll(tied[r]);
+    for (int part = 0; part < 2; ++part) {
+        const int g = part ? FT_THREADS + t : t;
+        const int s0 = 8 * g;
+        if (!part || t < NG - FT_THREADS) {
+            const uint32_t nb = (uint32_t)s_hbyte[g + 1] & 1u;                // (byte NG is the zero word behind the bitmap)
+            const uint32_t nxt = (head8[part] >> 1) | (nb << 7);
+            const int rem = valid_cnt - s0;
+            const uint32_t valid8 = rem >= 8 ? 0xffu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+            tied8[part] = valid8 & ~(head8[part] & nxt);
+            if (part) cnt_over = (uint32_t)__popc(tied8[part]); else cnt_main = (uint32_t)__popc(tied8[part]);
+        }
     }
-    __syncthreads();
+    uint32_t total_main;
+    uint32_t off_main = block_excl_sum<FT_THREADS>(cnt_main, s_woff, &total_main);       // (two barriers inside)
     if (w == 0) {
-        // exclusive offsets of the 36 words: one wave scan
-        const uint32_t c = l < FT_XITEMS * NW ? s_woff[l] : 0u;
-        const uint32_t inc = wave_incl_sum(c);
-        if (l < FT_XITEMS * NW) s_woff[l] = inc - c;
-        if (l == WAVE - 1) s_woff[FT_XITEMS * NW] = inc;
+        // the 32 overhang groups follow the 256 main ones in the list
+        const uint32_t inc = wave_incl_sum(l < NG - FT_THREADS ? cnt_over : 0u);
+        if (l < NG - FT_THREADS) {
+            uint32_t o = total_main + inc - cnt_over;
+            for (uint32_t m8 = tied8[1]; m8; m8 &= m8 - 1) s_list[o++] = (uint16_t)(8 * (FT_THREADS + t) + __builtin_ctz(m8));
+        }
+        if (l == WAVE - 1) s_woff[FT_XITEMS * NW] = total_main + inc;
     } else if (w == 1) {
         // per word: the last run start at or before its end, the first one at or after its beginning (so that the
         // extent of any group is two look-ups, however long the group)
@@ -1468,6 +1507,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_sorted(const KeyT *__rest
         if (l < FT_WORDS) { s_lastH[l] = last; s_nextH[l] = first == 0x7fffffff ? -1 : first; }
         if (l == 0) s_nextH[FT_WORDS] = -1;
     }
+    for (uint32_t m8 = tied8[0]; m8; m8 &= m8 - 1) s_list[off_main++] = (uint16_t)(8 * t + __builtin_ctz(m8));
     if (TODO && t == 0) {
         // last real run start of this tile's own 2048 slots (+1; 0: none): the group-head carry of k_todo_compact
         uint32_t lh = 0;
@@ -1481,13 +1521,6 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_sorted(const KeyT *__rest
     }
     __syncthreads();
     const uint32_t q_total = s_woff[FT_XITEMS * NW];
-#pragma unroll
-    for (int r = 0; r < FT_XITEMS; ++r) {
-        const uint32_t lo = (uint32_t)tied[r], hi = (uint32_t)(tied[r] >> 32);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-        if ((tied[r] >> l) & 1ull) s_list[s_woff[r * NW + w] + below] = (uint16_t)(r * FT_THREADS + t);
-    }
-    __syncthreads();
     // ---- phase 2, work-list entries only (uniform early exit: with 12-22 % of the slots tied, two or three per thread) ----
     int jl_[FT_XITEMS], start[FT_XITEMS], end[FT_XITEMS];
     uint32_t mine_mask = 0, n_unowned = 0, n_tied = 0;
