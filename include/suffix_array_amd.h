@@ -169,6 +169,10 @@ int32_t sa_amd_unpack(const uint8_t *bytes, int64_t nbytes, uint32_t *SA, int64_
  * copies up to `capacity` classes out (ms = summed event time, launches, units = elements or bytes
  * processed); returns the number of kernel classes.  Used by bench.py for the roofline line. */
 void sa_amd_profile_begin(void);
+/* the same for a subset of the kernel classes only (bit i = class i of sa_amd_profile_kernel_name): bench.py times just
+ * the dominant kernel inside its timed region -- ~300 event records per build are ~0.7 ms of host time -- and takes the
+ * full per-kernel table from one extra build outside it */
+void sa_amd_profile_begin_classes(uint64_t class_mask);
 int32_t sa_amd_profile_end(double *ms, int64_t *launches, int64_t *units, int32_t capacity);
 const char *sa_amd_profile_kernel_name(int32_t index);
 

@@ -53,6 +53,7 @@ static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys
                                                     "k_radix_upsweep32", "k_radix_downsweep32" };
 struct Profiler {
     bool on = false;
+    uint64_t mask = ~0ull;      // kernel classes that get events (each pair costs a few microseconds of host time)
     struct Rec { int cls; hipEvent_t a, b; int64_t units; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -67,12 +68,14 @@ struct Profiler {
     }
     void begin(int cls, int64_t u, hipStream_t st)
     {
-        if (!on) return;
+        open = on && ((mask >> cls) & 1ull);
+        if (!open) return;
         Rec r; r.cls = cls; r.units = u; r.a = get(); r.b = get();
         (void)hipEventRecord(r.a, st);
         recs.push_back(r);
     }
-    void end(hipStream_t st) { if (on && !recs.empty()) (void)hipEventRecord(recs.back().b, st); }
+    bool open = false;
+    void end(hipStream_t st) { if (open && !recs.empty()) (void)hipEventRecord(recs.back().b, st); open = false; }
     void resolve()   // call after the stream has been synchronised
     {
         for (auto &r : recs) {
@@ -1327,12 +1330,15 @@ SA_EXPORT const char *sa_amd_strerror(int32_t code)
     }
 }
 
-SA_EXPORT void sa_amd_profile_begin(void)
+SA_EXPORT void sa_amd_profile_begin_classes(uint64_t class_mask)
 {
     sa::Profiler &p = sa::g_prof;
     p.on = true;
+    p.mask = class_mask;
     for (int i = 0; i < sa::KC_COUNT; ++i) { p.ms[i] = 0; p.launches[i] = 0; p.units[i] = 0; }
 }
+
+SA_EXPORT void sa_amd_profile_begin(void) { sa_amd_profile_begin_classes(~0ull); }
 
 SA_EXPORT int32_t sa_amd_profile_end(double *ms, int64_t *launches, int64_t *units, int32_t capacity)
 {
