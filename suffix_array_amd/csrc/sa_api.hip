@@ -403,9 +403,18 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         else if (K.mode == KS_LOWKEY)
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_LOWKEY>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
                                                      Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
-        else
+        else if (K.mode == KS_RANK)
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_RANK>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
                                                      Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+        else {
+            // sparse look-up: its own kernel, one suffix per thread (a chain of ~60 dependent loads each), then the sort on those keys
+            int64_t gblocks = ceil_div(m, GK_THREADS);
+            if (gblocks > 8192) gblocks = 8192;
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_SPARSE>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
+            PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_PRE>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+        }
         if (gs_blocks > 1)
             PROF(KC_LOCAL, 0, st, hipLaunchKernelGGL((k_group_sort_straddle), dim3(gs_blocks - 1), dim3(GX_THREADS), 0, st, rkA, Vcur, Gcur,
                                                      Ucur, m, flags, cap));
@@ -444,8 +453,11 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         else if (K.mode == KS_LOWKEY)
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_LOWKEY>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
-        else
+        else if (K.mode == KS_RANK)
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_RANK>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
+        else
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_SPARSE>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
     }
     rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, kb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
@@ -590,7 +602,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         HIP_TRY(hipMemsetAsync(w.tcnt, 0, (size_t)tiles * 4, st));
         HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
         HIP_TRY(hipMemsetAsync(w.total, 0, 16, st));
-        KeySrc K; K.mode = KS_LOWKEY; K.h = 0; K.s = 0; K.kb = top_shift; K.isa = nullptr;
+        KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
         PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint32_t, KS_LOWKEY, false>), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS),
                                                  0, st, sorted32, SA, dT, P, n, K, cap, surv_bits, surv_head, w.tcnt, w.total, (uint32_t *)nullptr,
                                                  (uint32_t *)nullptr, (uint32_t *)nullptr));
@@ -633,7 +645,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         HIP_TRY(hipMemsetAsync(w.surv_cnt, 0, (size_t)tiles * 4, st));
         HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
         HIP_TRY(hipMemsetAsync(w.total, 0, 32, st));
-        KeySrc K; K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb; K.isa = nullptr;
+        KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
         PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint64_t, KS_TEXT, true>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
                                                  (const uint64_t *)sorted0, SA, dT, P, n, K, cap, w.surv_bits, surv_head, w.surv_cnt, w.total,
                                                  w.todo_bits, w.ft_cnt, w.ft_head));
@@ -701,7 +713,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                     w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
         uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
         Refined rf;
-        KeySrc K; K.mode = KS_LOWKEY; K.h = 0; K.s = 0; K.kb = top_shift; K.isa = nullptr;
+        KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
         rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf);
         if (rc) return rc;
         tiles = ceil_div(m, RR_TILE);
@@ -766,7 +778,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             const int64_t m_before = m;
             uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
             Refined rf;
-            KeySrc K; K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb; K.isa = nullptr;
+            KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
             rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf);
             if (rc) return rc;
             const uint64_t *keysS = rf.keys;                  // (group, text key) pairs ordered inside every group
@@ -813,28 +825,16 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     while (m > 0) {
         if (local.rounds >= 48) return SA_AMD_EINTERNAL;
         uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
-        const uint64_t *keysS; const uint32_t *valsS; uint32_t *Vnext;
-        if (sparse) {
-            int64_t gblocks = ceil_div(m, GK_THREADS);
-            if (gblocks > 8192) gblocks = 8192;
-            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_key2_sparse), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
-                                                      (const uint32_t *)Vcur, (const uint32_t *)Gcur, (const uint32_t *)w.isa,
-                                                      (const uint32_t *)w.has_isa, (const uint64_t *)sorted0, (const uint32_t *)SA, dT, P, m, n, h,
-                                                      depth_text, key2_bits, rkA, sorted32, top_shift));
-            rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, key2_bits + g_bits, w.spine, w.digit_tot, nullptr, st, &sr);
-            if (rc) return rc;
-            local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * m;
-            keysS = sr.keys; valsS = sr.vals;
-            Vnext = (sr.vals == w.valsA) ? w.valsB : w.valsA;
-        } else {
-            // dense: the same refinement machinery as the text rounds, keyed by ranks -- small groups (long repeats give
-            // millions of pairs) are ordered in LDS, only large groups go through the global sort
-            KeySrc K; K.mode = KS_RANK; K.h = h; K.s = 0; K.kb = key2_bits; K.isa = w.isa;
-            Refined rf;
-            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf);
-            if (rc) return rc;
-            keysS = rf.keys; valsS = rf.vals; Vnext = rf.vnext;
-        }
+        // the same refinement machinery as the text rounds, keyed by ranks -- small groups (a long repeat gives millions of
+        // pairs) are ordered in LDS, only large groups go through the global sort.  Dense: ranks from the ISA; sparse:
+        // looked up without one (sparse_key2)
+        KeySrc K = KeySrc();
+        K.mode = sparse ? KS_SPARSE : KS_RANK; K.h = h; K.kb = key2_bits; K.isa = w.isa;
+        K.has_isa = w.has_isa; K.sorted_keys = sorted0; K.sorted_top32 = sorted32; K.sa = SA; K.depth = depth_text; K.top_shift = top_shift;
+        Refined rf;
+        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf);
+        if (rc) return rc;
+        const uint64_t *keysS = rf.keys; const uint32_t *valsS = rf.vals; uint32_t *Vnext = rf.vnext;
         tiles = ceil_div(m, RR_TILE);
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m, w.tcnt,
                            w.thead, 0));

@@ -15,7 +15,7 @@
 //   k_group_sort (+ _straddle), k_flag_count / k_flag_gather / k_scatter_back
 //                      one refinement round: gather of the secondary key (text symbols, low key bits or ranks) fused
 //                      with an in-LDS sort of the small groups; large groups through the global radix sort
-//   k_gather_key2_sparse, k_isa_from_sa / k_isa_tied / k_scatter_pairs
+//   sparse_key2, k_isa_from_sa / k_isa_tied / k_scatter_pairs
 //                      prefix doubling: rank look-up without an ISA (few ties) or ISA maintenance (many)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
 //   v + h >= n : n - 1 - v          (text ended inside the compared prefix: the shorter suffix,
 //                                    i.e. the larger v, is smaller; all below every real rank)
 // key = (group head << key2_bits) | key2, so one sort by key refines every group at once
-// (text_key2<KS_RANK> below; the sparse variant without an ISA is k_gather_key2_sparse).
+// (text_key2<KS_RANK> below; the sparse variant without an ISA: sparse_key2).
 // ------------------------------------------------------------------------------------------
 constexpr int GK_THREADS = 256;
 
@@ -1134,19 +1134,76 @@ __device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ T, cons
 // suffix's own 64-bit key as the secondary key (KS_LOWKEY).
 // KS_RANK is the secondary key of a prefix-doubling round with a full ISA (step 7, dense): the rank of the suffix h
 // symbols further on, n + ISA[v + h], or n - 1 - v when the text ends inside the compared prefix.
-enum { KS_TEXT = 0, KS_LOWKEY = 1, KS_RANK = 2 };
+// KS_SPARSE is the same key when few suffixes are tied and no full ISA exists: the rank is looked up (sparse_rank below).
+// KS_PRE (k_group_sort only): the secondary keys have been gathered into the key array already (the sparse look-up is a long
+// chain of dependent loads per suffix: one thread per suffix in its own kernel, not eight per thread in the sort).
+enum { KS_TEXT = 0, KS_LOWKEY = 1, KS_RANK = 2, KS_SPARSE = 3, KS_PRE = 4 };
 struct KeySrc {
-    int mode;          // KS_TEXT / KS_LOWKEY / KS_RANK
-    int64_t h;         // KS_TEXT, KS_RANK: symbols already sorted (offset of the secondary key)
+    int mode;          // KS_TEXT / KS_LOWKEY / KS_RANK / KS_SPARSE
+    int64_t h;         // KS_TEXT, KS_RANK, KS_SPARSE: symbols already sorted (offset of the secondary key)
     int s;             // KS_TEXT: symbols per secondary key
     int kb;            // bits of the secondary key
-    const uint32_t *isa;   // KS_RANK
+    const uint32_t *isa;   // KS_RANK, KS_SPARSE
+    // KS_SPARSE only:
+    const uint32_t *has_isa;        // bit q: ISA[q] is valid (q has been in the tied list of a doubling round)
+    const uint64_t *sorted_keys;    // the initial 64-bit keys in SA order, or
+    const uint32_t *sorted_top32;   // (two-stage initial sort) only their top 32 bits; then sorted_keys is unused
+    const uint32_t *sa;             // SA[1..]
+    int64_t depth;                  // symbols the initial sort and the text-keyed rounds have ordered
+    int top_shift;
 };
+
+// Sparse rank lookup (few tied suffixes): no ISA is built.  rank(q) of suffix q under the current order:
+//  - q has been in the tied list of a doubling round: ISA[q] (has_isa bit set by k_rr_apply);
+//  - otherwise its rank is still what the initial sort and the text-keyed rounds gave it.  The sorted
+//    initial keys give the slot range [lo, hi) of the suffixes sharing q's first k symbols (binary
+//    search); text-keyed rounds have ordered that range by the symbols k .. depth-1, so a second binary
+//    search on those symbols (read from the text) finds the first slot of q's group.  rank = slot + 1,
+//    the value a dense ISA scatter would have stored.
+// sorted_top32 != nullptr: the first stage sorted only the top 32 key bits (no 64-bit sorted keys exist);
+// level 1 then searches those, level 2 compares ALL symbols 0 .. depth-1 through the text.
+__device__ __forceinline__ uint64_t sparse_key2(const uint8_t *__restrict__ T, const uint8_t *lcode, const KeyParams &P, int64_t n,
+                                                const KeySrc &K, uint32_t v, bool aligned8)
+{
+    const int64_t p = (int64_t)v + K.h;
+    if (p >= n) return (uint64_t)(n - 1 - (int64_t)v);
+    if ((K.has_isa[p >> 5] >> (p & 31)) & 1u) return (uint64_t)n + (uint64_t)K.isa[p];
+    const uint64_t kq = text_key(T, lcode, P, n, p, P.k, aligned8);
+    int64_t lo = 0, hi = n, a = 0;              // [lo, a): slots whose (top) key equals q's
+    if (K.sorted_top32) {
+        const uint32_t kt = (uint32_t)(kq >> K.top_shift);
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (K.sorted_top32[mid] < kt) lo = mid + 1; else hi = mid; }
+        a = lo; int64_t b = n;
+        while (a < b) { const int64_t mid = (a + b) >> 1; if (K.sorted_top32[mid] <= kt) a = mid + 1; else b = mid; }
+    } else {
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (K.sorted_keys[mid] < kq) lo = mid + 1; else hi = mid; }
+        a = lo; int64_t b = n;
+        if (K.depth > P.k) while (a < b) { const int64_t mid = (a + b) >> 1; if (K.sorted_keys[mid] <= kq) a = mid + 1; else b = mid; }
+    }
+    const int64_t from = K.sorted_top32 ? 0 : P.k;  // symbols already decided by level 1
+    if (K.depth > from && a - lo > 1) {
+        int64_t l2 = lo, h2 = a;                 // inside [lo, a): first slot not smaller on symbols from .. depth-1
+        while (l2 < h2) {
+            const int64_t mid = (l2 + h2) >> 1;
+            const int64_t sfx = (int64_t)K.sa[mid];
+            bool less = false;                   // suffix at mid < q on those symbols?
+            for (int64_t i = from; i < K.depth; ++i) {
+                const uint64_t ca = code_at(T, lcode, n, sfx + i), cb = code_at(T, lcode, n, p + i);
+                if (ca != cb) { less = ca < cb; break; }
+            }
+            if (less) l2 = mid + 1; else h2 = mid;
+        }
+        lo = l2;
+    }
+    return (uint64_t)n + (uint64_t)lo + 1u;
+}
 
 template <int MODE>
 __device__ __forceinline__ uint64_t text_key2(const uint8_t *__restrict__ T, const uint8_t *lcode, const KeyParams &P, int64_t n,
                                               const KeySrc &K, uint32_t v, bool aligned8)
 {
+    if (MODE == KS_PRE) return 0;
+    if (MODE == KS_SPARSE) return sparse_key2(T, lcode, P, n, K, v, aligned8);
     if (MODE == KS_RANK) {
         const int64_t p = (int64_t)v + K.h;
         return p < n ? (uint64_t)n + (uint64_t)K.isa[p] : (uint64_t)(n - 1 - (int64_t)v);
@@ -1201,7 +1258,7 @@ constexpr int GS_CAP = 1024;        // upper bound of the run-time group-size ca
 template <int MODE>
 __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, const uint32_t *__restrict__ G,
                                                             const uint32_t *__restrict__ U, const uint8_t *__restrict__ T, KeyParams P,
-                                                            int64_t m, int64_t n, KeySrc K, uint64_t *__restrict__ keys,
+                                                            int64_t m, int64_t n, KeySrc K, uint64_t *keys,
                                                             uint32_t *Vout, uint8_t *__restrict__ bigflag, int cap)   // Vout may be Vin
 {
     __shared__ uint64_t s_key[GS_TILE];
@@ -1227,7 +1284,8 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
 #pragma unroll
     for (int r = 0; r < GS_ITEMS; ++r) {
         const int64_t j = base + r * GS_THREADS + t;
-        key[r] = j < m ? text_key2<MODE>(T, lcode, P, n, K, v[r], aligned8) : 0ull;
+        if (MODE == KS_PRE) key[r] = j < m ? (keys[j] & ((1ull << K.kb) - 1ull)) : 0ull;
+        else key[r] = j < m ? text_key2<MODE>(T, lcode, P, n, K, v[r], aligned8) : 0ull;
     }
     // keys of at most 53 bits are ranked as (key << 11 | tile position): unique, so one compare per member
     static_assert(GS_TILE <= 2048, "11 bits of tile position");
@@ -1796,68 +1854,6 @@ __global__ __launch_bounds__(256) void k_count_sample_dups(const uint64_t *__res
         uint32_t t = 0;
         for (int w = 0; w < 256 / WAVE; ++w) t += wsum[w];
         if (t) atomicAdd(dups, t);
-    }
-}
-
-// Sparse rank lookup (few tied suffixes): no ISA is built.  rank(q) of suffix q under the current order:
-//  - q has been in the tied list of a doubling round: ISA[q] (has_isa bit set by k_rr_apply);
-//  - otherwise its rank is still what the initial sort and the text-keyed rounds gave it.  The sorted
-//    initial keys give the slot range [lo, hi) of the suffixes sharing q's first k symbols (binary
-//    search); text-keyed rounds have ordered that range by the symbols k .. depth-1, so a second binary
-//    search on those symbols (read from the text) finds the first slot of q's group.  rank = slot + 1,
-//    the value a dense ISA scatter would have stored.
-__global__ __launch_bounds__(GK_THREADS) void k_gather_key2_sparse(
-    const uint32_t *__restrict__ V, const uint32_t *__restrict__ G, const uint32_t *__restrict__ ISA,
-    const uint32_t *__restrict__ has_isa, const uint64_t *__restrict__ sorted_keys, const uint32_t *__restrict__ SA,
-    const uint8_t *__restrict__ T, KeyParams P, int64_t m, int64_t n, int64_t h, int64_t depth, int key2_bits,
-    uint64_t *__restrict__ keys, const uint32_t *__restrict__ sorted_top32, int top_shift)
-{
-    // sorted_top32 != nullptr: the first stage sorted only the top 32 key bits (no 64-bit sorted keys exist);
-    // level 1 then searches those, level 2 compares ALL symbols 0 .. depth-1 through the text
-    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
-    __shared__ uint8_t lcode[256];
-    lcode[threadIdx.x] = P.code[threadIdx.x];
-    __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * GK_THREADS;
-    for (int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x; j < m; j += stride) {
-        const uint32_t v = V[j];
-        const int64_t p = (int64_t)v + h;
-        uint64_t key2;
-        if (p >= n) {
-            key2 = (uint64_t)(n - 1 - (int64_t)v);
-        } else if ((has_isa[p >> 5] >> (p & 31)) & 1u) {
-            key2 = (uint64_t)n + (uint64_t)ISA[p];
-        } else {
-            const uint64_t kq = text_key(T, lcode, P, n, p, P.k, aligned8);
-            int64_t lo = 0, hi = n, a = 0;              // [lo, a): slots whose (top) key equals q's
-            if (sorted_top32) {
-                const uint32_t kt = (uint32_t)(kq >> top_shift);
-                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_top32[mid] < kt) lo = mid + 1; else hi = mid; }
-                a = lo; int64_t b = n;
-                while (a < b) { const int64_t mid = (a + b) >> 1; if (sorted_top32[mid] <= kt) a = mid + 1; else b = mid; }
-            } else {
-                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_keys[mid] < kq) lo = mid + 1; else hi = mid; }
-                a = lo; int64_t b = n;
-                if (depth > P.k) while (a < b) { const int64_t mid = (a + b) >> 1; if (sorted_keys[mid] <= kq) a = mid + 1; else b = mid; }
-            }
-            const int64_t from = sorted_top32 ? 0 : P.k;  // symbols already decided by level 1
-            if (depth > from && a - lo > 1) {
-                int64_t l2 = lo, h2 = a;                 // inside [lo, a): first slot not smaller on symbols from .. depth-1
-                while (l2 < h2) {
-                    const int64_t mid = (l2 + h2) >> 1;
-                    const int64_t sfx = (int64_t)SA[mid];
-                    bool less = false;                   // suffix at mid < q on those symbols?
-                    for (int64_t i = from; i < depth; ++i) {
-                        const uint64_t ca = code_at(T, lcode, n, sfx + i), cb = code_at(T, lcode, n, p + i);
-                        if (ca != cb) { less = ca < cb; break; }
-                    }
-                    if (less) l2 = mid + 1; else h2 = mid;
-                }
-                lo = l2;
-            }
-            key2 = (uint64_t)n + (uint64_t)lo + 1u;
-        }
-        keys[j] = ((uint64_t)G[j] << key2_bits) | key2;
     }
 }
 
