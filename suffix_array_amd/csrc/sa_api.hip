@@ -49,7 +49,7 @@ enum KClass { KC_BYTE_HIST = 0, KC_BUILD_KEYS, KC_UPSWEEP, KC_SPINE, KC_DOWNSWEE
               KC_GATHER, KC_SCATTER, KC_LOCAL, KC_MISC, KC_UPSWEEP32, KC_DOWNSWEEP32, KC_COUNT };
 static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys", "k_radix_upsweep", "k_spine_rows",
                                                     "k_radix_downsweep", "k_rr_count", "k_rr_scan", "k_rr_apply",
-                                                    "k_gather_key2", "k_scatter_pairs", "k_group_sort", "misc",
+                                                    "k_gather_key2", "k_scatter_pairs", "k_group_sort", "misc",   // (k_gather_key2: the plain gathers; k_group_sort: all fused gather + sort kernels)
                                                     "k_radix_upsweep32", "k_radix_downsweep32" };
 struct Profiler {
     bool on = false;
@@ -230,7 +230,7 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
     return SA_AMD_OK;
 }
 
-// 32-bit keys (two-stage initial sort): same three-kernel pass, 16 Ki-pair tiles (the 64 KiB stage holds twice the elements)
+// 32-bit keys (two-stage initial sort): same three-kernel pass, 12 Ki-pair tiles by default (the LDS stage holds more 4-byte elements)
 struct SortResult32 { uint32_t *keys; uint32_t *vals; int passes; };
 constexpr int SORT32_THREADS = 1024;
 typedef void (*Downsweep32Fn)(const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, int64_t, int,
@@ -427,7 +427,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         const size_t half = (((size_t)n / 2 + 1) & ~(size_t)1);
         if ((size_t)m_big <= half) {
             if (m_big > 0) {
-                // groups no window owns: global sort of (group head, key2), then back to their list positions
+                // groups no tile owns: global sort of (group head, key2), then back to their list positions
                 PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_flag_gather), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                             (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, m,
                                                             (const uint32_t *)w.tcnt, rkB, Valt, scratchU));
@@ -532,7 +532,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     local.top32_first = top_shift ? 1 : 0;
 
     // 3. packed keys, 4. initial sort: all key bits as (u64 key, u32 suffix) pairs, or only the top 32 bits as
-    //    (u32, u32) pairs in 16 Ki-element tiles -- two thirds of the bytes per pass and half the passes
+    //    (u32, u32) pairs in 12 Ki-element tiles -- two thirds of the bytes per pass and half the passes
     SortResult sr;
     sr.keys = w.keysA; sr.vals = w.valsA; sr.passes = 0;
     const uint32_t *sorted32 = nullptr;               // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
