@@ -737,7 +737,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     // 5. refinement of the tied suffixes.  Three regimes:
     //   text rounds  while more than n / SPARSE_DIV suffixes are tied: secondary key = the next symbols of
     //                the text itself (no rank array needed yet), depth grows by s symbols per round;
-    //   sparse       few tied suffixes: prefix doubling, ranks looked up without an ISA (k_gather_key2_sparse);
+    //   sparse       few tied suffixes: prefix doubling, ranks looked up without an ISA (sparse_key2);
     //   dense        prefix doubling with a full ISA (repetitive texts, or forced for A/B measurements).
     const int key2_bits = bit_length((uint64_t)(2 * n));
     int64_t sparse_div = SPARSE_DIV;
