@@ -580,16 +580,18 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     uint64_t *sorted0 = sr.keys;                      // the initial keys in SA order (kept for the rank look-ups)
     bool lists_ready = false;                         // (Ucur, Gcur, Vcur) already hold the tied suffixes
     int64_t depth = P.k;                               // symbols the current order is sorted by
-    int s_sym = 0, tkb = 0;                            // text-keyed rounds: symbols per round, bits of their packed key
+    // Text-keyed rounds pack their symbols as bit fields of ceil(log2 sigma) bits whatever the alphabet: a secondary key only
+    // has to preserve the order inside one round, and the base-sigma form costs a 64-bit multiply per symbol in kernels
+    // that are instruction-bound (k_group_sort: 26 ps per suffix however small the text).  English-like sigma = 56: six
+    // symbols in 36 bits either way.
+    KeyParams Ptext = P;
+    if (P.bits == 0) Ptext.bits = bit_length(P.sigma - 1);
+    int s_sym = 0, tkb = 0;                            // symbols per round, bits of their packed key
     {
         const int room = 64 - g_bits;                   // bits left below the group head
-        if (P.bits > 0) { s_sym = room / P.bits; tkb = s_sym * P.bits; }
-        else {
-            unsigned __int128 pw = 1;
-            while (pw * P.sigma <= ((unsigned __int128)1 << room)) { pw *= P.sigma; ++s_sym; }
-            tkb = bit_length((uint64_t)(pw - 1));
-        }
+        s_sym = room / Ptext.bits;
         if (s_sym > 64) s_sym = 64;
+        tkb = s_sym * Ptext.bits;
     }
     bool finished32 = false, fused64 = false;
     if (top_shift && local_ok && !getenv("SA_AMD_NO_FUSED_FINISH") && !getenv("SA_AMD_TIMING_ONLY_INITIAL_SORT")) {
@@ -647,7 +649,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         HIP_TRY(hipMemsetAsync(w.total, 0, 32, st));
         KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
         PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint64_t, KS_TEXT, true>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
-                                                 (const uint64_t *)sorted0, SA, dT, P, n, K, cap, w.surv_bits, surv_head, w.surv_cnt, w.total,
+                                                 (const uint64_t *)sorted0, SA, dT, Ptext, n, K, cap, w.surv_bits, surv_head, w.surv_cnt, w.total,
                                                  w.todo_bits, w.ft_cnt, w.ft_head));
         PROF(KC_RR_SCAN, ft_tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, ft_tiles, w.total + 3));
         uint32_t cnt4[4] = { 0, 0, 0, 0 };                    // [2] tied after the initial sort, [3] members left to the general route
@@ -665,7 +667,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
             Refined rf;
             bool big_local = true;                             // (large groups: the global sort does the work either way)
-            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m_todo, n, dT, P, K, g_bits, &big_local, w, st, &local, &rf);
+            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m_todo, n, dT, Ptext, K, g_bits, &big_local, w, st, &local, &rf);
             if (rc) return rc;
             const int64_t tt = ceil_div(m_todo, RR_TILE);
             PROF(KC_RR_COUNT, m_todo, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st, rf.keys,
@@ -779,7 +781,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
             Refined rf;
             KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
-            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf);
+            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, Ptext, K, g_bits, &local_ok, w, st, &local, &rf);
             if (rc) return rc;
             const uint64_t *keysS = rf.keys;                  // (group, text key) pairs ordered inside every group
             const uint32_t *valsS = rf.vals;
