@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -990,12 +991,26 @@ SA_EXPORT int32_t sa_amd_saca_batch(const uint8_t *const *T, uint32_t *const *SA
         if (d < 0 || d >= ndev) { st[(size_t)i] = SA_AMD_EINVAL; continue; }
         per_dev[(size_t)d].push_back(i);
     }
+    // Two host threads per device (SA_AMD_BATCH_THREADS, 1..4), each with its own stream and device block, take the
+    // device's items in turn: while one waits for its 4(n+1)-byte copy back over PCIe the other uploads and computes,
+    // so the link and the GPU overlap instead of alternating.
+    int per = 2;
+    if (const char *e = getenv("SA_AMD_BATCH_THREADS")) { per = atoi(e); if (per < 1) per = 1; if (per > 4) per = 4; }
+    std::vector<std::atomic<size_t>> next((size_t)ndev);
+    for (auto &a : next) a.store(0);
     std::vector<std::thread> workers;
     for (int d = 0; d < ndev; ++d) {
-        if (per_dev[(size_t)d].empty()) continue;
-        workers.emplace_back([&, d]() {
-            for (int i : per_dev[(size_t)d]) st[(size_t)i] = sa::build_host(T[i], SA[i], n[i], true, d);
-        });
+        const size_t items = per_dev[(size_t)d].size();
+        for (int k = 0; k < per && (size_t)k < items; ++k) {
+            workers.emplace_back([&, d]() {
+                for (;;) {
+                    const size_t q = next[(size_t)d].fetch_add(1);
+                    if (q >= per_dev[(size_t)d].size()) break;
+                    const int i = per_dev[(size_t)d][q];
+                    st[(size_t)i] = sa::build_host(T[i], SA[i], n[i], true, d);
+                }
+            });
+        }
     }
     for (auto &t : workers) t.join();
     int32_t first = SA_AMD_OK;
