@@ -51,6 +51,8 @@ while time.time() - t0 < budget:
     except Exception as e:
         ok = False; print("EXC", e)
     cases += 1
+    if cases % 2000 == 0:
+        print(f"  ... {cases} cases, {fails} failures, {time.time()-t0:.0f} s", flush=True)   # (a silent run is taken to be hung)
     if not ok:
         fails += 1
         print("FAIL n", n, "kind", kind, "env", chosen, sa.last_stats())
