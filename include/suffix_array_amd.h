@@ -179,6 +179,8 @@ const char *sa_amd_profile_kernel_name(int32_t index);
 /* diagnostic builds of the dominant kernel only (SA_AMD_SORT_VARIANT = the 'phase stamps' entry):
  * cycles per phase summed over tiles and workgroups; reading zeroes the counters */
 int32_t sa_amd_debug_phase_cycles(uint64_t *out, int32_t count);
+/* k_group_sort: switch its per-phase stamps on / off (entries 8..13 of the same array; tools/group_sort_stamps.py) */
+int32_t sa_amd_debug_group_sort_stamps(int32_t on);
 
 /* ---- primitive test hooks: exercised by tests/ to localise a failing kernel ---- */
 

@@ -1319,6 +1319,12 @@ SA_EXPORT int32_t sa_amd_debug_phase_cycles(uint64_t *out, int32_t count)
     return 16;
 }
 
+SA_EXPORT int32_t sa_amd_debug_group_sort_stamps(int32_t on)
+{
+    const int v = on ? 1 : 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(sa::g_gs_stamp_on), &v, sizeof(v)) == hipSuccess ? SA_AMD_OK : SA_AMD_EHIP;
+}
+
 SA_EXPORT void sa_amd_release_cache(void) { sa::g_cache.release(); }
 
 SA_EXPORT void sa_amd_last_stats(sa_amd_stats *out)

@@ -608,6 +608,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep(
 // ------------------------------------------------------------------------------------------
 // diagnostic build only (STAMP): cycles of wave 0 per phase, summed over tiles and workgroups
 __device__ unsigned long long g_phase_cycles[16];
+__device__ int g_gs_stamp_on;          // diagnostic: k_group_sort adds its per-phase cycles (wave 0) to g_phase_cycles[8..15]
 
 // PF > 0: the first PF of a thread's ITEMS keys of the NEXT tile are prefetched into LDS by global->LDS DMA
 // (no registers) right after this tile's keys are in registers, and stay in flight across the LDS-only
@@ -1271,6 +1272,15 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
     const bool aligned8 = (((uintptr_t)T) & 7) == 0;
     const int64_t base = (int64_t)blockIdx.x * GS_TILE;
     const int t = threadIdx.x;
+    const bool stamping = g_gs_stamp_on != 0 && t == 0;
+    unsigned long long t_prev = stamping ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto stamp = [&](int phase) {
+        if (stamping) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            atomicAdd(&g_phase_cycles[8 + phase], now - t_prev);
+            t_prev = now;
+        }
+    };
     uint32_t v[GS_ITEMS], g[GS_ITEMS], u[GS_ITEMS];
     uint64_t key[GS_ITEMS];
 #pragma unroll
@@ -1281,12 +1291,14 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         g[r] = valid ? G[j] : 0u;
         u[r] = valid ? U[j] : 0u;
     }
+    stamp(0);      // list loads issued
 #pragma unroll
     for (int r = 0; r < GS_ITEMS; ++r) {
         const int64_t j = base + r * GS_THREADS + t;
         if (MODE == KS_PRE) key[r] = j < m ? (keys[j] & ((1ull << K.kb) - 1ull)) : 0ull;
         else key[r] = j < m ? text_key2<MODE>(T, lcode, P, n, K, v[r], aligned8) : 0ull;
     }
+    stamp(1);      // secondary keys gathered (includes the wait for the list loads)
     // keys of at most 53 bits are ranked as (key << 11 | tile position): unique, so one compare per member
     static_assert(GS_TILE <= 2048, "11 bits of tile position");
     const bool packed = K.kb <= 53;
@@ -1317,6 +1329,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         if (l == 0) s_nextH[GS_WORDS + 1] = -1;
     }
     __syncthreads();
+    stamp(2);      // keys + group-start bitmap in LDS, next-start table (3 barriers)
     int dest[GS_ITEMS];
     bool big[GS_ITEMS];
 #pragma unroll
@@ -1346,6 +1359,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         dest[r] = owned ? start + rank : jl;
         big[r] = valid && !owned;
     }
+    stamp(3);      // group extents + rank loops
     __syncthreads();                                             // every rank is known: the key slots can be reused
 #pragma unroll
     for (int r = 0; r < GS_ITEMS; ++r) {
@@ -1353,12 +1367,14 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         s_val[dest[r]] = v[r];
     }
     __syncthreads();
+    stamp(4);      // permuted through LDS (2 barriers)
 #pragma unroll
     for (int r = 0; r < GS_ITEMS; ++r) {
         const int jl = r * GS_THREADS + t;
         const int64_t j = base + jl;
         if (j < m) { keys[j] = s_key[jl]; Vout[j] = s_val[jl]; bigflag[j] = big[r] ? 1 : 0; }
     }
+    stamp(5);      // stores issued
 }
 
 // The groups k_group_sort could not own only because they straddle a tile boundary: one workgroup per
