@@ -514,16 +514,15 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             const int64_t S = (int64_t)1 << 20;
             PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_keys), dim3((unsigned)ceil_div(S, GK_THREADS)), dim3(GK_THREADS), 0, st, dT, P, n, S,
                                                     key_bits - 32, w.keysA));
-            SortResult ss;
-            int rcs = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, S, 32, 64, w.spine, w.digit_tot, nullptr, st, &ss);
-            if (rcs) return rcs;
-            local.sort_passes += ss.passes; local.sorted_elements += (int64_t)ss.passes * S;
+            // duplicates counted in a hash table (4 entries per sample, in the other key buffer) instead of sorting the sample
+            const uint32_t H = (uint32_t)S * 4u;
+            HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
             HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
-            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(64), dim3(256), 0, st,
-                                                    (const uint64_t *)ss.keys, S, w.total));
+            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
+                                                    (unsigned long long *)w.keysB, H - 1u, w.total));
             uint32_t dups = 0;
             { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
-            // adjacent duplicates of a sorted sample under-count pairs only when runs are long, which is the
+            // c - 1 per value seen c times under-counts pairs only when values repeat often, which is the
             // "do not" case anyway; expected number of other suffixes sharing the top bits with a given one:
             const double q = 2.0 * (double)dups / ((double)S * (double)S);
             use = (double)n * q < 0.5;

@@ -1855,13 +1855,27 @@ __global__ __launch_bounds__(GK_THREADS) void k_sample_keys(const uint8_t *__res
     out[i] = ((kq >> top_shift) << 32) | (uint64_t)(uint32_t)p;      // position in the low half: equal positions are not collisions
 }
 
-__global__ __launch_bounds__(256) void k_count_sample_dups(const uint64_t *__restrict__ sorted, int64_t samples, uint32_t *__restrict__ dups)
+// Duplicates of the top 32 key bits among the samples, without sorting them: every sample ((top bits << 32) | position)
+// is inserted into an open-addressing hash table of 64-bit entries (all ones = empty).  Meeting an entry with the
+// same top bits and another position counts one duplicate (a value seen c times counts c - 1, as adjacent equal
+// neighbours of a sorted sample would); the same position drawn twice is not a collision.
+__global__ __launch_bounds__(256) void k_count_sample_dups(const uint64_t *__restrict__ samples, int64_t count, unsigned long long *table,
+                                                            uint32_t table_mask, uint32_t *__restrict__ dups)
 {
-    // grid-stride, one atomic per workgroup (one per wave serialised 16 Ki atomics on one address: 190 us)
     __shared__ uint32_t wsum[256 / WAVE];
     uint32_t c = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < samples; i += (int64_t)gridDim.x * 256)
-        if (i > 0) c += ((sorted[i] >> 32) == (sorted[i - 1] >> 32) && (uint32_t)sorted[i] != (uint32_t)sorted[i - 1]) ? 1u : 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long e = samples[i];
+        const uint32_t k = (uint32_t)(e >> 32);
+        uint32_t h = (k * 2654435761u) >> 7;
+        for (;;) {
+            h &= table_mask;
+            const unsigned long long old = atomicCAS(&table[h], ~0ull, e);
+            if (old == ~0ull) break;                                           // inserted
+            if ((uint32_t)(old >> 32) == k) { c += old != e ? 1u : 0u; break; }
+            ++h;
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
     if (lane_id() == 0) wsum[wave_id()] = c;
