@@ -330,6 +330,7 @@ def test_first_round_from_sorted_keys(oracle, monkeypatch, gen, n, seed, cap):
     else:
         text = getattr(corpus, gen)(n, seed)
     exp = oracle.sais(text)
+    monkeypatch.delenv("SA_AMD_NO_FUSED_FINISH", raising=False)      # (the suite may be run under global switches)
     monkeypatch.setenv("SA_AMD_GROUP_CAP", cap)
     monkeypatch.setenv("SA_AMD_FUSED64", "1")
     monkeypatch.setenv("SA_AMD_NO_TOP32", "1")
