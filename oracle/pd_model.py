@@ -1,9 +1,12 @@
 """numpy model of the DEVICE algorithm (test infrastructure only, like everything in oracle/).
 
-It restates, step for step, what suffix_array_amd/csrc does on the GPU -- packed-symbol
-initial keys, a stable LSD sort, group-head ranks, text-keyed refinement rounds while many
-suffixes are tied, then prefix-doubling refinement of the unresolved groups with the end-of-text rule -- so that the algorithm's logic (not the HIP
-code) can be checked on the CPU against oracle_naive_sa / oracle_sais.
+It restates the LOGIC of what suffix_array_amd/csrc does on the GPU -- packed-symbol initial keys, a
+stable sort, group-head ranks, text-keyed refinement rounds while many suffixes are tied, then
+prefix-doubling refinement of the unresolved groups with the end-of-text rule -- so that the
+algorithm (not the HIP code) can be checked on the CPU against oracle_naive_sa / oracle_sais.
+Device-side staging that does not change the result is not modelled: the 32-bit first stage of the
+initial sort and its one-pass finish, the in-LDS group sort versus the global sort, the bit-field
+packing of the text-round keys, the sparse rank look-up versus a full ISA.
 
 The output contract is the reference's: sa[0] = n, sa[1..] sorted suffix offsets
 (reference src/saca.rs:9-15), order as in reference src/sa.rs:72-84.
