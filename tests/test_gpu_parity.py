@@ -12,6 +12,7 @@ from conftest import KNOWN_ANSWERS, adversarial_cases
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def build(text):
@@ -595,3 +596,33 @@ def test_pack_correctness_property_of_the_reference(oracle):
     bad = sa.SuffixArray(b"banana").dump_bytes()
     with pytest.raises(ValueError):
         sa.SuffixArray.load_bytes(b"bananb", bad)       # integrity check fails: the reference's InvalidData
+
+
+def test_c_program_through_the_abi(tmp_path):
+    """a plain C caller of the drop-in symbols: sa_amd_divsufsort has the signature of the C engine the crate's
+    src/saca.rs:14 binds (T, SA, n -> 0), sa_amd_saca_u8 the contract of saca() itself (src/saca.rs:9-15)"""
+    import subprocess
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include "suffix_array_amd.h"
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+    const unsigned char *t = (const unsigned char *)"mississippi";
+    int32_t sa[11]; uint32_t full[12];
+    static const int32_t want[11] = { 10, 7, 4, 1, 0, 9, 8, 6, 3, 5, 2 };
+    if (sa_amd_divsufsort(t, sa, 11) != 0) return 1;
+    if (memcmp(sa, want, sizeof(want)) != 0) return 2;
+    if (sa_amd_saca_u8(t, full, 11) != 0) return 3;
+    if (full[0] != 11 || memcmp(full + 1, want, sizeof(want)) != 0) return 4;
+    if (sa_amd_divsufsort(t, sa, 0) != 0) return 5;                 /* n = 0: success, nothing written */
+    if (sa_amd_divsufsort((const unsigned char *)0, sa, 3) == 0) return 6;   /* null text: an error code, no abort */
+    puts("ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "caller"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "suffix_array_amd"), "-lsuffix_array_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "suffix_array_amd")])
+    assert subprocess.call([str(exe)]) == 0
