@@ -84,17 +84,22 @@ int64_t sa_amd_workspace_bytes(int32_t n);
 
 /*
  * dT: n bytes in device memory; dSA: n + 1 uint32 in device memory (layout of sa_amd_saca_u8);
- * dWork: sa_amd_workspace_bytes(n) bytes of device scratch, 256-byte aligned; stream: a
+ * dWork: sa_amd_workspace_bytes(n) bytes of device scratch, 256-byte aligned (else SA_AMD_EINVAL); stream: a
  * hipStream_t (NULL = default stream) on the current device.  Blocks until the array is
  * complete (the refinement loop reads a 4-byte counter back per round).  stats may be NULL.
  */
 int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n, void *dWork,
                            int64_t work_bytes, void *stream, sa_amd_stats *stats);
 
-/* The host-pointer entry points keep one grow-only device block and one stream per calling thread
- * (at most SA_AMD_CACHE_MAX_BYTES, default 1 GiB; larger requests are allocated per call).
- * This frees the calling thread's block now; it is also freed when the thread exits. */
+/* The host-pointer entry points take their device memory (text + SA + workspace of one build = one block), streams and
+ * pinned staging buffers from a process-wide pool, so repeated calls do not pay hipMalloc / hipFree; the pool retains at
+ * most SA_AMD_CACHE_MAX_BYTES of device memory (default 64 GiB of the 288 GB).  This empties the pool now. */
 void sa_amd_release_cache(void);
+
+/* wall-clock phases of the calling thread's most recent host-pointer build, milliseconds:
+ * [0] acquire device block + stream, [1] text upload, [2] build on the device, [3] suffix array download,
+ * [4] release, [5] total, [6] helper threads of the staged download (0 = one plain hipMemcpy).  Returns 7. */
+int32_t sa_amd_last_host_timing(double *ms, int32_t capacity);
 
 /* statistics of the most recent build issued by the calling thread (any entry point) */
 void sa_amd_last_stats(sa_amd_stats *out);
@@ -144,7 +149,9 @@ typedef struct sa_amd_index sa_amd_index;
 int32_t sa_amd_index_create(const uint8_t *T, int32_t n, const uint32_t *SA, sa_amd_index **out);
 void sa_amd_index_destroy(sa_amd_index *ix);
 int32_t sa_amd_index_sa(const sa_amd_index *ix, uint32_t *SA_out);               /* n + 1 entries */
-int32_t sa_amd_index_buckets(const sa_amd_index *ix, uint32_t *bkt);             /* 65 793 entries */
+int32_t sa_amd_index_buckets(sa_amd_index *ix, uint32_t *bkt);                   /* 65 793 entries; the index keeps the table and
+                                                                                    later searches start from the pattern's bucket
+                                                                                    (get_bucket, reference src/sa.rs:123-144) */
 int32_t sa_amd_index_check_integrity(const sa_amd_index *ix);                    /* as sa_amd_check_integrity */
 int32_t sa_amd_index_search(const sa_amd_index *ix, const uint8_t *pat_data, const int64_t *pat_off, int32_t count,
                             uint8_t *contains, uint32_t *range_lo, uint32_t *range_hi, uint32_t *lcp_start,
@@ -175,23 +182,6 @@ void sa_amd_profile_begin(void);
 void sa_amd_profile_begin_classes(uint64_t class_mask);
 int32_t sa_amd_profile_end(double *ms, int64_t *launches, int64_t *units, int32_t capacity);
 const char *sa_amd_profile_kernel_name(int32_t index);
-
-/* diagnostic builds of the dominant kernel only (SA_AMD_SORT_VARIANT = the 'phase stamps' entry):
- * cycles per phase summed over tiles and workgroups; reading zeroes the counters */
-int32_t sa_amd_debug_phase_cycles(uint64_t *out, int32_t count);
-/* k_group_sort: switch its per-phase stamps on / off (entries 8..13 of the same array; tools/group_sort_stamps.py) */
-int32_t sa_amd_debug_group_sort_stamps(int32_t on);
-
-/* ---- primitive test hooks: exercised by tests/ to localise a failing kernel ---- */
-
-/* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit); host buffers */
-int32_t sa_amd_test_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit,
-                               int32_t end_bit);
-/* the 32-bit-key form of the same sort (first stage of the two-stage initial sort) */
-int32_t sa_amd_test_sort_pairs32(uint32_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit,
-                                 int32_t end_bit);
-/* initial packed keys of a text (host buffers; keys has n entries); returns bits in *bits, symbols in *k */
-int32_t sa_amd_test_build_keys(const uint8_t *T, int32_t n, uint64_t *keys, int32_t *bits, int32_t *k);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@
  *                          induce B right-to-left, induce A left-to-right)
  *   oracle_check_integrity literal restatement of reference src/sa.rs:72-84
  *   oracle_verify_sa       linear-time equivalent of the same check
+ *   oracle_verify_sa_mt    the same on several host threads (full-size configs)
  * Pinning: tests/test_oracle.py checks all of them against the known answers
  * of SURVEY.md section 8a, the reference's only literal vector
  * (`search_all(b"splend") == [0, 9]` on b"splendid splendor", reference
@@ -118,6 +119,98 @@ ORACLE_API int32_t oracle_verify_sa(const uint8_t *s, int64_t n, const uint32_t 
         if (s[a] < s[b]) continue;
         if (s[a] > s[b]) { ok = 0; break; }
         if (rank[a + 1] >= rank[b + 1]) ok = 0;
+    }
+    free(rank);
+    return ok;
+}
+
+/* ------------------------------------------------------------------ */
+/* LCP statistics of a text from its suffix array (Kasai et al.): the   */
+/* corpus facts bench.py states for its workload (mean / max LCP, how   */
+/* many suffixes share at least 2^k symbols with their SA predecessor). */
+/* out: [0] sum of LCP, [1] max LCP, [2 + k] count of LCP >= 2^k, k<30  */
+/* ------------------------------------------------------------------ */
+ORACLE_API int32_t oracle_lcp_stats(const uint8_t *s, int64_t n, const uint32_t *sa, uint64_t *out)
+{
+    for (int k = 0; k < 32; ++k) out[k] = 0;
+    if (n <= 0) return 0;
+    uint32_t *rank = (uint32_t *)malloc(((size_t)n + 1) * sizeof(uint32_t));
+    if (!rank) return -2;
+    for (int64_t i = 0; i <= n; ++i) rank[sa[i]] = (uint32_t)i;
+    int64_t h = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = rank[i];          /* >= 1: slot 0 is the empty suffix */
+        const int64_t j = sa[r - 1];        /* predecessor (j == n: the empty suffix, LCP 0) */
+        while (i + h < n && j + h < n && s[i + h] == s[j + h]) ++h;
+        out[0] += (uint64_t)h;
+        if ((uint64_t)h > out[1]) out[1] = (uint64_t)h;
+        for (int k = 0; k < 30 && ((int64_t)1 << k) <= h; ++k) out[2 + k]++;
+        if (h > 0) --h;
+    }
+    free(rank);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* the same linear-time check on `threads` host threads, for the        */
+/* full-size configs (1 GiB: four random accesses per entry).  The      */
+/* sequential duplicate test is replaced by a read-back pass: after the */
+/* scatter rank[sa[i]] == i must hold for every i, which fails for one  */
+/* of any two entries that name the same suffix.                        */
+/* ------------------------------------------------------------------ */
+#include <pthread.h>
+
+typedef struct {
+    const uint8_t *s; const uint32_t *sa; uint32_t *rank; int64_t n, lo, hi; int phase; int ok;
+} verify_job;
+
+static void *verify_worker(void *arg)
+{
+    verify_job *j = (verify_job *)arg;
+    const uint8_t *s = j->s; const uint32_t *sa = j->sa; uint32_t *rank = j->rank;
+    const int64_t n = j->n;
+    int ok = 1;
+    if (j->phase == 0) {
+        for (int64_t i = j->lo; i < j->hi; ++i) {
+            if ((int64_t)sa[i] > n) { ok = 0; break; }
+            rank[sa[i]] = (uint32_t)i;
+        }
+    } else if (j->phase == 1) {
+        for (int64_t i = j->lo; i < j->hi; ++i) if (rank[sa[i]] != (uint32_t)i) { ok = 0; break; }
+    } else {
+        for (int64_t i = j->lo < 2 ? 2 : j->lo; i < j->hi; ++i) {
+            const uint32_t a = sa[i - 1], b = sa[i];
+            if (s[a] < s[b]) continue;
+            if (s[a] > s[b] || rank[a + 1] >= rank[b + 1]) { ok = 0; break; }
+        }
+    }
+    j->ok = ok;
+    return NULL;
+}
+
+ORACLE_API int32_t oracle_verify_sa_mt(const uint8_t *s, int64_t n, const uint32_t *sa, int64_t sa_len, int32_t threads)
+{
+    if (n + 1 != sa_len) return 0;
+    if (sa[0] != (uint32_t)n) return 0;
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    uint32_t *rank = (uint32_t *)malloc(((size_t)n + 1) * sizeof(uint32_t));
+    if (!rank) return -2;
+    int ok = 1;
+    for (int phase = 0; phase < 3 && ok; ++phase) {
+        pthread_t th[64];
+        verify_job jobs[64];
+        const int64_t per = (n + 1 + threads - 1) / threads;
+        int started = 0;
+        for (int t = 0; t < threads; ++t) {
+            verify_job *j = &jobs[t];
+            j->s = s; j->sa = sa; j->rank = rank; j->n = n; j->phase = phase; j->ok = 1;
+            j->lo = (int64_t)t * per; j->hi = j->lo + per > n + 1 ? n + 1 : j->lo + per;
+            if (j->lo >= j->hi) break;
+            if (pthread_create(&th[t], NULL, verify_worker, j) != 0) { verify_worker(j); th[t] = 0; }
+            started = t + 1;
+        }
+        for (int t = 0; t < started; ++t) { if (th[t]) pthread_join(th[t], NULL); if (!jobs[t].ok) ok = 0; }
     }
     free(rank);
     return ok;

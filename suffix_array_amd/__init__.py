@@ -19,7 +19,7 @@ from typing import Optional
 
 import numpy as np
 
-__all__ = ["MAX_LENGTH", "saca", "SuffixArray", "SuffixArrayError", "lib", "library_path", "Stats",
+__all__ = ["MAX_LENGTH", "saca", "SuffixArray", "SuffixArrayError", "lib", "diag_lib", "library_path", "Stats", "last_host_timing",
            "saca_batch", "workspace_bytes", "saca_device_ptr", "bucket_table", "check_integrity", "last_stats", "DeviceIndex", "pack", "unpack"]
 
 #: reference src/saca.rs:6
@@ -109,14 +109,51 @@ def lib() -> ctypes.CDLL:
         L.sa_amd_profile_end.restype = ctypes.c_int32
         L.sa_amd_profile_kernel_name.argtypes = [ctypes.c_int32]
         L.sa_amd_profile_kernel_name.restype = ctypes.c_char_p
+        L.sa_amd_last_host_timing.argtypes = [c_vp, ctypes.c_int32]
+        L.sa_amd_last_host_timing.restype = ctypes.c_int32
+        L.sa_amd_profile_begin_classes.argtypes = [ctypes.c_uint64]
+        L.sa_amd_profile_begin_classes.restype = None
+        L.sa_amd_check_integrity_device.argtypes = [c_vp, ctypes.c_int32, c_vp, c_vp, ctypes.c_int64, c_vp]
+        L.sa_amd_check_integrity_device.restype = ctypes.c_int32
+        _lib = L
+    return _lib
+
+
+_diag: Optional[ctypes.CDLL] = None
+
+
+def diag_lib() -> ctypes.CDLL:
+    """libsuffix_array_amd_diag.so (csrc/sa_diag.h): the same sources built with -DSA_AMD_DIAG -- primitive test hooks,
+    phase stamps and the timing ablations.  For tests/ and tools/ only; nothing in the product path loads it."""
+    global _diag
+    if _diag is None:
+        path = os.path.join(_HERE, "libsuffix_array_amd_diag.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} not found: run __graft_entry__.build()")
+        L = ctypes.CDLL(path)
+        c_vp = ctypes.c_void_p
         L.sa_amd_test_sort_pairs.argtypes = [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
         L.sa_amd_test_sort_pairs.restype = ctypes.c_int32
         L.sa_amd_test_sort_pairs32.argtypes = [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
         L.sa_amd_test_sort_pairs32.restype = ctypes.c_int32
         L.sa_amd_test_build_keys.argtypes = [c_vp, ctypes.c_int32, c_vp, c_vp, c_vp]
         L.sa_amd_test_build_keys.restype = ctypes.c_int32
-        _lib = L
-    return _lib
+        L.sa_amd_debug_phase_cycles.argtypes = [c_vp, ctypes.c_int32]
+        L.sa_amd_debug_phase_cycles.restype = ctypes.c_int32
+        L.sa_amd_debug_group_sort_stamps.argtypes = [ctypes.c_int32]
+        L.sa_amd_debug_group_sort_stamps.restype = ctypes.c_int32
+        L.sa_amd_debug_sort_variant_count.restype = ctypes.c_int32
+        L.sa_amd_debug_sort_variant_name.argtypes = [ctypes.c_int32]
+        L.sa_amd_debug_sort_variant_name.restype = ctypes.c_char_p
+        L.sa_amd_saca_u8.argtypes = [c_vp, c_vp, ctypes.c_int32]
+        L.sa_amd_saca_u8.restype = ctypes.c_int32
+        L.sa_amd_saca_device.argtypes = [c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int64, c_vp, c_vp]
+        L.sa_amd_saca_device.restype = ctypes.c_int32
+        L.sa_amd_workspace_bytes.argtypes = [ctypes.c_int32]
+        L.sa_amd_workspace_bytes.restype = ctypes.c_int64
+        L.sa_amd_version.restype = ctypes.c_char_p
+        _diag = L
+    return _diag
 
 
 def _check(code: int) -> None:
@@ -167,6 +204,13 @@ def saca_batch(texts, devices=None):
     rc = lib().sa_amd_saca_batch(T, S, N, D, cnt, st)
     _check(rc)
     return outs
+
+
+def last_host_timing() -> dict:
+    """wall-clock phases (ms) of this thread's most recent host-pointer build (sa_amd_last_host_timing)"""
+    v = (ctypes.c_double * 7)()
+    lib().sa_amd_last_host_timing(v, 7)
+    return {"acquire": v[0], "h2d": v[1], "build": v[2], "d2h": v[3], "release": v[4], "total": v[5], "staged_threads": int(v[6])}
 
 
 def last_stats() -> dict:
@@ -339,6 +383,7 @@ class SuffixArray:
         t = _as_u8(s)
         self._sa = np.resize(self._sa, t.size + 1)
         saca(t, self._sa)
+        self._ix = None                                # the device-resident index (a cache of this object) held the old array
 
     def fit(self) -> None:                             # src/sa.rs:36-38 (shrink_to_fit: numpy arrays carry no slack)
         self._sa = np.ascontiguousarray(self._sa)
@@ -397,6 +442,8 @@ class SuffixArray:
         """reference src/sa.rs:89-119; a no-op when the table exists (src/sa.rs:90-92)"""
         if self._bkt is None:
             self._bkt = bucket_table(self._s, self._sa)
+            if getattr(self, "_ix", None) is not None:
+                self._ix.buckets()                     # the resident index now narrows its searches (get_bucket, src/sa.rs:123-144)
 
     def buckets(self) -> Optional[np.ndarray]:
         return self._bkt
@@ -406,6 +453,8 @@ class SuffixArray:
     def _index(self) -> "DeviceIndex":
         if getattr(self, "_ix", None) is None:
             self._ix = DeviceIndex(self._s, self._sa)
+            if self._bkt is not None:
+                self._ix.buckets()
         return self._ix
 
     def contains(self, pat) -> bool:

@@ -27,6 +27,8 @@ def _gen():
         L.sa_gen_dna_repeats.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double]
         L.sa_gen_english.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32]
         L.sa_gen_english.restype = ctypes.c_int32
+        L.sa_gen_english_corpus.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_double]
+        L.sa_gen_english_corpus.restype = ctypes.c_int32
         _lib = L
     return _lib
 
@@ -63,11 +65,29 @@ def english(n: int, seed: int, vocab: int = 50000) -> np.ndarray:
     return out
 
 
+def english_iid(n: int, seed: int, vocab: int = 50000) -> np.ndarray:
+    """round-1 C3 model: iid Zipf words, no phrase reuse (mean LCP 9, max 29 at 32 MiB) -- kept as `c3_iid_256m`"""
+    return english(n, seed, vocab)
+
+
+def english_corpus(n: int, seed: int, vocab: int = 50000, dup_fraction: float = 0.08) -> np.ndarray:
+    """C3: English-like text with the repeat structure of a real corpus (word bigrams, stock sentences, copied passages
+    with mutations; csrc/textgen.c sa_gen_english_corpus) -- the offline stand-in for Pizza&Chili `english`
+    (reference benches/utils.rs:24-45)"""
+    out = np.empty(n, dtype=np.uint8)
+    rc = _gen().sa_gen_english_corpus(out.ctypes.data, n, seed, vocab, dup_fraction)
+    if rc:
+        raise MemoryError("sa_gen_english_corpus")
+    return out
+
+
 #: BASELINE.md section 2 workloads: name -> (generator, n, seed)
 WORKLOADS = {
     "c1_uniform_1k": (uniform, 1 << 10, 1),
     "c2_uniform_64m": (uniform, 64 << 20, 2),
-    "c3_english_256m": (english, 256 << 20, 3),
+    "c3_english_256m": (english_corpus, 256 << 20, 3),
+    "c3_iid_256m": (english_iid, 256 << 20, 3),
+    "c2_uniform_256m": (uniform, 256 << 20, 2),          # north_star's literal "256 MiB random-byte text"
     "c4_dna_1g": (dna, 1 << 30, 4),
     "c5_uniform_512m": (uniform, 512 << 20, 50),
 }

@@ -1,0 +1,783 @@
+// host/pipeline.hpp -- the device pipeline of one build: workspace layout, radix-sort driver, refinement rounds,
+// build_device().  Replaces the arithmetic behind `cdivsufsort::sort_in_place` (reference src/saca.rs:14).
+// There is deliberately no CPU fallback: every step launches the HIP kernels of kernels/*.hpp or returns an error code.
+#pragma once
+#include "support.hpp"
+#include "tuning.hpp"
+
+namespace sa {
+
+constexpr int MAX_TEXT_ROUNDS = 4;   // text-keyed rounds before falling back to rank doubling with a full ISA
+constexpr int SORT_MAX_WG = 1024;   // spine rows are scanned by one 1024-thread block
+static_assert(GROUP_CAP_MAX == GS_CAP, "Tuning clamps SA_AMD_GROUP_CAP to the kernel's cap");
+
+// Tile-scatter kernel shapes (threads, items per thread, workgroups per CU).  SA_AMD_SORT_VARIANT selects one at run
+// time for A/B measurements; every entry of the PRODUCT table sorts correctly.  The diagnostic library appends the
+// first-generation scatter, its timing ablations (wrong orders, on purpose) and the phase-stamp build.
+typedef void (*DownsweepFn)(const uint64_t *, const uint32_t *, uint64_t *, uint32_t *, uint32_t *,
+                            const uint32_t *, int64_t, int, uint32_t, int64_t, int);
+struct SortVariant { int threads, items, wg_per_cu; DownsweepFn fn; const char *name; };
+static const SortVariant sort_variants[] = {
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 16, 1, false, uint64_t, 4>, "carry-completed lines 1024x8 + LDS prefetch of half of the next tile's keys (default)" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8" },
+    { 512, 16, 1, k_radix_downsweep_wcl<512, 16>, "carry-completed lines 512x16" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 8>, "carry 1024x8, granule 8" },
+#ifdef SA_AMD_DIAG
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 4>, "plain tile scatter 1024x8 (first generation)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 4, 1>, "plain 1024x8 ABLATION sequential stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 4, 33>, "plain 1024x8 ABLATION no ranking + sequential stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 4, 16>, "plain 1024x8 ABLATION no stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep<1024, 8, 4, 49>, "plain 1024x8 ABLATION no ranking, no stores (wrong results)" },
+    { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 16, 1, true>, "carry 1024x8 DIAGNOSTIC phase stamps (tools/phase_stamps.py)" },
+#endif
+};
+constexpr int N_SORT_VARIANTS = (int)(sizeof(sort_variants) / sizeof(sort_variants[0]));
+
+struct SortGrid { int G; int64_t tiles_per_wg; int tile; };
+static SortGrid sort_grid(int64_t count, const SortVariant &sv)
+{
+    SortGrid g;
+    g.tile = sv.threads * sv.items;
+    const int64_t tiles = ceil_div(count, g.tile);
+    int max_wg = 256 * sv.wg_per_cu;
+    if (max_wg > SORT_MAX_WG) max_wg = SORT_MAX_WG;
+    g.tiles_per_wg = ceil_div(tiles, max_wg);
+    if (g.tiles_per_wg < 1) g.tiles_per_wg = 1;
+    g.G = (int)ceil_div(tiles, g.tiles_per_wg);
+    if (g.G < 1) g.G = 1;
+    return g;
+}
+
+// device scratch layout for a text of n bytes
+struct Workspace {
+    uint64_t *keysA, *keysB, *keysC;
+    uint32_t *valsA, *valsB, *isa, *U0, *U1, *G0, *G1;
+    uint32_t *spine, *digit_tot, *tcnt, *thead, *hist, *total, *has_isa;
+    uint8_t *packed;           // bit-packed text (alphabets of 2, 4 or 16 symbols): n / 2 + 64 bytes
+    uint32_t *surv_bits, *surv_cnt, *todo_bits, *ft_cnt, *ft_head;   // first refinement round straight from the sorted keys (k_finish_sorted)
+    size_t bytes;
+};
+
+static Workspace carve(void *base, int64_t n)
+{
+    Workspace w;
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off = align_up(off + b, 256); return (char *)base + o; };
+    w.keysA = (uint64_t *)take(N * 8);
+    w.keysB = (uint64_t *)take(N * 8);
+    w.keysC = (uint64_t *)take(N * 8);
+    w.valsA = (uint32_t *)take(N * 4);
+    w.valsB = (uint32_t *)take(N * 4);
+    w.isa = (uint32_t *)take(N * 4);
+    w.U0 = (uint32_t *)take(N * 4);
+    w.U1 = (uint32_t *)take(N * 4);
+    w.G0 = (uint32_t *)take(N * 4);
+    w.G1 = (uint32_t *)take(N * 4);
+    w.spine = (uint32_t *)take((size_t)RADIX * SORT_MAX_WG * 4);
+    w.digit_tot = (uint32_t *)take(RADIX * 4);
+    const size_t rr_tiles = (size_t)ceil_div((int64_t)N, RR_TILE);
+    w.tcnt = (uint32_t *)take(rr_tiles * 4);
+    w.thead = (uint32_t *)take(rr_tiles * 4);
+    w.hist = (uint32_t *)take(256 * 4);
+    w.total = (uint32_t *)take(256);
+    w.has_isa = (uint32_t *)take((N + 31) / 32 * 4);
+    w.packed = (uint8_t *)take(N / 2 + 64);
+    w.surv_bits = (uint32_t *)take((N + 31) / 32 * 4);
+    w.surv_cnt = (uint32_t *)take(rr_tiles * 4);          // (not tcnt: refine_list uses that one for its own compaction)
+    w.todo_bits = (uint32_t *)take((N + 31) / 32 * 4);
+    const size_t ft_tiles = (size_t)ceil_div((int64_t)N, FT_TILE) + 1;
+    w.ft_cnt = (uint32_t *)take(ft_tiles * 4);
+    w.ft_head = (uint32_t *)take(ft_tiles * 4);
+    w.bytes = off;
+    return w;
+}
+
+struct SortResult { uint64_t *keys; uint32_t *vals; int passes; };
+
+// stable LSD sort of `count` pairs on key bits [begin_bit, end_bit); ping-pongs between in/alt.
+// spine: RADIX * SORT_MAX_WG words, digit_tot: RADIX words.  final_vals (optional): the LAST pass
+// writes its values there instead of into the ping-pong buffer (the initial sort delivers
+// straight into SA this way).
+static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, uint32_t *vals_alt, int64_t count,
+                      int begin_bit, int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals,
+                      hipStream_t st, SortResult *res, const Tuning &tn, bool iota = false)   // iota: value i = index i, vals_in is scratch only
+{
+    res->keys = keys_in; res->vals = vals_in; res->passes = 0;
+    if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
+    const SortVariant &sv = sort_variants[tn.sort_variant];
+    const SortGrid g = sort_grid(count, sv);
+    uint64_t *kin = keys_in, *kout = keys_alt;
+    uint32_t *vin = vals_in, *vout = vals_alt;
+    for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
+        const int nb = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
+        const uint32_t dmask = (1u << nb) - 1u;
+        const bool last = shift + RADIX_BITS >= end_bit;
+        uint32_t *vdst = (last && final_vals) ? final_vals : vout;
+        {
+            const int64_t chunk = g.tiles_per_wg * g.tile;
+            int split = 2048 / g.G;
+            if (split < 1) split = 1;
+            while (split > 1 && chunk / split < 4096) split /= 2;
+            const int64_t sub = (ceil_div(chunk, split) + 1) & ~(int64_t)1;
+            // (atomic accumulation needs a zeroed spine: once here, afterwards every downsweep zeroes what it consumed)
+            if (split > 1 && res->passes == 0) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * g.G * 4, st));
+            PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.G * split), dim3(SORT_THREADS), 0, st, kin, spine,
+                                                           count, shift, dmask, chunk, g.G, split, sub));
+        }
+        PROF(KC_SPINE, (int64_t)RADIX * g.G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st,
+                                                                    spine, digit_tot, g.G));
+        PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((sv.fn), dim3(g.G), dim3(sv.threads), 0, st,
+                                                         (const uint64_t *)kin, (const uint32_t *)((iota && res->passes == 0) ? nullptr : vin), kout, vdst,
+                                                         spine, (const uint32_t *)digit_tot, count, shift,
+                                                         dmask, g.tiles_per_wg, g.G));
+        uint64_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *free_v = vin;     // the values just consumed become the next scratch target
+        vin = vdst;
+        vout = free_v;
+        res->passes++;
+    }
+    res->keys = kin; res->vals = vin;
+    return SA_AMD_OK;
+}
+
+// 32-bit keys (two-stage initial sort): same three-kernel pass, 12 Ki-pair tiles by default (the LDS stage holds more 4-byte elements)
+struct SortResult32 { uint32_t *keys; uint32_t *vals; int passes; };
+constexpr int SORT32_THREADS = 1024;
+typedef void (*Downsweep32Fn)(const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, int64_t, int,
+                              uint32_t, int64_t, int);
+struct Sort32Variant { int items; Downsweep32Fn fn; };
+static const Sort32Variant sort32_variants[] = {
+    { 12, k_radix_downsweep_wcl<SORT32_THREADS, 12, 16, 1, false, uint32_t, 12> },    // default: next tile's keys prefetched into LDS
+    { 12, k_radix_downsweep_wcl<SORT32_THREADS, 12, 16, 1, false, uint32_t> },
+    { 8, k_radix_downsweep_wcl<SORT32_THREADS, 8, 16, 1, false, uint32_t> },
+    { 16, k_radix_downsweep_wcl<SORT32_THREADS, 16, 16, 1, false, uint32_t> },        // spills
+    { 8, k_radix_downsweep_wcl<SORT32_THREADS, 8, 16, 1, false, uint32_t, 8> },
+};
+constexpr int N_SORT32_VARIANTS = (int)(sizeof(sort32_variants) / sizeof(sort32_variants[0]));
+
+static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit,
+                        int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals, hipStream_t st, SortResult32 *res,
+                        const Tuning &tn, bool iota = false)
+{
+    res->keys = keys_in; res->vals = vals_in; res->passes = 0;
+    if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
+    const Sort32Variant &sv = sort32_variants[tn.sort32_variant];
+    const int64_t SORT32_TILE = (int64_t)SORT32_THREADS * sv.items;
+    const int64_t tiles = ceil_div(count, SORT32_TILE);
+    int64_t tiles_per_wg = ceil_div(tiles, 512);
+    if (tiles_per_wg < 1) tiles_per_wg = 1;
+    const int G = (int)ceil_div(tiles, tiles_per_wg);
+    uint32_t *kin = keys_in, *kout = keys_alt, *vin = vals_in, *vout = vals_alt;
+    for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
+        const int nb = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
+        const uint32_t dmask = (1u << nb) - 1u;
+        const bool last = shift + RADIX_BITS >= end_bit;
+        uint32_t *vdst = (last && final_vals) ? final_vals : vout;
+        {
+            const int64_t chunk = tiles_per_wg * SORT32_TILE;
+            int split = 2048 / G;
+            if (split < 1) split = 1;
+            while (split > 1 && chunk / split < 8192) split /= 2;
+            const int64_t sub = (ceil_div(chunk, split) + 3) & ~(int64_t)3;
+            if (split > 1 && res->passes == 0) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * G * 4, st));
+            PROF(KC_UPSWEEP32, count, st, hipLaunchKernelGGL((k_radix_upsweep32), dim3(G * split), dim3(SORT_THREADS), 0, st,
+                                                           (const uint32_t *)kin, spine, count, shift, dmask, chunk, G, split, sub));
+        }
+        PROF(KC_SPINE, (int64_t)RADIX * G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st, spine, digit_tot, G));
+        PROF(KC_DOWNSWEEP32, count, st, hipLaunchKernelGGL((sv.fn),
+                                                         dim3(G), dim3(SORT32_THREADS), 0, st, (const uint32_t *)kin,
+                                                         (const uint32_t *)((iota && res->passes == 0) ? nullptr : vin), kout,
+                                                         vdst, spine, (const uint32_t *)digit_tot, count, shift, dmask,
+                                                         tiles_per_wg, G));
+        uint32_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *free_v = vin;
+        vin = vdst;
+        vout = free_v;
+        res->passes++;
+    }
+    res->keys = kin; res->vals = vin;
+    return SA_AMD_OK;
+}
+
+// symbol codes and key geometry from the sigma = 256 histogram; returns the number of key bits to sort
+static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out, int kb_max = 64)
+{
+    int sigma = 0;
+    for (int c = 0; c < 256; ++c) {
+        if (hist[c]) P->code[c] = (uint8_t)sigma++;
+        else P->code[c] = 0;
+    }
+    *sigma_out = sigma;
+    P->packed = nullptr;
+    const uint64_t se = sigma > 2 ? (uint64_t)sigma : 2u;      // effective radix (a unary text still needs one bit)
+    P->sigma = se;
+    // kb_max < 64 (A/B): fewer key bits = fewer radix passes, more left to the rounds
+    if ((se & (se - 1)) == 0) {                                // power of two: plain bit fields
+        const int bits = bit_length(se - 1);
+        P->bits = bits;
+        P->k = kb_max / bits;
+        const int used = P->k * bits;
+        P->mask = used >= 64 ? ~0ull : ((1ull << used) - 1ull);
+        P->top = 0;
+        return used;
+    }
+    // otherwise pack as a base-sigma number: the largest k with sigma^k <= 2^64
+    unsigned __int128 pw = 1;
+    int k = 0;
+    while (pw * se <= ((unsigned __int128)1 << kb_max)) { pw *= se; ++k; }
+    P->bits = 0;
+    P->k = k;
+    P->mask = ~0ull;
+    uint64_t top = 1;
+    for (int i = 0; i + 1 < k; ++i) top *= se;
+    P->top = top;
+    const unsigned __int128 maxkey = pw - 1;                   // fits in 64 bits
+    return bit_length((uint64_t)maxkey);
+}
+
+// Small device -> host read-backs (counts that steer the host loop) go through a pinned per-thread buffer:
+// a 4-byte hipMemcpyAsync into pageable memory costs ~50-90 us per round trip, into pinned memory ~10.
+struct PinnedWords {
+    uint32_t *p = nullptr;
+    ~PinnedWords() { if (p) (void)hipHostFree(p); }
+};
+static thread_local PinnedWords g_pinned;
+static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)     // bytes <= 1024; synchronises the stream
+{
+    if (!g_pinned.p && hipHostMalloc((void **)&g_pinned.p, 1024, hipHostMallocDefault) != hipSuccess) {
+        g_pinned.p = nullptr;
+        (void)hipGetLastError();
+        HIP_TRY(hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return SA_AMD_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(g_pinned.p, dsrc, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(dst, g_pinned.p, bytes);
+    return SA_AMD_OK;
+}
+
+// binned ISA update pays off once the ISA is far larger than the caches and there is enough to write
+static bool binned(int64_t n, int64_t count, const Tuning &tn)
+{
+    if (tn.no_binned_isa) return false;
+    if (tn.binned_isa_always) return count > 0;      // tests: exercise the path at small sizes
+    return n >= ((int64_t)1 << 25) && count >= ((int64_t)1 << 22);
+}
+
+// (suffix, rank) pairs -> one radix pass on the top 8 bits of the suffix position -> windowed scatter
+static int scatter_binned(uint64_t *pk, uint32_t *pv, uint64_t *altk, uint32_t *altv, int64_t count, int64_t n,
+                          const Workspace &w, hipStream_t st, sa_amd_stats *local, const Tuning &tn)
+{
+    const int nb = bit_length((uint64_t)(n - 1));
+    const int shift = nb > RADIX_BITS ? nb - RADIX_BITS : 0;
+    SortResult pr;
+    int rc = sort_pairs(pk, pv, altk, altv, count, shift, shift + RADIX_BITS, w.spine, w.digit_tot, nullptr, st, &pr, tn);
+    if (rc) return rc;
+    local->sort_passes += pr.passes; local->sorted_elements += (int64_t)pr.passes * count;
+    PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_pairs), dim3((unsigned)ceil_div(count, 1024)), dim3(256), 0, st,
+                                                   (const uint64_t *)pr.keys, (const uint32_t *)pr.vals, w.isa, count, (uint32_t)n));
+    return SA_AMD_OK;
+}
+
+struct Refined { const uint64_t *keys; const uint32_t *vals; uint32_t *vnext; };
+
+// One refinement round of the tied list with a secondary key taken from the text (KeySrc): afterwards every
+// group is ordered by (group head << kb) | key2.  Small groups: gather fused with the in-LDS group sort
+// (k_group_sort); groups no tile owns, or everything when *local_ok is off: plain gather + global radix sort.
+// scratchU / scratchG: two free 4n-byte buffers.
+static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *Valt, const uint32_t *Ucur, const uint32_t *Gcur,
+                       uint32_t *scratchU, uint32_t *scratchG, int64_t m, int64_t n, const uint8_t *dT, const KeyParams &P,
+                       const KeySrc &K, int g_bits, bool *local_ok, const Workspace &w, hipStream_t st, sa_amd_stats *local,
+                       Refined *out, const Tuning &tn)
+{
+    const int64_t tiles = ceil_div(m, RR_TILE);
+    const int kb = K.kb;
+    SortResult sr;
+    int rc;
+    if (*local_ok) {
+        uint8_t *flags = (uint8_t *)scratchG;
+        const unsigned gs_blocks = (unsigned)ceil_div(m, GS_TILE);
+        const int cap = tn.group_cap;                    // largest group ordered in LDS (C3: 1024 beats 512 by 1%)
+        if (K.mode == KS_TEXT)
+            PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_TEXT>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+        else if (K.mode == KS_LOWKEY)
+            PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_LOWKEY>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+        else if (K.mode == KS_RANK)
+            PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_RANK>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+        else {
+            // sparse look-up: its own kernel, one suffix per thread (a chain of ~60 dependent loads each), then the sort on those keys
+            int64_t gblocks = ceil_div(m, GK_THREADS);
+            if (gblocks > 8192) gblocks = 8192;
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_SPARSE>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
+            PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_PRE>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+        }
+        if (gs_blocks > 1)
+            PROF(KC_LOCAL, 0, st, hipLaunchKernelGGL((k_group_sort_straddle), dim3(gs_blocks - 1), dim3(GX_THREADS), 0, st, rkA, Vcur, Gcur,
+                                                     Ucur, m, flags, cap));
+        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    (const uint8_t *)flags, m, w.tcnt));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+        uint32_t big32 = 0;
+        { const int rcw = read_words(&big32, w.total, 4, st); if (rcw) return rcw; }
+        const int64_t m_big = big32;
+        const size_t half = (((size_t)n / 2 + 1) & ~(size_t)1);
+        if ((size_t)m_big <= half) {
+            if (m_big > 0) {
+                // groups no tile owns: global sort of (group head, key2), then back to their list positions
+                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_flag_gather), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, m,
+                                                            (const uint32_t *)w.tcnt, rkB, Valt, scratchU));
+                rc = sort_pairs(rkB, Valt, rkB + half, Valt + half, m_big, 0, kb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn);
+                if (rc) return rc;
+                local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m_big;
+                PROF(KC_SCATTER, m_big, st, hipLaunchKernelGGL((k_scatter_back), dim3((unsigned)ceil_div(m_big, 256)), dim3(256), 0, st,
+                                                               (const uint64_t *)sr.keys, (const uint32_t *)sr.vals,
+                                                               (const uint32_t *)scratchU, m_big, rkA, Vcur));
+            }
+            out->keys = rkA; out->vals = Vcur; out->vnext = Valt;
+            local->locally_sorted += m - m_big;
+            if (m_big * 2 > m) *local_ok = false;           // mostly large groups: not worth another local pass
+            return SA_AMD_OK;
+        }
+    }
+    else {
+        int64_t gblocks = ceil_div(m, GK_THREADS);
+        if (gblocks > 8192) gblocks = 8192;
+        if (K.mode == KS_TEXT)
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_TEXT>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
+        else if (K.mode == KS_LOWKEY)
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_LOWKEY>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
+        else if (K.mode == KS_RANK)
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_RANK>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
+        else
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_SPARSE>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
+    }
+    rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, kb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn);
+    if (rc) return rc;
+    local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m;
+    out->keys = sr.keys; out->vals = sr.vals;
+    out->vnext = (sr.vals == Vcur) ? Valt : Vcur;
+    return SA_AMD_OK;
+}
+
+static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWork, int64_t work_bytes, hipStream_t st,
+                        sa_amd_stats *stats)
+{
+    const int64_t n = n32;
+    const Tuning tn = Tuning::from_env(N_SORT_VARIANTS, N_SORT32_VARIANTS);
+    sa_amd_stats local;
+    memset(&local, 0, sizeof(local));
+    if (n == 0) {
+        PROF(KC_MISC, 1, st, hipLaunchKernelGGL((k_set_u32), dim3(1), dim3(1), 0, st, dSA, 0u));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (stats) *stats = local;
+        return SA_AMD_OK;
+    }
+    Workspace w = carve(dWork, n);
+    if ((int64_t)w.bytes > work_bytes) return SA_AMD_EINVAL;
+    uint32_t *SA = dSA + 1;
+
+    // 1. sigma = 256 histogram -> symbol codes, bits per symbol, symbols per key
+    HIP_TRY(hipMemsetAsync(w.hist, 0, 256 * 4, st));
+    {
+        int64_t blocks = ceil_div(ceil_div(n, 16), BH_THREADS);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        PROF(KC_BYTE_HIST, n, st, hipLaunchKernelGGL((k_byte_hist), dim3((unsigned)blocks), dim3(BH_THREADS), 0, st, dT, n, w.hist));
+    }
+    uint32_t hist[256];
+    { const int rcw = read_words(hist, w.hist, sizeof(hist), st); if (rcw) return rcw; }
+    KeyParams P;
+    int sigma;
+    const int key_bits = make_key_params(hist, &P, &sigma, tn.key_bits_max);
+    local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
+
+    const int g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
+    const bool force_dense = tn.force_dense;
+    const bool text_ok = !force_dense && !tn.no_text_rounds;
+    bool local_ok = !tn.no_local_sort;
+
+    // 2. entropy probe: do the top 32 key bits already separate (almost) all suffixes?  Then the initial
+    //    sort only needs those 4 digits and a cheap round on the low bits finishes the few ties.
+    int top_shift = 0;
+    if (text_ok && local_ok && key_bits > 32 && !tn.no_top32) {
+        bool use = tn.force_top32;
+        if (!use && n >= ((int64_t)1 << 24)) {
+            const int64_t S = (int64_t)1 << 20;
+            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_keys), dim3((unsigned)ceil_div(S, GK_THREADS)), dim3(GK_THREADS), 0, st, dT, P, n, S,
+                                                    key_bits - 32, w.keysA));
+            // duplicates counted in a hash table (4 entries per sample, in the other key buffer) instead of sorting the sample
+            const uint32_t H = (uint32_t)S * 4u;
+            HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
+            HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
+            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
+                                                    (unsigned long long *)w.keysB, H - 1u, w.total));
+            uint32_t dups = 0;
+            { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
+            // c - 1 per value seen c times under-counts pairs only when values repeat often, which is the
+            // "do not" case anyway; expected number of other suffixes sharing the top bits with a given one:
+            const double q = 2.0 * (double)dups / ((double)S * (double)S);
+            use = (double)n * q < 0.5;
+        }
+        if (use) top_shift = key_bits - 32;
+    }
+    local.top32_first = top_shift ? 1 : 0;
+
+    // 3. packed keys, 4. initial sort: all key bits as (u64 key, u32 suffix) pairs, or only the top 32 bits as
+    //    (u32, u32) pairs in 12 Ki-element tiles -- two thirds of the bytes per pass and half the passes
+    SortResult sr;
+    sr.keys = w.keysA; sr.vals = w.valsA; sr.passes = 0;
+    const uint32_t *sorted32 = nullptr;               // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
+    int rc;
+    // value of pair i = i: not stored by k_build_keys, the first sort pass takes the index (saves 8 B / suffix)
+    const bool iota = n >= 2 && key_bits > 0;
+    uint32_t *vals0 = iota ? (uint32_t *)nullptr : w.valsA;
+    // alphabets of 2, 4 or 16 symbols: k_build_keys also writes the text as bit-packed codes, which every later random
+    // read of the text uses instead (a key becomes a bit field of two words; DNA shrinks to a quarter: cache-resident)
+    uint8_t *packed_out = nullptr;
+    if ((P.bits == 1 || P.bits == 2 || P.bits == 4) && n >= 64 && !tn.no_packed_text) {
+        packed_out = w.packed;
+        HIP_TRY(hipMemsetAsync(packed_out + (size_t)(n >> 3) * P.bits, 0, 64, st));     // the padding behind the last whole group
+    }
+    if (top_shift) {
+        uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
+        PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                      (uint64_t *)nullptr, vals0, k32a, top_shift, packed_out));
+        SortResult32 s32;
+        rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.spine, w.digit_tot, SA, st, &s32, tn, iota);
+        if (rc) return rc;
+        local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
+        sorted32 = s32.keys;
+        sr.vals = s32.vals; sr.passes = s32.passes;
+        sr.keys = (s32.keys == k32a) ? w.keysA : w.keysB;      // the 8n-byte buffer that now holds the sorted 32-bit keys
+    } else {
+        PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                      w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out));
+        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr, tn, iota);
+        if (rc) return rc;
+        local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
+    }
+    P.packed = packed_out;
+    if (sr.vals != SA) {   // n == 1: no pass ran, the values are still in the input buffer
+        PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_copy_u32), dim3(1), dim3(256), 0, st, sr.vals, SA, n));
+    }
+
+    // 4. group heads of the initial order; how many suffixes are still tied with a neighbour
+    uint32_t *Ucur = w.U0, *Unext = w.U1, *Gcur = w.G0, *Gnext = w.G1;
+    uint32_t *Vcur = w.valsA;
+    int64_t tiles = ceil_div(n, RR_TILE);
+    uint32_t m32 = 0;
+    int64_t m = 0;
+    uint64_t *rkA = w.keysA, *rkB = w.keysB;          // key buffers of the refinement rounds
+    uint64_t *sorted0 = sr.keys;                      // the initial keys in SA order (kept for the rank look-ups)
+    bool lists_ready = false;                         // (Ucur, Gcur, Vcur) already hold the tied suffixes
+    int64_t depth = P.k;                               // symbols the current order is sorted by
+    // Text-keyed rounds pack their symbols as bit fields of ceil(log2 sigma) bits whatever the alphabet: a secondary key only
+    // has to preserve the order inside one round, and the base-sigma form costs a 64-bit multiply per symbol in kernels
+    // that are instruction-bound (k_group_sort: 26 ps per suffix however small the text).  English-like sigma = 56: six
+    // symbols in 36 bits either way.
+    KeyParams Ptext = P;
+    if (P.bits == 0) Ptext.bits = bit_length(P.sigma - 1);
+    int s_sym = 0, tkb = 0;                            // symbols per round, bits of their packed key
+    {
+        const int room = 64 - g_bits;                   // bits left below the group head
+        s_sym = room / Ptext.bits;
+        if (s_sym > 64) s_sym = 64;
+        tkb = s_sym * Ptext.bits;
+    }
+    bool finished32 = false, fused64 = false;
+#ifdef SA_AMD_DIAG
+    const bool timing_only = tn.timing_only_initial_sort;       // diag library only: stop after the initial sort (array NOT finished)
+#else
+    constexpr bool timing_only = false;
+#endif
+    if (top_shift && local_ok && !tn.no_fused_finish && !timing_only) {
+        // fast finish of the 32-bit first stage: one pass orders every small group by its low key bits in place
+        // (k_finish_sorted); only if some group is too large for it does the general path below run instead
+        const int cap = tn.group_cap;
+        uint32_t *surv_bits = w.surv_bits, *surv_head = w.isa;  // (the ISA is not in use before the doubling rounds)
+        HIP_TRY(hipMemsetAsync(surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
+        HIP_TRY(hipMemsetAsync(w.tcnt, 0, (size_t)tiles * 4, st));
+        HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
+        HIP_TRY(hipMemsetAsync(w.total, 0, 16, st));
+        KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
+        PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint32_t, KS_LOWKEY, false>), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS),
+                                                 0, st, sorted32, SA, dT, P, n, K, cap, surv_bits, surv_head, w.tcnt, w.total, (uint32_t *)nullptr,
+                                                 (uint32_t *)nullptr, (uint32_t *)nullptr));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+        uint32_t cnt3[3] = { 0, 0, 0 };                       // still tied on 64 bits, members of groups nobody owned, tied on 32 bits
+        { const int rcw = read_words(cnt3, w.total, 12, st); if (rcw) return rcw; }
+        if (cnt3[1] == 0) {
+            finished32 = true;
+            m = cnt3[0];
+            local.locally_sorted += cnt3[2];
+            local.unresolved_after_initial = m;
+            if (m > 0) {
+                PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_surv_compact), dim3((unsigned)tiles), dim3(256), 0, st, (const uint32_t *)surv_bits,
+                                                            (const uint32_t *)surv_head, (const uint32_t *)SA, n, (const uint32_t *)w.tcnt,
+                                                            (const uint32_t *)w.total, Ucur, Gcur, Vcur));
+                rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+                rkB = w.keysC;
+                lists_ready = true;
+            }
+        }
+    }
+    // (SA_AMD_SPARSE_DIV moves the text-round / doubling boundary for the tests: then the general route decides, as before)
+    // Opt-in (SA_AMD_FUSED64=1): measured on C3 the one-pass round costs 8.2 ms against the 4.3 ms of k_group_sort on the tied
+    // list -- with 68 % of the slots tied the work list is six entries per thread -- and the whole build 31.0 instead of 28.8 ms.
+    if (!top_shift && text_ok && local_ok && s_sym > 0 && tn.fused64 && !tn.no_fused_finish && !tn.sparse_div_set && !timing_only) {
+        // the first text-keyed round straight from the sorted keys (k_finish_sorted): groups of up to `cap` members are
+        // ordered in place by the next s_sym symbols, their still-tied members recorded by slot; the members of larger
+        // groups are listed (k_todo_compact) and take the general route (refine_list + re-rank), joining the same record;
+        // k_surv_compact then lists everything that is still tied, in slot order, for the second round
+        const int cap = tn.group_cap;
+        const int64_t ft_tiles = ceil_div(n, FT_TILE);
+        uint32_t *surv_head = w.isa;
+        HIP_TRY(hipMemsetAsync(w.surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
+        HIP_TRY(hipMemsetAsync(w.todo_bits, 0, ((size_t)n + 31) / 32 * 4, st));
+        HIP_TRY(hipMemsetAsync(w.ft_cnt, 0, (size_t)(ft_tiles + 1) * 4, st));
+        HIP_TRY(hipMemsetAsync(w.ft_head, 0, (size_t)(ft_tiles + 1) * 4, st));
+        HIP_TRY(hipMemsetAsync(w.surv_cnt, 0, (size_t)tiles * 4, st));
+        HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
+        HIP_TRY(hipMemsetAsync(w.total, 0, 32, st));
+        KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
+        PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint64_t, KS_TEXT, true>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
+                                                 (const uint64_t *)sorted0, SA, dT, Ptext, n, K, cap, w.surv_bits, surv_head, w.surv_cnt, w.total,
+                                                 w.todo_bits, w.ft_cnt, w.ft_head));
+        PROF(KC_RR_SCAN, ft_tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, ft_tiles, w.total + 3));
+        uint32_t cnt4[4] = { 0, 0, 0, 0 };                    // [2] tied after the initial sort, [3] members left to the general route
+        { const int rcw = read_words(cnt4, w.total, 16, st); if (rcw) return rcw; }
+        local.unresolved_after_initial = cnt4[2];
+        const int64_t m_todo = cnt4[3];
+        local.locally_sorted += (int64_t)cnt4[2] - m_todo;
+        rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+        rkB = w.keysC;
+        if (m_todo > 0) {
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_todo_compact<uint64_t>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
+                                                        (const uint64_t *)sorted0, (const uint32_t *)SA, n, (const uint32_t *)w.todo_bits,
+                                                        (const uint32_t *)w.ft_cnt, (const uint32_t *)w.ft_head, (const uint32_t *)(w.total + 3),
+                                                        Ucur, Gcur, Vcur));
+            uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+            Refined rf;
+            bool big_local = true;                             // (large groups: the global sort does the work either way)
+            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m_todo, n, dT, Ptext, K, g_bits, &big_local, w, st, &local, &rf, tn);
+            if (rc) return rc;
+            const int64_t tt = ceil_div(m_todo, RR_TILE);
+            PROF(KC_RR_COUNT, m_todo, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st, rf.keys,
+                                                        (const uint32_t *)Ucur, m_todo, w.ft_cnt, w.ft_head, 0));
+            PROF(KC_RR_SCAN, tt, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, tt, w.total + 4));
+            PROF(KC_RR_APPLY, m_todo, st, hipLaunchKernelGGL((k_rr_apply<false, true, 4>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st,
+                                                        rf.keys, rf.vals, (const uint32_t *)Ucur, m_todo, (const uint32_t *)w.ft_cnt,
+                                                        (const uint32_t *)w.ft_head, SA, surv_head, Unext, Gnext, rf.vnext, (uint32_t)n,
+                                                        w.surv_bits, 0, (uint64_t *)nullptr, w.surv_cnt, (const uint32_t *)(w.total + 4), 0));
+        }
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.surv_cnt, w.thead, tiles, w.total));
+        { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+        m = m32;
+        Ucur = w.U0; Gcur = w.G0; Vcur = w.valsA; Unext = w.U1; Gnext = w.G1;
+        if (m > 0)
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_surv_compact), dim3((unsigned)tiles), dim3(256), 0, st, (const uint32_t *)w.surv_bits,
+                                                        (const uint32_t *)surv_head, (const uint32_t *)SA, n, (const uint32_t *)w.surv_cnt,
+                                                        (const uint32_t *)w.total, Ucur, Gcur, Vcur));
+        fused64 = true;
+        lists_ready = true;
+        depth += s_sym;
+        local.text_rounds++;
+        local.rounds++;
+    }
+    if (!finished32 && !fused64) {
+    if (top_shift)
+        PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sorted32,
+                                                    (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0));
+    else
+        PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)sr.keys,
+                                                    (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0));
+    PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+    { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+    m = m32;
+    local.unresolved_after_initial = m;
+    if (timing_only) m = 0;   // diag library: ablation kernels produce wrong orders; stop here
+    }
+    if (!finished32 && top_shift && m > 0) {
+        // finish the initial sort: the suffixes tied on the top 32 bits are ordered by their low key bits
+        rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+        rkB = w.keysC;
+        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    sorted32, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
+                                                    (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
+                                                    w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+        uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+        Refined rf;
+        KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
+        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn);
+        if (rc) return rc;
+        tiles = ceil_div(m, RR_TILE);
+        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rf.keys,
+                                                    (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    rf.keys, rf.vals, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
+                                                    (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, rf.vnext, (uint32_t)n,
+                                                    (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                                    (const uint32_t *)w.total, 0));
+        { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+        m = m32;
+        uint32_t *t;
+        t = Ucur; Ucur = Unext; Unext = t;
+        t = Gcur; Gcur = Gnext; Gnext = t;
+        Vcur = rf.vnext;
+        lists_ready = true;
+        local.unresolved_after_initial = m;           // now: tied on the whole 64-bit key, as after a full sort
+    }
+    // 5. refinement of the tied suffixes.  Three regimes:
+    //   text rounds  while more than n / SPARSE_DIV suffixes are tied: secondary key = the next symbols of
+    //                the text itself (no rank array needed yet), depth grows by s symbols per round;
+    //   sparse       few tied suffixes: prefix doubling, ranks looked up without an ISA (sparse_key2);
+    //   dense        prefix doubling with a full ISA (repetitive texts, or forced for A/B measurements).
+    const int key2_bits = bit_length((uint64_t)(2 * n));
+    const int64_t sparse_div = tn.sparse_div;      // (SA_AMD_SPARSE_DIV moves the boundary for tests / A-B)
+    const int64_t sparse_limit = n / sparse_div;
+    bool sparse = false;
+    const bool dense_first = m > 0 && !lists_ready && (force_dense || (!text_ok && m > sparse_limit));
+    if (m > 0 && dense_first) {
+        // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
+        if (binned(n, n, tn)) {
+            uint64_t *pk = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total, 0));
+            rc = scatter_binned(pk, w.U1, sr.keys, w.G1, n, n, w, st, &local, tn);
+            if (rc) return rc;
+        } else {
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0,
+                                                        (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+        }
+    } else if (m > 0) {
+        // compaction only; the sorted initial keys stay intact for the rank look-ups
+        HIP_TRY(hipMemsetAsync(w.has_isa, 0, ((size_t)n + 31) / 32 * 4, st));
+        if (!lists_ready) {
+            rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+            rkB = w.keysC;
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        (const uint64_t *)sorted0, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
+                                                        (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
+                                                        w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+        }
+        // ---- text-keyed rounds ----
+        bool progressing = true;     // a text round that resolves little (runs, long repeats) is the last one
+
+        while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < MAX_TEXT_ROUNDS && progressing) {
+            const int64_t m_before = m;
+            uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+            Refined rf;
+            KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
+            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, Ptext, K, g_bits, &local_ok, w, st, &local, &rf, tn);
+            if (rc) return rc;
+            const uint64_t *keysS = rf.keys;                  // (group, text key) pairs ordered inside every group
+            const uint32_t *valsS = rf.vals;
+            uint32_t *Vnext = rf.vnext;
+            tiles = ceil_div(m, RR_TILE);
+            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS,
+                                                        (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0));
+            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        keysS, valsS, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
+                                                        (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                        (uint32_t)n, (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                                        (const uint32_t *)w.total, 0));
+            { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+            m = m32;
+            uint32_t *t;
+            t = Ucur; Ucur = Unext; Unext = t;
+            t = Gcur; Gcur = Gnext; Gnext = t;
+            Vcur = Vnext;
+            depth += s_sym;
+            local.text_rounds++;
+            local.rounds++;
+            progressing = m * 4 <= m_before * 3;
+        }
+        if (m > sparse_limit) {
+            // still many ties (repetitive text): build the ISA of the current order and double densely
+            int64_t blocks = ceil_div(n, 256);
+            if (blocks > 16384) blocks = 16384;
+            PROF(KC_SCATTER, n, st, hipLaunchKernelGGL((k_isa_from_sa), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)SA, w.isa, n));
+            blocks = ceil_div(m, 256);
+            if (blocks > 16384) blocks = 16384;
+            PROF(KC_SCATTER, m, st, hipLaunchKernelGGL((k_isa_tied), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)Vcur,
+                                                       (const uint32_t *)Gcur, w.isa, m, n));
+        } else {
+            sparse = m > 0;
+        }
+    }
+    local.sparse_mode = sparse ? 1 : 0;
+
+    // prefix doubling on what is still tied; `depth` symbols are sorted, so the first offset is `depth`
+    const int64_t depth_text = depth;
+    int64_t h = depth;
+    while (m > 0) {
+        if (local.rounds >= 48) return SA_AMD_EINTERNAL;
+        uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+        // the same refinement machinery as the text rounds, keyed by ranks -- small groups (a long repeat gives millions of
+        // pairs) are ordered in LDS, only large groups go through the global sort.  Dense: ranks from the ISA; sparse:
+        // looked up without one (sparse_key2)
+        KeySrc K = KeySrc();
+        K.mode = sparse ? KS_SPARSE : KS_RANK; K.h = h; K.kb = key2_bits; K.isa = w.isa;
+        K.has_isa = w.has_isa; K.sorted_keys = sorted0; K.sorted_top32 = sorted32; K.sa = SA; K.depth = depth_text; K.top_shift = top_shift;
+        Refined rf;
+        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn);
+        if (rc) return rc;
+        const uint64_t *keysS = rf.keys; const uint32_t *valsS = rf.vals; uint32_t *Vnext = rf.vnext;
+        tiles = ceil_div(m, RR_TILE);
+        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m, w.tcnt,
+                           w.thead, 0));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+        if (sparse) {
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                        (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+        } else if (binned(n, m, tn)) {
+            // Gcur has been consumed by the gather, the other key buffer by nothing: they take the pairs
+            uint64_t *pk = (keysS == rkA) ? rkB : rkA;
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total, 0));
+            rc = scatter_binned(pk, Gcur, (uint64_t *)keysS, (uint32_t *)valsS, m, n, w, st, &local, tn);
+            if (rc) return rc;
+        } else {
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, (uint64_t *)nullptr,
+                                                        (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+        }
+        { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+        m = m32;
+        uint32_t *t;
+        t = Ucur; Ucur = Unext; Unext = t;
+        t = Gcur; Gcur = Gnext; Gnext = t;
+        Vcur = Vnext;
+        h *= 2;
+        local.rounds++;
+    }
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);   // reference src/saca.rs:13
+    LAUNCH_CHECK(st);
+    HIP_TRY(hipStreamSynchronize(st));
+    g_prof.resolve();
+    g_last_stats = local;
+    if (stats) *stats = local;
+    return SA_AMD_OK;
+}
+
+}  // namespace sa

@@ -1,0 +1,87 @@
+// host/tuning.hpp -- every environment knob of the engine, parsed in ONE place, once per build.
+//
+// All knobs are ROUTE switches: they choose between kernels / regimes that produce the same (unique) suffix array, and
+// every numeric one is clamped to the range the kernels accept, so no value of any SA_AMD_* variable can change a
+// result (tests/test_gpu_parity.py::test_any_environment_is_bit_exact).  Kernels that produce wrong orders on purpose
+// (timing ablations) and the truncated "initial sort only" build exist only in libsuffix_array_amd_diag.so
+// (-DSA_AMD_DIAG), never in the product library.
+#pragma once
+#include <cstdlib>
+#include <cstdint>
+
+namespace sa {
+
+constexpr int64_t SPARSE_DIV_DEFAULT = 64;  // sparse refinement when at most n / 64 suffixes are tied after the initial sort
+constexpr int GROUP_CAP_MAX = 1024;         // == GS_CAP (kernels/refine.hpp), checked there
+
+inline bool env_flag(const char *name)
+{
+    const char *e = getenv(name);
+    return e && *e && !(e[0] == '0' && e[1] == 0);
+}
+
+// integer knob: unparsable text = default; clamped to [lo, hi]
+inline int64_t env_int(const char *name, int64_t def, int64_t lo, int64_t hi)
+{
+    const char *e = getenv(name);
+    if (!e || !*e) return def;
+    char *end = nullptr;
+    const long long v = strtoll(e, &end, 10);
+    if (end == e) return def;
+    return v < lo ? lo : (v > hi ? hi : (int64_t)v);
+}
+
+struct Tuning {
+    int sort_variant = 0;            // SA_AMD_SORT_VARIANT: tile-scatter kernel shape, 64-bit keys (all shapes give the same order)
+    int sort32_variant = 0;          // SA_AMD_SORT32_VARIANT: the same for the 32-bit first stage
+    int key_bits_max = 64;           // SA_AMD_KEY_BITS: 16..64 bits of packed key in the initial sort
+    int group_cap = GROUP_CAP_MAX;   // SA_AMD_GROUP_CAP: largest group ordered in LDS, 2..1024
+    int64_t sparse_div = SPARSE_DIV_DEFAULT;   // SA_AMD_SPARSE_DIV
+    bool sparse_div_set = false;
+    bool force_dense = false;        // SA_AMD_FORCE_DENSE
+    bool no_text_rounds = false;     // SA_AMD_NO_TEXT_ROUNDS
+    bool no_local_sort = false;      // SA_AMD_NO_LOCAL_SORT
+    bool no_top32 = false;           // SA_AMD_NO_TOP32
+    bool force_top32 = false;        // SA_AMD_FORCE_TOP32
+    bool no_fused_finish = false;    // SA_AMD_NO_FUSED_FINISH
+    bool fused64 = false;            // SA_AMD_FUSED64
+    bool no_packed_text = false;     // SA_AMD_NO_PACKED_TEXT
+    bool no_binned_isa = false;      // SA_AMD_NO_BINNED_ISA
+    bool binned_isa_always = false;  // SA_AMD_BINNED_ISA_ALWAYS
+    bool no_fused_hist = false;      // SA_AMD_NO_FUSED_HIST: every radix pass runs its own histogram kernel
+    bool no_run_skip = false;        // SA_AMD_NO_RUN_SKIP
+#ifdef SA_AMD_DIAG
+    bool timing_only_initial_sort = false;     // SA_AMD_TIMING_ONLY_INITIAL_SORT (diag library only: the array is NOT finished)
+#endif
+
+    static Tuning from_env(int n_sort_variants, int n_sort32_variants)
+    {
+        Tuning t;
+        t.sort_variant = (int)env_int("SA_AMD_SORT_VARIANT", 0, 0, 1 << 20);
+        if (t.sort_variant >= n_sort_variants) t.sort_variant = 0;
+        t.sort32_variant = (int)env_int("SA_AMD_SORT32_VARIANT", 0, 0, 1 << 20);
+        if (t.sort32_variant >= n_sort32_variants) t.sort32_variant = 0;
+        t.key_bits_max = (int)env_int("SA_AMD_KEY_BITS", 64, 16, 64);
+        t.group_cap = (int)env_int("SA_AMD_GROUP_CAP", GROUP_CAP_MAX, 2, GROUP_CAP_MAX);
+        t.sparse_div_set = getenv("SA_AMD_SPARSE_DIV") != nullptr;
+        t.sparse_div = env_int("SA_AMD_SPARSE_DIV", SPARSE_DIV_DEFAULT, 1, (int64_t)1 << 40);
+        t.force_dense = env_flag("SA_AMD_FORCE_DENSE");
+        t.no_text_rounds = env_flag("SA_AMD_NO_TEXT_ROUNDS");
+        t.no_local_sort = env_flag("SA_AMD_NO_LOCAL_SORT");
+        t.no_top32 = env_flag("SA_AMD_NO_TOP32");
+        t.force_top32 = env_flag("SA_AMD_FORCE_TOP32");
+        t.no_fused_finish = env_flag("SA_AMD_NO_FUSED_FINISH");
+        t.fused64 = env_flag("SA_AMD_FUSED64");
+        t.no_packed_text = env_flag("SA_AMD_NO_PACKED_TEXT");
+        t.no_binned_isa = env_flag("SA_AMD_NO_BINNED_ISA");
+        t.binned_isa_always = env_flag("SA_AMD_BINNED_ISA_ALWAYS");
+        t.no_fused_hist = env_flag("SA_AMD_NO_FUSED_HIST");
+        t.no_run_skip = env_flag("SA_AMD_NO_RUN_SKIP");
+#ifdef SA_AMD_DIAG
+        t.timing_only_initial_sort = env_flag("SA_AMD_TIMING_ONLY_INITIAL_SORT");
+#endif
+        return t;
+    }
+};
+
+}  // namespace sa

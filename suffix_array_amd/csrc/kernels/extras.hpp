@@ -1,10 +1,10 @@
-// sa_extras.hpp -- the "next" rows of SURVEY.md section 8f that sit directly on either side of the
+// kernels/extras.hpp -- the "next" rows of SURVEY.md section 8f that sit directly on either side of the
 // construction path, as HIP kernels working on the device-resident text and suffix array:
 //   k_bucket_table     reference src/sa.rs:89-119 (enable_buckets): right edge of every 1-/2-byte
 //                      prefix bucket of the SA, 65 793 entries
 //   k_ci_*             reference src/sa.rs:72-84 (check_integrity) in its linear-time form
 #pragma once
-#include "sa_kernels.hpp"
+#include "common.hpp"
 
 namespace sa {
 
@@ -115,22 +115,33 @@ constexpr int SEARCH_THREADS = 256;
 __global__ __launch_bounds__(SEARCH_THREADS) void k_search_batch(
     const uint8_t *__restrict__ T, const uint32_t *__restrict__ SA, int64_t n, const uint8_t *__restrict__ pat_data,
     const int64_t *__restrict__ pat_off, int32_t count, uint8_t *__restrict__ contains, uint32_t *__restrict__ range_lo,
-    uint32_t *__restrict__ range_hi, uint32_t *__restrict__ lcp_start, uint32_t *__restrict__ lcp_len)
+    uint32_t *__restrict__ range_hi, uint32_t *__restrict__ lcp_start, uint32_t *__restrict__ lcp_len,
+    const uint32_t *__restrict__ bkt)          // bucket table (enable_buckets) or nullptr
 {
     const int q = (int)((blockIdx.x * (int64_t)SEARCH_THREADS + threadIdx.x) / WAVE);
     if (q >= count) return;                                   // whole waves leave together
     const uint8_t *pat = pat_data + pat_off[q];
     const int64_t plen = pat_off[q + 1] - pat_off[q];
     const int64_t len = n + 1;                                // sa.len()
-    // search_all, first loop (reference src/sa.rs:182-190): first i with !(pat > s[sa[i]..])
+    // get_bucket (reference src/sa.rs:123-144): with a bucket table the binary searches start from the SA range of the
+    // pattern's first one or two bytes.  Every suffix below that range is smaller than the pattern and every one above
+    // it larger, so the insertion point and the match range are the same as over the whole array.
     int64_t lo = 0, hi = len;
+    if (bkt && plen > 1) {
+        const int idx = (int)pat[0] * 257 + (int)pat[1] + 2;
+        lo = bkt[idx - 1]; hi = bkt[idx];
+    } else if (bkt && plen == 1) {
+        lo = bkt[(int)pat[0] * 257]; hi = bkt[(int)pat[0] * 257 + 257];
+    }
+    const int64_t bucket_hi = hi;
+    // search_all, first loop (reference src/sa.rs:182-190): first i with !(pat > s[sa[i]..])
     while (lo < hi) {
         const int64_t m = lo + (hi - lo) / 2;
         if (wave_compare(T, n, (int64_t)SA[m], pat, plen).ord < 0) lo = m + 1; else hi = m;
     }
     const int64_t i = lo;
     // second loop (src/sa.rs:192-201): first j >= i whose suffix does not start with pat
-    int64_t lo2 = i, hi2 = len;
+    int64_t lo2 = i, hi2 = bucket_hi;
     while (lo2 < hi2) {
         const int64_t m = lo2 + (hi2 - lo2) / 2;
         if ((int64_t)wave_compare(T, n, (int64_t)SA[m], pat, plen).lcp == plen) lo2 = m + 1; else hi2 = m;

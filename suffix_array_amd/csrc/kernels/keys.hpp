@@ -1,0 +1,265 @@
+// kernels/keys.hpp -- which byte values occur, packed-symbol keys of the suffixes, text-key reads, entropy probe.
+// Part of the MI355X-native suffix-array engine (gfx950 / CDNA4, wave64); see DESIGN.md section 3.
+#pragma once
+#include "common.hpp"
+
+namespace sa {
+
+// ------------------------------------------------------------------------------------------
+// k_byte_hist: WHICH of the 256 byte values occur (hist[c] != 0 <=> c occurs).  The symbol codes
+// and the key geometry only need the set of used values, not their counts, so instead of LDS
+// atomics (which serialise on a 4-symbol text: 0.9 TB/s on DNA) every byte is a plain LDS store
+// of 1 to its flag word -- same-address stores of a wave need no ordering.
+// Algorithmic traffic: 1 B read per input byte.
+// ------------------------------------------------------------------------------------------
+constexpr int BH_THREADS = 256;
+
+__global__ __launch_bounds__(BH_THREADS) void k_byte_hist(const uint8_t *__restrict__ T, int64_t n,
+                                                           uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    // 16-byte aligned body, scalar head and tail
+    const uintptr_t addr = (uintptr_t)T;
+    int64_t head = (int64_t)((16 - (addr & 15)) & 15);
+    if (head > n) head = n;
+    const int64_t nvec = (n - head) / 16;
+    const uint4 *V = (const uint4 *)(T + head);
+    const int64_t gtid = (int64_t)blockIdx.x * BH_THREADS + threadIdx.x;
+    const int64_t gstride = (int64_t)gridDim.x * BH_THREADS;
+    for (int64_t i = gtid; i < nvec; i += gstride) {
+        uint4 q = V[i];
+        uint32_t w4[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) h[(w4[a] >> (8 * b)) & 255u] = 1u;
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = threadIdx.x; i < head; i += BH_THREADS) h[T[i]] = 1u;
+        for (int64_t i = head + nvec * 16 + threadIdx.x; i < n; i += BH_THREADS) h[T[i]] = 1u;
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) hist[threadIdx.x] = 1u;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_build_keys: key[i] = the first k symbol codes of suffix i, `bits` bits each, most
+// significant symbol first, zero codes past the end of the text; val[i] = i.
+// The text tile (+ k bytes of halo) is read once, mapped to codes and staged in LDS; each
+// thread builds one key from k LDS bytes and rolls it forward for its next 7 positions.
+// Algorithmic traffic: 1 B read + 12 B written per suffix.
+// ------------------------------------------------------------------------------------------
+constexpr int KB_THREADS = 256;
+constexpr int KB_ITEMS = 8;
+constexpr int KB_TILE = KB_THREADS * KB_ITEMS;   // 2048 suffixes per workgroup
+constexpr int KB_HALO = 64 + 8;                  // k <= 64 symbols, +8 so the halo loads stay 8-byte wide
+
+struct KeyParams {
+    uint8_t code[256];
+    int32_t bits;      // > 0: sigma is a power of two, symbols are `bits`-wide fields (shift/or path)
+    int32_t k;         // symbols per key
+    uint64_t mask;     // shift path: the k * bits low bits
+    uint64_t sigma;    // multiply path (bits == 0): key = sum code_i * sigma^(k-1-i), an order-preserving
+    uint64_t top;      //   base-sigma number; top = sigma^(k-1).  sigma = 56 packs 11 symbols, not 10.
+    const uint8_t *packed;   // bits in {1, 2, 4}: the text as bit-packed codes, first symbol in the top bits of byte 0
+                             // (written by k_build_keys; 4x smaller than DNA bytes, so the rounds' random reads stay in
+                             // the 256 MB Infinity Cache), zero-padded by >= 24 bytes; nullptr: read the text itself
+};
+
+// TOP32: only the top 32 bits of every key are stored (keys32), for the two-stage initial sort
+template <bool TOP32>
+__global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__restrict__ T, int64_t n,
+                                                            KeyParams P, uint64_t *__restrict__ keys,
+                                                            uint32_t *__restrict__ vals, uint32_t *__restrict__ keys32,
+                                                            int top_shift, uint8_t *__restrict__ packed_out)
+{
+    __shared__ uint8_t lcode[256];
+    __shared__ __attribute__((aligned(16))) uint8_t c[KB_TILE + KB_HALO];
+    const int tid = threadIdx.x;
+    lcode[tid] = P.code[tid];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * KB_TILE;
+    // stage KB_TILE + KB_HALO codes, 8 bytes per thread per step
+    for (int o = tid * 8; o < KB_TILE + KB_HALO; o += KB_THREADS * 8) {
+        const int64_t p = base + o;
+        uint8_t b[8];
+        if (p + 8 <= n && (((uintptr_t)(T + p)) & 7) == 0) {
+            uint2 q = *(const uint2 *)(T + p);
+            uint32_t w2[2] = { q.x, q.y };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = lcode[(w2[j >> 2] >> (8 * (j & 3))) & 255u];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = (p + j < n) ? lcode[T[p + j]] : (uint8_t)0;
+        }
+        uint2 o2;
+        o2.x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        o2.y = (uint32_t)b[4] | ((uint32_t)b[5] << 8) | ((uint32_t)b[6] << 16) | ((uint32_t)b[7] << 24);
+        *(uint2 *)(c + o) = o2;
+    }
+    __syncthreads();
+    const int p0 = tid * KB_ITEMS;
+    const int k = P.k, bits = P.bits;
+    uint64_t kk[KB_ITEMS];
+    if (bits > 0) {
+        const uint64_t mask = P.mask;
+        uint64_t key = 0;
+        for (int j = 0; j < k; ++j) key = (key << bits) | (uint64_t)c[p0 + j];
+        kk[0] = key;
+#pragma unroll
+        for (int r = 1; r < KB_ITEMS; ++r) {
+            key = ((key << bits) | (uint64_t)c[p0 + k - 1 + r]) & mask;
+            kk[r] = key;
+        }
+    } else {
+        const uint64_t sigma = P.sigma, top = P.top;
+        uint64_t key = 0;
+        for (int j = 0; j < k; ++j) key = key * sigma + (uint64_t)c[p0 + j];
+        kk[0] = key;
+#pragma unroll
+        for (int r = 1; r < KB_ITEMS; ++r) {
+            key = (key - (uint64_t)c[p0 + r - 1] * top) * sigma + (uint64_t)c[p0 + k - 1 + r];
+            kk[r] = key;
+        }
+    }
+    const int64_t g0 = base + p0;
+    if (packed_out && g0 < n) {
+        // this thread's 8 codes -> `bits` bytes of the packed text (codes past the end are 0)
+        uint32_t val = 0;
+#pragma unroll
+        for (int r = 0; r < KB_ITEMS; ++r) val = (val << bits) | (uint32_t)c[p0 + r];
+        uint8_t *po = packed_out + (g0 >> 3) * bits;
+        for (int b = 0; b < bits; ++b) po[b] = (uint8_t)(val >> (8 * (bits - 1 - b)));
+    }
+    if (g0 + KB_ITEMS <= n) {
+        if (TOP32) {
+            uint4 *ko = (uint4 *)(keys32 + g0);
+            ko[0] = make_uint4((uint32_t)(kk[0] >> top_shift), (uint32_t)(kk[1] >> top_shift), (uint32_t)(kk[2] >> top_shift),
+                               (uint32_t)(kk[3] >> top_shift));
+            ko[1] = make_uint4((uint32_t)(kk[4] >> top_shift), (uint32_t)(kk[5] >> top_shift), (uint32_t)(kk[6] >> top_shift),
+                               (uint32_t)(kk[7] >> top_shift));
+        } else {
+            ulonglong2 *ko = (ulonglong2 *)(keys + g0);
+#pragma unroll
+            for (int r = 0; r < KB_ITEMS / 2; ++r) ko[r] = make_ulonglong2(kk[2 * r], kk[2 * r + 1]);
+        }
+        if (vals) {                                           // nullptr: the first sort pass takes the index as the value
+            uint4 *vo = (uint4 *)(vals + g0);
+            const uint32_t v0 = (uint32_t)g0;
+            vo[0] = make_uint4(v0, v0 + 1, v0 + 2, v0 + 3);
+            vo[1] = make_uint4(v0 + 4, v0 + 5, v0 + 6, v0 + 7);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < KB_ITEMS; ++r)
+            if (g0 + r < n) {
+                if (TOP32) keys32[g0 + r] = (uint32_t)(kk[r] >> top_shift); else keys[g0 + r] = kk[r];
+                if (vals) vals[g0 + r] = (uint32_t)(g0 + r);
+            }
+    }
+}
+
+constexpr int GK_THREADS = 256;
+
+// symbol code of text position pos (0 past the end: the same padding the initial keys use)
+__device__ __forceinline__ uint64_t code_at(const uint8_t *__restrict__ T, const uint8_t *lcode, int64_t n, int64_t pos)
+{
+    return pos < n ? (uint64_t)lcode[T[pos]] : 0ull;
+}
+
+// packed key of the `nsym` symbols T[p .. p + nsym) (zero codes past the end), most significant first.
+// Away from the end of an 8-byte aligned text the bytes come from aligned 8-byte loads, not byte loads.
+__device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ T, const uint8_t *lcode, const KeyParams &P, int64_t n,
+                                             int64_t p, int nsym, bool aligned8)
+{
+    uint64_t tk = 0;
+    if (P.packed) {
+        // bit-packed codes: the key is a bit field of the packed text (two aligned big-endian 64-bit words)
+        const int64_t bo = p * P.bits;
+        const int nb = nsym * P.bits;                                    // <= 64
+        if (nb == 0 || p >= n) return 0;
+        const uint64_t *W = (const uint64_t *)P.packed + (bo >> 6);
+        const uint64_t w0 = __builtin_bswap64(W[0]), w1 = __builtin_bswap64(W[1]);
+        const int sh = (int)(bo & 63);
+        const uint64_t val = sh ? ((w0 << sh) | (w1 >> (64 - sh))) : w0;
+        return val >> (64 - nb);
+    }
+    if (aligned8 && p + nsym + 16 <= n) {
+        const uint64_t *W = (const uint64_t *)(T + (p & ~(int64_t)7));
+        const int sh = (int)(p & 7) * 8;
+        uint64_t w0 = W[0];
+        for (int done = 0, wi = 1; done < nsym; done += 8, ++wi) {
+            const uint64_t w1 = W[wi];
+            const uint64_t bytes = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+            const int cnt = nsym - done < 8 ? nsym - done : 8;
+            for (int i = 0; i < cnt; ++i) {
+                const uint64_t cs = (uint64_t)lcode[(bytes >> (8 * i)) & 255u];
+                tk = P.bits > 0 ? ((tk << P.bits) | cs) : (tk * P.sigma + cs);
+            }
+            w0 = w1;
+        }
+    } else {
+        for (int i = 0; i < nsym; ++i) {
+            const uint64_t cs = code_at(T, lcode, n, p + i);
+            tk = P.bits > 0 ? ((tk << P.bits) | cs) : (tk * P.sigma + cs);
+        }
+    }
+    return tk;
+}
+
+// ---- entropy probe + two-stage initial sort ---------------------------------------------------
+// When the top 32 bits of the packed key already separate almost all suffixes (random bytes, DNA),
+// the initial sort only needs those 4 digits; the few ties are finished by a refinement round on the
+// low key bits (k_group_sort).  Whether that holds is measured, not assumed: the keys of
+// SAMPLE pseudo-random suffixes are sorted and their duplicates counted (a word-structured text looks
+// harmless under an iid model but is not).
+__global__ __launch_bounds__(GK_THREADS) void k_sample_keys(const uint8_t *__restrict__ T, KeyParams P, int64_t n, int64_t samples,
+                                                             int top_shift, uint64_t *__restrict__ out)
+{
+    __shared__ uint8_t lcode[256];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x;
+    if (i >= samples) return;
+    const uint64_t r = ((uint64_t)i + 1u) * 0x9E3779B97F4A7C15ull;
+    const int64_t p = (int64_t)((r >> 11) % (uint64_t)n);
+    const uint64_t kq = text_key(T, lcode, P, n, p, P.k, (((uintptr_t)T) & 7) == 0);
+    out[i] = ((kq >> top_shift) << 32) | (uint64_t)(uint32_t)p;      // position in the low half: equal positions are not collisions
+}
+
+// Duplicates of the top 32 key bits among the samples, without sorting them: every sample ((top bits << 32) | position)
+// is inserted into an open-addressing hash table of 64-bit entries (all ones = empty).  Meeting an entry with the
+// same top bits and another position counts one duplicate (a value seen c times counts c - 1, as adjacent equal
+// neighbours of a sorted sample would); the same position drawn twice is not a collision.
+__global__ __launch_bounds__(256) void k_count_sample_dups(const uint64_t *__restrict__ samples, int64_t count, unsigned long long *table,
+                                                            uint32_t table_mask, uint32_t *__restrict__ dups)
+{
+    __shared__ uint32_t wsum[256 / WAVE];
+    uint32_t c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long e = samples[i];
+        const uint32_t k = (uint32_t)(e >> 32);
+        uint32_t h = (k * 2654435761u) >> 7;
+        for (;;) {
+            h &= table_mask;
+            const unsigned long long old = atomicCAS(&table[h], ~0ull, e);
+            if (old == ~0ull) break;                                           // inserted
+            if ((uint32_t)(old >> 32) == k) { c += old != e ? 1u : 0u; break; }
+            ++h;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
+    if (lane_id() == 0) wsum[wave_id()] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 256 / WAVE; ++w) t += wsum[w];
+        if (t) atomicAdd(dups, t);
+    }
+}
+
+}  // namespace sa

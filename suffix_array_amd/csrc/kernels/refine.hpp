@@ -1,0 +1,731 @@
+// kernels/refine.hpp -- one refinement round: secondary keys (text symbols, low key bits, ranks) and the in-LDS group sort.
+// Part of the MI355X-native suffix-array engine (gfx950 / CDNA4, wave64); see DESIGN.md section 3.
+#pragma once
+#include "common.hpp"
+#include "keys.hpp"
+#include "rerank.hpp"
+#include "radix_sort.hpp"
+
+namespace sa {
+
+// ------------------------------------------------------------------------------------------
+// Secondary key of prefix doubling.  For suffix v with offset h:
+//   v + h <  n : n + ISA[v + h]     (rank of the suffix h symbols further on; ranks start at 1)
+//   v + h >= n : n - 1 - v          (text ended inside the compared prefix: the shorter suffix,
+//                                    i.e. the larger v, is smaller; all below every real rank)
+// key = (group head << key2_bits) | key2, so one sort by key refines every group at once
+// (text_key2<KS_RANK> below; the sparse variant without an ISA: sparse_key2).
+
+// Text-keyed refinement round (used while MANY suffixes are still tied): instead of ranks -- which
+// would need the ISA, n random 4-byte writes -- the secondary key is the next `s` symbols of the text
+// itself, T[v+h .. v+h+s), packed like the initial keys into `kb` bits below the group head.  The
+// order after the round is by h + s symbols; depth grows additively, but no rank array exists yet.
+// The round that finishes a top-32-bit initial sort is the same thing with the low `kb` bits of the
+// suffix's own 64-bit key as the secondary key (KS_LOWKEY).
+// KS_RANK is the secondary key of a prefix-doubling round with a full ISA (step 7, dense): the rank of the suffix h
+// symbols further on, n + ISA[v + h], or n - 1 - v when the text ends inside the compared prefix.
+// KS_SPARSE is the same key when few suffixes are tied and no full ISA exists: the rank is looked up (sparse_rank below).
+// KS_PRE (k_group_sort only): the secondary keys have been gathered into the key array already (the sparse look-up is a long
+// chain of dependent loads per suffix: one thread per suffix in its own kernel, not eight per thread in the sort).
+enum { KS_TEXT = 0, KS_LOWKEY = 1, KS_RANK = 2, KS_SPARSE = 3, KS_PRE = 4 };
+struct KeySrc {
+    int mode;          // KS_TEXT / KS_LOWKEY / KS_RANK / KS_SPARSE
+    int64_t h;         // KS_TEXT, KS_RANK, KS_SPARSE: symbols already sorted (offset of the secondary key)
+    int s;             // KS_TEXT: symbols per secondary key
+    int kb;            // bits of the secondary key
+    const uint32_t *isa;   // KS_RANK, KS_SPARSE
+    // KS_SPARSE only:
+    const uint32_t *has_isa;        // bit q: ISA[q] is valid (q has been in the tied list of a doubling round)
+    const uint64_t *sorted_keys;    // the initial 64-bit keys in SA order, or
+    const uint32_t *sorted_top32;   // (two-stage initial sort) only their top 32 bits; then sorted_keys is unused
+    const uint32_t *sa;             // SA[1..]
+    int64_t depth;                  // symbols the initial sort and the text-keyed rounds have ordered
+    int top_shift;
+};
+
+// Sparse rank lookup (few tied suffixes): no ISA is built.  rank(q) of suffix q under the current order:
+//  - q has been in the tied list of a doubling round: ISA[q] (has_isa bit set by k_rr_apply);
+//  - otherwise its rank is still what the initial sort and the text-keyed rounds gave it.  The sorted
+//    initial keys give the slot range [lo, hi) of the suffixes sharing q's first k symbols (binary
+//    search); text-keyed rounds have ordered that range by the symbols k .. depth-1, so a second binary
+//    search on those symbols (read from the text) finds the first slot of q's group.  rank = slot + 1,
+//    the value a dense ISA scatter would have stored.
+// sorted_top32 != nullptr: the first stage sorted only the top 32 key bits (no 64-bit sorted keys exist);
+// level 1 then searches those, level 2 compares ALL symbols 0 .. depth-1 through the text.
+__device__ __forceinline__ uint64_t sparse_key2(const uint8_t *__restrict__ T, const uint8_t *lcode, const KeyParams &P, int64_t n,
+                                                const KeySrc &K, uint32_t v, bool aligned8)
+{
+    const int64_t p = (int64_t)v + K.h;
+    if (p >= n) return (uint64_t)(n - 1 - (int64_t)v);
+    if ((K.has_isa[p >> 5] >> (p & 31)) & 1u) return (uint64_t)n + (uint64_t)K.isa[p];
+    const uint64_t kq = text_key(T, lcode, P, n, p, P.k, aligned8);
+    int64_t lo = 0, hi = n, a = 0;              // [lo, a): slots whose (top) key equals q's
+    if (K.sorted_top32) {
+        const uint32_t kt = (uint32_t)(kq >> K.top_shift);
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (K.sorted_top32[mid] < kt) lo = mid + 1; else hi = mid; }
+        a = lo; int64_t b = n;
+        while (a < b) { const int64_t mid = (a + b) >> 1; if (K.sorted_top32[mid] <= kt) a = mid + 1; else b = mid; }
+    } else {
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (K.sorted_keys[mid] < kq) lo = mid + 1; else hi = mid; }
+        a = lo; int64_t b = n;
+        if (K.depth > P.k) while (a < b) { const int64_t mid = (a + b) >> 1; if (K.sorted_keys[mid] <= kq) a = mid + 1; else b = mid; }
+    }
+    const int64_t from = K.sorted_top32 ? 0 : P.k;  // symbols already decided by level 1
+    if (K.depth > from && a - lo > 1) {
+        int64_t l2 = lo, h2 = a;                 // inside [lo, a): first slot not smaller on symbols from .. depth-1
+        while (l2 < h2) {
+            const int64_t mid = (l2 + h2) >> 1;
+            const int64_t sfx = (int64_t)K.sa[mid];
+            bool less = false;                   // suffix at mid < q on those symbols?
+            for (int64_t i = from; i < K.depth; ++i) {
+                const uint64_t ca = code_at(T, lcode, n, sfx + i), cb = code_at(T, lcode, n, p + i);
+                if (ca != cb) { less = ca < cb; break; }
+            }
+            if (less) l2 = mid + 1; else h2 = mid;
+        }
+        lo = l2;
+    }
+    return (uint64_t)n + (uint64_t)lo + 1u;
+}
+
+template <int MODE>
+__device__ __forceinline__ uint64_t text_key2(const uint8_t *__restrict__ T, const uint8_t *lcode, const KeyParams &P, int64_t n,
+                                              const KeySrc &K, uint32_t v, bool aligned8)
+{
+    if (MODE == KS_PRE) return 0;
+    if (MODE == KS_SPARSE) return sparse_key2(T, lcode, P, n, K, v, aligned8);
+    if (MODE == KS_RANK) {
+        const int64_t p = (int64_t)v + K.h;
+        return p < n ? (uint64_t)n + (uint64_t)K.isa[p] : (uint64_t)(n - 1 - (int64_t)v);
+    }
+    if (MODE == KS_TEXT) return text_key(T, lcode, P, n, (int64_t)v + K.h, K.s, aligned8);
+    if (P.bits > 0 && K.kb % P.bits == 0) {
+        // bit-field keys: the low bits ARE the last kb / bits symbols of the key
+        const int ns = K.kb / P.bits;
+        return text_key(T, lcode, P, n, (int64_t)v + (P.k - ns), ns, aligned8);
+    }
+    return text_key(T, lcode, P, n, (int64_t)v, P.k, aligned8) & ((1ull << K.kb) - 1ull);
+}
+
+// plain gather (the tied list then goes through the global radix sort): keys[j] = (group head << kb) | key2
+template <int MODE>
+__global__ __launch_bounds__(GK_THREADS) void k_gather_textkey(const uint32_t *__restrict__ V, const uint32_t *__restrict__ G,
+                                                                const uint8_t *__restrict__ T, KeyParams P, int64_t m, int64_t n,
+                                                                KeySrc K, uint64_t *__restrict__ keys)
+{
+    __shared__ uint8_t lcode[256];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    __syncthreads();
+    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
+    const int64_t stride = (int64_t)gridDim.x * GK_THREADS;
+    for (int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x; j < m; j += stride)
+        keys[j] = ((uint64_t)G[j] << K.kb) | text_key2<MODE>(T, lcode, P, n, K, V[j], aligned8);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_group_sort: gather of the secondary keys FUSED with the refinement of the small groups.
+// After the initial sort the tied suffixes sit in millions of tiny groups (mean size 5-10 on
+// English-like text), so a global 8-pass radix sort of (group head, key2) mostly re-establishes
+// an order it already has.  The tied list is in slot order with every group contiguous, and the
+// offset of an element inside its group is its slot minus the group-head slot, so group starts
+// are known without a scan.  One workgroup takes GS_TILE consecutive list elements:
+//   1. every thread loads (V, G, U) of its elements and gathers their secondary keys from the
+//      text (the random accesses of the round; all of a thread's loads are in flight together);
+//      keys and a group-start bitmap go to LDS;
+//   2. a group that lies completely inside the tile and has at most GS_CAP members is OWNED: every
+//      member counts the members that order before it (key, then list position) -- an LDS
+//      broadcast read per step, wave cost = its largest group -- which is its place in the group;
+//   3. (key, suffix) pairs are permuted through LDS and stored coalesced.  Members of groups that
+//      are not owned keep their place and are flagged; they go through the global radix sort.
+// Algorithmic traffic per element: 12 B read + the text gather, 13 B written.
+// ------------------------------------------------------------------------------------------
+constexpr int GS_THREADS = 256;
+constexpr int GS_ITEMS = 8;
+constexpr int GS_TILE = GS_THREADS * GS_ITEMS;
+constexpr int GS_WORDS = GS_TILE / 64;
+constexpr int GS_CAP = 1024;        // upper bound of the run-time group-size cap
+
+template <int MODE>
+__global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, const uint32_t *__restrict__ G,
+                                                            const uint32_t *__restrict__ U, const uint8_t *__restrict__ T, KeyParams P,
+                                                            int64_t m, int64_t n, KeySrc K, uint64_t *keys,
+                                                            uint32_t *Vout, uint8_t *__restrict__ bigflag, int cap)   // Vout may be Vin
+{
+    __shared__ uint64_t s_key[GS_TILE];
+    __shared__ uint32_t s_val[GS_TILE];
+    __shared__ uint64_t s_head[GS_WORDS + 1];
+    __shared__ int s_nextH[GS_WORDS + 2];          // first group start in words >= w (-1: none): a group's end is one look-up
+    __shared__ uint8_t lcode[256];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    __syncthreads();
+    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
+    const int64_t base = (int64_t)blockIdx.x * GS_TILE;
+    const int t = threadIdx.x;
+#ifdef SA_AMD_DIAG
+    const bool stamping = g_gs_stamp_on != 0 && t == 0;
+    unsigned long long t_prev = stamping ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto stamp = [&](int phase) {
+        if (stamping) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            atomicAdd(&g_phase_cycles[8 + phase], now - t_prev);
+            t_prev = now;
+        }
+    };
+#else
+    auto stamp = [](int) {};
+#endif
+    uint32_t v[GS_ITEMS], g[GS_ITEMS], u[GS_ITEMS];
+    uint64_t key[GS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        const int64_t j = base + r * GS_THREADS + t;
+        const bool valid = j < m;
+        v[r] = valid ? Vin[j] : 0u;
+        g[r] = valid ? G[j] : 0u;
+        u[r] = valid ? U[j] : 0u;
+    }
+    stamp(0);      // list loads issued
+#pragma unroll
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        const int64_t j = base + r * GS_THREADS + t;
+        if (MODE == KS_PRE) key[r] = j < m ? (keys[j] & ((1ull << K.kb) - 1ull)) : 0ull;
+        else key[r] = j < m ? text_key2<MODE>(T, lcode, P, n, K, v[r], aligned8) : 0ull;
+    }
+    stamp(1);      // secondary keys gathered (includes the wait for the list loads)
+    // keys of at most 53 bits are ranked as (key << 11 | tile position): unique, so one compare per member
+    static_assert(GS_TILE <= 2048, "11 bits of tile position");
+    const bool packed = K.kb <= 53;
+#pragma unroll
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        const int jl = r * GS_THREADS + t;
+        const bool head = (base + jl >= m) || u[r] == g[r];       // past the end counts as a group start
+        const uint64_t hb = __ballot(head);
+        if (lane_id() == 0) s_head[jl >> 6] = hb;
+        s_key[jl] = packed ? ((key[r] << 11) | (uint64_t)jl) : key[r];
+    }
+    if (t == 0) {
+        // does a group start exactly at the first element after the tile?
+        const int64_t jx = base + GS_TILE;
+        s_head[GS_WORDS] = (jx >= m || U[jx] == G[jx]) ? 1ull : 0ull;
+    }
+    __syncthreads();
+    if (wave_id() == 0) {
+        const int l = lane_id();
+        const uint64_t hw = l <= GS_WORDS ? s_head[l] : 0ull;
+        int first = hw ? l * 64 + __builtin_ctzll(hw) : 0x7fffffff;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int bb = __shfl_down(first, o, WAVE);
+            if (l + o < WAVE) first = min(first, bb);
+        }
+        if (l <= GS_WORDS) s_nextH[l] = first == 0x7fffffff ? -1 : first;
+        if (l == 0) s_nextH[GS_WORDS + 1] = -1;
+    }
+    __syncthreads();
+    stamp(2);      // keys + group-start bitmap in LDS, next-start table (3 barriers)
+    int dest[GS_ITEMS];
+    bool big[GS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        const int jl = r * GS_THREADS + t;
+        const bool valid = base + jl < m;
+        const int start = jl - (int)(u[r] - g[r]);               // negative: the group starts before the tile
+        // end of the group = next group start after jl (GS_TILE: the tile ends with the group)
+        int end;
+        {
+            const int wi = jl >> 6;
+            const uint64_t wbits = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
+            end = wbits ? wi * 64 + __builtin_ctzll(wbits) : s_nextH[wi + 1];
+        }
+        const bool owned = valid && start >= 0 && end >= 0 && end - start <= cap;
+        int rank = 0;
+        if (owned && packed) {
+            const uint64_t mine = (key[r] << 11) | (uint64_t)jl;
+            for (int i = start; i < end; ++i) rank += s_key[i] < mine ? 1 : 0;
+        } else if (owned) {
+            const uint64_t mine = key[r];
+            for (int i = start; i < end; ++i) {
+                const uint64_t k = s_key[i];
+                rank += (k < mine || (k == mine && i < jl)) ? 1 : 0;
+            }
+        }
+        dest[r] = owned ? start + rank : jl;
+        big[r] = valid && !owned;
+    }
+    stamp(3);      // group extents + rank loops
+    __syncthreads();                                             // every rank is known: the key slots can be reused
+#pragma unroll
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        s_key[dest[r]] = ((uint64_t)g[r] << K.kb) | key[r];
+        s_val[dest[r]] = v[r];
+    }
+    __syncthreads();
+    stamp(4);      // permuted through LDS (2 barriers)
+#pragma unroll
+    for (int r = 0; r < GS_ITEMS; ++r) {
+        const int jl = r * GS_THREADS + t;
+        const int64_t j = base + jl;
+        if (j < m) { keys[j] = s_key[jl]; Vout[j] = s_val[jl]; bigflag[j] = big[r] ? 1 : 0; }
+    }
+    stamp(5);      // stores issued
+}
+
+// The groups k_group_sort could not own only because they straddle a tile boundary: one workgroup per
+// boundary sorts the (at most one) group of up to GS_CAP members that contains it, the same way, on
+// the keys the first kernel stored, and clears its flags.  What stays flagged are groups > GS_CAP.
+constexpr int GX_THREADS = 256;
+constexpr int GX_ITEMS = GS_CAP / GX_THREADS;
+__global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__restrict__ keys, uint32_t *__restrict__ V,
+                                                                     const uint32_t *__restrict__ G, const uint32_t *__restrict__ U,
+                                                                     int64_t m, uint8_t *__restrict__ bigflag, int cap)
+{
+    __shared__ uint64_t s_key[GS_CAP];
+    __shared__ int s_end;
+    const int64_t b = ((int64_t)blockIdx.x + 1) * GS_TILE;          // first element of the next tile
+    if (b >= m) return;
+    const uint32_t ub = U[b], gb = G[b];
+    if (ub == gb) return;                                            // a group starts here: nothing straddles
+    const int64_t span = (int64_t)(ub - gb);                         // members before the boundary
+    if (span >= cap) return;
+    const int64_t start = b - span;
+    const int t = threadIdx.x;
+    if (t == 0) s_end = cap + 1;
+    __syncthreads();
+    // end of the group: the first group start after the boundary, at most GS_CAP from `start`
+    // (searched 256 positions at a time: most groups end within the first few)
+    for (int i0 = (int)span + 1; i0 <= cap; i0 += GX_THREADS) {
+        const int i = i0 + t;
+        const int64_t j = start + i;
+        if (i <= cap && (j >= m || U[j] == G[j])) atomicMin(&s_end, i);
+        __syncthreads();
+        if (s_end <= cap) break;                                     // uniform: every thread reads the same value
+        __syncthreads();
+    }
+    const int size = s_end;
+    if (size > cap) return;
+    uint64_t key[GX_ITEMS]; uint32_t v[GX_ITEMS];
+#pragma unroll
+    for (int r = 0; r < GX_ITEMS; ++r) {
+        const int i = r * GX_THREADS + t;
+        key[r] = 0; v[r] = 0;
+        if (i < size) { key[r] = keys[start + i]; v[r] = V[start + i]; s_key[i] = key[r]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < GX_ITEMS; ++r) {
+        const int i = r * GX_THREADS + t;
+        if (i < size) {
+            int rank = 0;
+            for (int q = 0; q < size; ++q) {
+                const uint64_t k = s_key[q];
+                rank += (k < key[r] || (k == key[r] && q < i)) ? 1 : 0;
+            }
+            keys[start + rank] = key[r];
+            V[start + rank] = v[r];
+            bigflag[start + i] = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finish_sorted: the round that finishes a top-32-bit initial sort, in ONE pass over the sorted
+// keys and SA -- no tied-suffix lists, no re-rank kernels.  The probe only allows the 32-bit first
+// stage when the suffixes tied on the top 32 bits are few and sit in tiny groups, so: a workgroup
+// takes 2048 slots (+ 256 of overhang), finds the groups (runs of equal 32-bit keys) from a bitmap of
+// run starts in LDS, and for every group that STARTS in its 2048 slots, ends inside the overhang
+// and has <= cap members: gathers the members' low key bits from the text (KS_LOWKEY), ranks them in
+// LDS (as k_group_sort does) and writes the suffixes back to their SA slots in the new order.
+// Members that are still tied afterwards (equal 64-bit keys; rare) are recorded -- bit in surv_bits,
+// slot of their subgroup's first member in surv_head, count per re-rank tile -- and k_surv_compact
+// turns that into the (slot, group head, suffix) list the later rounds expect.  A group it cannot
+// own (too large / longer overhang) only bumps counters[1]; the host then runs the general path
+// (k_rr_* + refine_list) over everything: correct on any input, fast on the inputs the probe admits.
+// Algorithmic traffic per slot: 4 B key + (tied: 4 B SA read, text gather, 4 B SA write).
+// ------------------------------------------------------------------------------------------
+constexpr int FT_THREADS = 256;
+constexpr int FT_TILE = 2048;
+constexpr int FT_XITEMS = FT_TILE / FT_THREADS + 1;         // 8 items + 1 of overhang
+constexpr int FT_SPAN = FT_THREADS * FT_XITEMS;             // 2304
+constexpr int FT_WORDS = FT_SPAN / 64;                      // 36
+
+// KeyT / MODE: uint32_t keys + KS_LOWKEY (finish of the 32-bit first stage) or uint64_t keys + KS_TEXT (the first
+// text-keyed round straight from the fully sorted keys).  TODO = false: a group nobody can own only bumps
+// counters[1] (the host then runs the general path over everything).  TODO = true: its members are flagged in
+// todo_bits (todo_cnt per 2048-slot tile, ft_head = last run start + 1 of every tile for the group-head carry);
+// k_todo_compact turns them into a tied list for the general path, whose survivors join surv_bits.
+template <typename KeyT, int MODE, bool TODO>
+__global__ __launch_bounds__(FT_THREADS) void k_finish_sorted(const KeyT *__restrict__ skeys, uint32_t *SA, const uint8_t *__restrict__ T,
+                                                               KeyParams P, int64_t n, KeySrc K, int cap, uint32_t *__restrict__ surv_bits,
+                                                               uint32_t *__restrict__ surv_head, uint32_t *__restrict__ tile_cnt,
+                                                               uint32_t *__restrict__ counters, uint32_t *__restrict__ todo_bits,
+                                                               uint32_t *__restrict__ todo_cnt, uint32_t *__restrict__ ft_head)
+{
+    typedef typename std::conditional<MODE == KS_LOWKEY, uint32_t, uint64_t>::type Key2T;   // low key bits: key_bits - 32 <= 32
+    static_assert(sizeof(KeyT) == 4 || sizeof(Key2T) == 8, "64-bit keys are staged in the 64-bit key buffer");
+    constexpr int NW = FT_THREADS / WAVE;
+    __shared__ Key2T s_key[FT_SPAN];
+    __shared__ uint32_t s_val[FT_SPAN];
+    __shared__ uint16_t s_list[FT_SPAN];          // local indices of the slots that are in a group of more than one (work list)
+    __shared__ uint64_t s_head[FT_WORDS + 1];
+    __shared__ uint8_t lcode[256];
+    __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_woff[FT_XITEMS * NW + 1];
+    __shared__ uint32_t s_surv[FT_SPAN / 32], s_todo[FT_SPAN / 32];   // this tile's survivor / todo bits, merged into the global bitmaps once
+    __shared__ KeyT s_last[FT_SPAN / 8];            // last key of every group of 8 slots (the next group's left neighbour)
+    __shared__ int s_lastH[FT_WORDS], s_nextH[FT_WORDS + 1];   // last run start in words <= w / first one in words >= w (-1: none)
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < FT_SPAN / 32) { s_surv[threadIdx.x] = 0; s_todo[threadIdx.x] = 0; }
+    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
+    const int64_t base = (int64_t)blockIdx.x * FT_TILE;
+    const int t = threadIdx.x, l = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());       // wave-uniform values stay in scalar registers
+    const int valid_cnt = (int)(n - base < FT_SPAN ? n - base : FT_SPAN);
+    const KeyT prev = base > 0 ? skeys[base - 1] : (KeyT)0;
+    // ---- phase 1, every slot, cheap: run starts -> bitmap; slots in runs longer than one -> work list ----
+    // A thread takes 8 CONSECUTIVE slots (16-byte loads, neighbours in registers): group t of the tile's own 2048 slots,
+    // and threads 0..31 also group 256 + t of the overhang.  Its 8 run-start bits are one byte of the bitmap.
+    constexpr int NG = FT_SPAN / 8;                // 288 groups of 8 slots
+    uint8_t *s_hbyte = (uint8_t *)s_head;
+    uint32_t tied8[2] = { 0, 0 };
+    KeyT kq[2][8];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int g = part ? FT_THREADS + t : t;
+        const int s0 = 8 * g;
+        if (part && t >= NG - FT_THREADS) {
+            // (only 32 groups of overhang)
+        } else if (s0 + 8 <= valid_cnt) {
+            const uint4 *src = (const uint4 *)(skeys + base + s0);
+            if (sizeof(KeyT) == 4) {
+                const uint4 a = src[0], c = src[1];
+                const uint32_t tmp[8] = { a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w };
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kq[part][i] = (KeyT)tmp[i];
+            } else {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const uint4 a = src[h];
+                    kq[part][2 * h] = (KeyT)(((uint64_t)a.y << 32) | a.x);
+                    kq[part][2 * h + 1] = (KeyT)(((uint64_t)a.w << 32) | a.z);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kq[part][i] = s0 + i < valid_cnt ? skeys[base + s0 + i] : (KeyT)0;
+        }
+        if (!part || t < NG - FT_THREADS) s_last[g] = kq[part][7];
+    }
+    if (t == 0) s_head[FT_WORDS] = 0;              // beyond the span: unknown, treated as "the run goes on"
+    __syncthreads();
+    uint32_t head8[2] = { 0, 0 };
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int g = part ? FT_THREADS + t : t;
+        const int s0 = 8 * g;
+        if (!part || t < NG - FT_THREADS) {
+            KeyT left = g ? s_last[g - 1] : prev;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool head = s0 + i >= valid_cnt || kq[part][i] != left || (s0 + i == 0 && base == 0);   // past the end: a run start
+                head8[part] |= (head ? 1u : 0u) << i;
+                left = kq[part][i];
+            }
+            s_hbyte[g] = (uint8_t)head8[part];
+        }
+    }
+    __syncthreads();
+    uint32_t cnt_main = 0, cnt_over = 0;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int g = part ? FT_THREADS + t : t;
+        const int s0 = 8 * g;
+        if (!part || t < NG - FT_THREADS) {
+            const uint32_t nb = (uint32_t)s_hbyte[g + 1] & 1u;                // (byte NG is the zero word behind the bitmap)
+            const uint32_t nxt = (head8[part] >> 1) | (nb << 7);
+            const int rem = valid_cnt - s0;
+            const uint32_t valid8 = rem >= 8 ? 0xffu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+            tied8[part] = valid8 & ~(head8[part] & nxt);
+            if (part) cnt_over = (uint32_t)__popc(tied8[part]); else cnt_main = (uint32_t)__popc(tied8[part]);
+        }
+    }
+    uint32_t total_main;
+    uint32_t off_main = block_excl_sum<FT_THREADS>(cnt_main, s_woff, &total_main);       // (two barriers inside)
+    if (w == 0) {
+        // the 32 overhang groups follow the 256 main ones in the list
+        const uint32_t inc = wave_incl_sum(l < NG - FT_THREADS ? cnt_over : 0u);
+        if (l < NG - FT_THREADS) {
+            uint32_t o = total_main + inc - cnt_over;
+            for (uint32_t m8 = tied8[1]; m8; m8 &= m8 - 1) s_list[o++] = (uint16_t)(8 * (FT_THREADS + t) + __builtin_ctz(m8));
+        }
+        if (l == WAVE - 1) s_woff[FT_XITEMS * NW] = total_main + inc;
+    } else if (w == 1) {
+        // per word: the last run start at or before its end, the first one at or after its beginning (so that the
+        // extent of any group is two look-ups, however long the group)
+        const uint64_t hw = l < FT_WORDS ? s_head[l] : 0ull;
+        int last = hw ? l * 64 + 63 - __builtin_clzll(hw) : -1;
+        int first = hw ? l * 64 + __builtin_ctzll(hw) : 0x7fffffff;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int a = __shfl_up(last, o, WAVE), bb = __shfl_down(first, o, WAVE);
+            if (l >= o) last = max(last, a);
+            if (l + o < WAVE) first = min(first, bb);
+        }
+        if (l < FT_WORDS) { s_lastH[l] = last; s_nextH[l] = first == 0x7fffffff ? -1 : first; }
+        if (l == 0) s_nextH[FT_WORDS] = -1;
+    }
+    for (uint32_t m8 = tied8[0]; m8; m8 &= m8 - 1) s_list[off_main++] = (uint16_t)(8 * t + __builtin_ctz(m8));
+    if (TODO && t == 0) {
+        // last real run start of this tile's own 2048 slots (+1; 0: none): the group-head carry of k_todo_compact
+        uint32_t lh = 0;
+        const int lim = valid_cnt < FT_TILE ? valid_cnt : FT_TILE;
+        for (int wi = (lim - 1) >> 6; wi >= 0 && lim > 0; --wi) {
+            const int rem = lim - wi * 64;
+            const uint64_t wb = s_head[wi] & (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull));
+            if (wb) { lh = (uint32_t)(base + wi * 64 + 63 - __builtin_clzll(wb)) + 1u; break; }
+        }
+        ft_head[blockIdx.x] = lh;
+    }
+    __syncthreads();
+    const uint32_t q_total = s_woff[FT_XITEMS * NW];
+    // ---- phase 2, work-list entries only (uniform early exit: with 12-22 % of the slots tied, two or three per thread) ----
+    int jl_[FT_XITEMS], start[FT_XITEMS], end[FT_XITEMS];
+    uint32_t mine_mask = 0, n_unowned = 0, n_tied = 0;
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        jl_[i] = 0; start[i] = -1; end[i] = -1;
+        const uint32_t q = (uint32_t)(i * FT_THREADS + t);
+        if ((uint32_t)(i * FT_THREADS) < q_total && q < q_total) {             // (first test: uniform, skips the unused rounds)
+        const int jl = s_list[q];
+        jl_[i] = jl;
+        {
+            const int wi = jl >> 6;
+            const uint64_t wb = s_head[wi] & ((jl & 63) == 63 ? ~0ull : ((2ull << (jl & 63)) - 1ull));
+            start[i] = wb ? wi * 64 + 63 - __builtin_clzll(wb) : (wi ? s_lastH[wi - 1] : -1);    // -1: the run started before this tile
+            const uint64_t wa = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
+            end[i] = wa ? wi * 64 + __builtin_ctzll(wa) : s_nextH[wi + 1];                        // -1: it goes on beyond the span
+        }
+        const bool in_main = start[i] >= 0 && start[i] < FT_TILE;              // the group is this workgroup's to handle
+        const bool mine = in_main && end[i] > 0 && end[i] - start[i] <= cap;
+        if (mine) mine_mask |= 1u << i;
+        if (jl < FT_TILE && (in_main || start[i] < 0)) ++n_tied;               // (statistics; counted by the slot's own workgroup)
+        if (in_main && !mine && jl < FT_TILE) ++n_unowned;                     // whoever holds a group's first slot owns or reports it
+        if (TODO) {
+            // every member of a group nobody owns must be flagged by SOME workgroup that sees it:
+            //  - the group starts in my slots and I cannot own it: I flag all of it that I see (overhang included);
+            //  - it started before my slots: its owner sees at most my first 256 slots, so a member beyond them, or one of a
+            //    group that goes on beyond them, is nobody's; one of a group that ends inside them is the earlier workgroup's call
+            bool todo;
+            if (in_main) todo = !mine;
+            else if (start[i] >= FT_TILE) todo = false;
+            else todo = jl >= FT_SPAN - FT_TILE || end[i] < 0 || end[i] > FT_SPAN - FT_TILE;
+            if (todo) atomicOr(&s_todo[jl >> 5], 1u << (jl & 31));
+        }
+        }
+    }
+    uint32_t v[FT_XITEMS];
+    Key2T key[FT_XITEMS];
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        v[i] = 0; key[i] = 0;
+        if ((mine_mask >> i) & 1u) v[i] = SA[base + jl_[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        if ((mine_mask >> i) & 1u) {
+            key[i] = (Key2T)text_key2<MODE>(T, lcode, P, n, K, v[i], aligned8);
+            s_key[jl_[i]] = key[i];
+        }
+    }
+    __syncthreads();
+    // ---- rank inside the group = place ----
+    int dest[FT_XITEMS];
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        dest[i] = 0;
+        if ((mine_mask >> i) & 1u) {
+            int rank = 0;
+            const Key2T me = key[i];
+            const int jl = jl_[i];
+            for (int p = start[i]; p < end[i]; ++p) {
+                const Key2T k = s_key[p];
+                rank += (k < me || (k == me && p < jl)) ? 1 : 0;
+            }
+            dest[i] = start[i] + rank;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        if ((mine_mask >> i) & 1u) { s_key[dest[i]] = key[i]; s_val[dest[i]] = v[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FT_XITEMS; ++i) {
+        if (!((mine_mask >> i) & 1u)) continue;
+        const int jl = jl_[i];                                                 // now: the POSITION this thread finishes
+        const int64_t j = base + jl;
+        SA[j] = s_val[jl];
+        const Key2T kk = s_key[jl];
+        const bool tl = jl > start[i] && s_key[jl - 1] == kk, tr = jl + 1 < end[i] && s_key[jl + 1] == kk;
+        if (tl || tr) {                                                        // still tied after this round's key
+            int p = jl;
+            while (p > start[i] && s_key[p - 1] == kk) --p;
+            surv_head[j] = (uint32_t)(base + p);
+            atomicOr(&s_surv[jl >> 5], 1u << (jl & 31));
+        }
+    }
+    if (n_unowned) atomicAdd(&s_cnt[0], n_unowned);
+    if (n_tied) atomicAdd(&s_cnt[1], n_tied);
+    __syncthreads();
+    if (t == 0) {
+        if (s_cnt[0]) atomicAdd(&counters[1], s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&counters[2], s_cnt[1]);
+    }
+    if (t < FT_SPAN / 32) {
+        // one atomic per non-empty 32-slot word (base is a multiple of 2048, so words are aligned in the global bitmaps)
+        const int64_t j0 = base + 32 * t;
+        const uint32_t sw = s_surv[t];
+        if (sw) { atomicOr(&surv_bits[j0 >> 5], sw); atomicAdd(&tile_cnt[j0 / RR_TILE], (uint32_t)__popc(sw)); }
+        if (TODO) {
+            const uint32_t tw = s_todo[t];
+            if (tw) {
+                const uint32_t fresh = tw & ~atomicOr(&todo_bits[j0 >> 5], tw);      // (a neighbour may have flagged some already)
+                if (fresh) atomicAdd(&todo_cnt[j0 / FT_TILE], (uint32_t)__popc(fresh));
+            }
+        }
+    }
+}
+
+// Members of the groups k_finish_sorted<.., TODO = true> left to the general path -> (slot, group head, suffix) list in
+// slot order.  One workgroup per 2048-slot tile (those without flagged members leave at once); todo_cnt / ft_head
+// hold the exclusive sums / running maxima of k_rr_scan.  The group head of a member is the last run start at or
+// before it: found in the tile's own run-start bitmap (recomputed from the keys), else carried in.
+template <typename KeyT>
+__global__ __launch_bounds__(FT_THREADS) void k_todo_compact(const KeyT *__restrict__ skeys, const uint32_t *__restrict__ SA, int64_t n,
+                                                              const uint32_t *__restrict__ todo_bits, const uint32_t *__restrict__ todo_cnt,
+                                                              const uint32_t *__restrict__ ft_head, const uint32_t *__restrict__ todo_total,
+                                                              uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo)
+{
+    constexpr int ITEMS = FT_TILE / FT_THREADS;
+    constexpr int BW = FT_TILE / 32;                                          // 64 bitmap words of 32 slots
+    __shared__ KeyT s_nb[FT_TILE];
+    __shared__ uint64_t s_head[FT_TILE / 64];
+    __shared__ uint32_t s_bits[BW], s_off[BW];
+    const uint32_t here = todo_cnt[blockIdx.x];
+    const uint32_t next = (blockIdx.x + 1 < gridDim.x) ? todo_cnt[blockIdx.x + 1] : *todo_total;
+    if (next == here) return;
+    const uint32_t carry = ft_head[blockIdx.x];                              // (last run start before this tile) + 1
+    const int64_t base = (int64_t)blockIdx.x * FT_TILE;
+    const int t = threadIdx.x, l = lane_id();
+    const int valid_cnt = (int)(n - base < FT_TILE ? n - base : FT_TILE);
+    const KeyT prev = base > 0 ? skeys[base - 1] : (KeyT)0;
+    KeyT k[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int jl = r * FT_THREADS + t;
+        k[r] = jl < valid_cnt ? skeys[base + jl] : (KeyT)0;
+        s_nb[jl] = k[r];
+    }
+    if (t < BW) {
+        const int64_t wi = base / 32 + t;
+        const uint32_t b = wi < (n + 31) / 32 ? todo_bits[wi] : 0u;
+        s_bits[t] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int jl = r * FT_THREADS + t;
+        const bool head = jl < valid_cnt && (k[r] != (jl ? s_nb[jl - 1] : prev) || (jl == 0 && base == 0));
+        const uint64_t hb = __ballot(head);
+        if (l == 0) s_head[jl >> 6] = hb;
+    }
+    if (t < WAVE) {                                                           // wave 0: exclusive offsets of the 64 words
+        const uint32_t c = (uint32_t)__popc(s_bits[t]);
+        const uint32_t inc = wave_incl_sum(c);
+        s_off[t] = inc - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int jl = r * FT_THREADS + t;
+        const uint32_t bits = s_bits[jl >> 5];
+        if (!((bits >> (jl & 31)) & 1u)) continue;
+        int wi = jl >> 6;
+        uint64_t wb = s_head[wi] & ((jl & 63) == 63 ? ~0ull : ((2ull << (jl & 63)) - 1ull));
+        while (!wb && wi > 0) wb = s_head[--wi];
+        const uint32_t g = wb ? (uint32_t)(base + wi * 64 + 63 - __builtin_clzll(wb)) : carry - 1u;
+        const uint32_t pos = here + s_off[jl >> 5] + (uint32_t)__popc(bits & ((1u << (jl & 31)) - 1u));
+        const uint32_t slot = (uint32_t)(base + jl);
+        Uo[pos] = slot; Go[pos] = g; Vo[pos] = SA[slot];
+    }
+}
+
+// survivors of k_finish_sorted -> (slot, group head, suffix) lists in slot order; tile_cnt holds the exclusive
+// offsets of the re-rank tiles (k_rr_scan), one workgroup per tile, one bitmap word per thread
+__global__ __launch_bounds__(256) void k_surv_compact(const uint32_t *__restrict__ surv_bits, const uint32_t *__restrict__ surv_head,
+                                                       const uint32_t *__restrict__ SA, int64_t n, const uint32_t *__restrict__ tile_cnt,
+                                                       const uint32_t *__restrict__ tile_total, uint32_t *__restrict__ Uo,
+                                                       uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo)
+{
+    static_assert(RR_TILE == 256 * 32, "one bitmap word per thread");
+    __shared__ uint32_t lds[256 / WAVE + 1];
+    const uint32_t here = tile_cnt[blockIdx.x];
+    const uint32_t next = (blockIdx.x + 1 < gridDim.x) ? tile_cnt[blockIdx.x + 1] : *tile_total;
+    if (next == here) return;
+    const int64_t widx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nwords = (n + 31) / 32;
+    uint32_t bits = widx < nwords ? surv_bits[widx] : 0u;
+    uint32_t tot;
+    uint32_t off = here + block_excl_sum<256>((uint32_t)__popc(bits), lds, &tot);
+    while (bits) {
+        const int b = __builtin_ctz(bits);
+        bits &= bits - 1;
+        const uint32_t slot = (uint32_t)(widx * 32 + b);
+        Uo[off] = slot; Go[off] = surv_head[slot]; Vo[off] = SA[slot];
+        ++off;
+    }
+}
+
+// ---- ordered compaction of the flagged elements (those the local pass could not own) ----
+__global__ __launch_bounds__(RR_THREADS) void k_flag_count(const uint8_t *__restrict__ flag, int64_t m, uint32_t *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
+    const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) if (idx0 + r < m) c += flag[idx0 + r];
+    uint32_t tot;
+    block_excl_sum<RR_THREADS>(c, lds, &tot);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(RR_THREADS) void k_flag_gather(const uint8_t *__restrict__ flag, const uint64_t *__restrict__ keys,
+                                                             const uint32_t *__restrict__ V, int64_t m, const uint32_t *__restrict__ tile_cnt,
+                                                             uint64_t *__restrict__ bk, uint32_t *__restrict__ bv, uint32_t *__restrict__ bidx)
+{
+    __shared__ uint32_t lds[RR_THREADS / WAVE + 1];
+    const int64_t idx0 = (int64_t)blockIdx.x * RR_TILE + (int64_t)threadIdx.x * RR_ITEMS;
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) if (idx0 + r < m) c += flag[idx0 + r];
+    uint32_t tot;
+    uint32_t off = tile_cnt[blockIdx.x] + block_excl_sum<RR_THREADS>(c, lds, &tot);
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t j = idx0 + r;
+        if (j < m && flag[j]) { bk[off] = keys[j]; bv[off] = V[j]; bidx[off] = (uint32_t)j; ++off; }
+    }
+}
+
+// sorted flagged elements back to their list positions (sorted by group first, and bidx is increasing,
+// so the o-th sorted element belongs at the o-th flagged position)
+__global__ __launch_bounds__(256) void k_scatter_back(const uint64_t *__restrict__ bk, const uint32_t *__restrict__ bv,
+                                                       const uint32_t *__restrict__ bidx, int64_t count, uint64_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ V)
+{
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o < count) { const uint32_t j = bidx[o]; keys[j] = bk[o]; V[j] = bv[o]; }
+}
+
+}  // namespace sa

@@ -1,0 +1,233 @@
+// kernels/rerank.hpp -- group heads -> ranks, SA write-back, compaction of the suffixes still tied with a neighbour.
+// Part of the MI355X-native suffix-array engine (gfx950 / CDNA4, wave64); see DESIGN.md section 3.
+#pragma once
+#include "common.hpp"
+
+namespace sa {
+
+// ------------------------------------------------------------------------------------------
+// Re-rank: m sorted (key, suffix) pairs sitting in slots U[0..m) of SA (FIRST: U[j] = j).
+// A group = maximal run of equal keys; its rank is (slot of its first element) + 1.
+//   k_rr_count : per tile, how many elements stay tied with a neighbour, and the last group
+//                head slot (+1) inside the tile
+//   k_rr_scan  : exclusive sum / exclusive max over the tiles (one workgroup)
+//   k_rr_apply : SA[U[j]] = V[j]; ISA[V[j]] = rank; compact (slot, group head, suffix) of the
+//                elements that are still tied
+// Algorithmic traffic per element: 12 B read twice (keys + vals [+ 4 B slot]), 4 B SA write,
+// 4 B ISA scatter, 12 B per surviving element.
+// ------------------------------------------------------------------------------------------
+constexpr int RR_THREADS = 1024;
+constexpr int RR_ITEMS = 8;
+constexpr int RR_TILE = RR_THREADS * RR_ITEMS;   // 8192
+
+constexpr int RR_WAVE_ELEMS = WAVE * RR_ITEMS;   // 512 consecutive elements per wave, item r of lane l = base + 64 r + l
+
+// Head / tied masks of one wave's 512 elements.  Loads are wave-striped (512 contiguous bytes per
+// instruction); the neighbour keys come from shuffles, so the whole classification is 8 ballots
+// and scalar bit arithmetic: head[r] bit l = element (r, l) starts a group, tied[r] bit l = it is
+// in a group of more than one element, valid[r] = it exists.
+struct WaveGroups { uint64_t head[RR_ITEMS], tied[RR_ITEMS], valid[RR_ITEMS]; };
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
+{
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, WAVE);
+}
+
+template <typename KeyT>
+__device__ __forceinline__ WaveGroups rr_wave_classify(const KeyT *__restrict__ keys, int64_t m, int64_t wbase, int key_shift)
+{
+    const int l = lane_id();
+    uint64_t k[RR_ITEMS];
+    WaveGroups g;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        k[r] = i < m ? ((uint64_t)keys[i] >> key_shift) : 0ull; // groups are runs of equal key >> key_shift
+        g.valid[r] = __ballot(i < m);
+    }
+    const uint64_t before = (wbase > 0 && wbase - 1 < m) ? ((uint64_t)keys[wbase - 1] >> key_shift) : 0ull;
+    const uint64_t after = (wbase + RR_WAVE_ELEMS < m) ? ((uint64_t)keys[wbase + RR_WAVE_ELEMS] >> key_shift) : 0ull;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        uint64_t up = shfl64(k[r], l ? l - 1 : 0);
+        const uint64_t prev_last = r ? shfl64(k[r ? r - 1 : 0], 63) : before;   // executed by every lane (no shuffle under divergence)
+        if (l == 0) up = prev_last;
+        const int64_t i = wbase + 64 * r + l;
+        g.head[r] = __ballot(i < m && (i == 0 || k[r] != up));
+    }
+    const uint64_t last_key = shfl64(k[RR_ITEMS - 1], 63);
+    const bool boundary_after = (wbase + RR_WAVE_ELEMS >= m) || after != last_key;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        // is the NEXT element a group boundary (a head, or past the end)?
+        const uint64_t bnd = g.head[r] | ~g.valid[r];
+        const uint64_t bnd_next0 = (r + 1 < RR_ITEMS) ? ((g.head[(r + 1) % RR_ITEMS] | ~g.valid[(r + 1) % RR_ITEMS]) & 1ull)
+                                                      : (boundary_after ? 1ull : 0ull);
+        const uint64_t next = (bnd >> 1) | (bnd_next0 << 63);
+        g.tied[r] = g.valid[r] & ~(g.head[r] & next);
+    }
+    return g;
+}
+
+template <bool FIRST, typename KeyT = uint64_t>
+__global__ __launch_bounds__(RR_THREADS) void k_rr_count(const KeyT *__restrict__ keys,
+                                                          const uint32_t *__restrict__ U, int64_t m,
+                                                          uint32_t *__restrict__ tile_cnt,
+                                                          uint32_t *__restrict__ tile_head, int key_shift)
+{
+    __shared__ uint32_t wcnt[RR_THREADS / WAVE], whead[RR_THREADS / WAVE];
+    const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)wave_id() * RR_WAVE_ELEMS;
+    const WaveGroups g = rr_wave_classify(keys, m, wbase, key_shift);
+    uint32_t cnt = 0, lasthead = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        cnt += (uint32_t)__popcll(g.tied[r]);
+        if (g.head[r]) {
+            const int64_t i = wbase + 64 * r + (63 - __builtin_clzll(g.head[r]));
+            lasthead = (FIRST ? (uint32_t)i : U[i]) + 1u;       // slots grow with the index: the last head wins
+        }
+    }
+    if (lane_id() == 0) { wcnt[wave_id()] = cnt; whead[wave_id()] = lasthead; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0, mx = 0;
+        for (int w = 0; w < RR_THREADS / WAVE; ++w) { tot += wcnt[w]; mx = mx > whead[w] ? mx : whead[w]; }
+        tile_cnt[blockIdx.x] = tot;
+        tile_head[blockIdx.x] = mx;
+    }
+}
+
+// one workgroup: tile_cnt -> exclusive sums (+ total), tile_head -> exclusive running max.
+// Every thread owns a contiguous run of entries (a multiple of 4, read and written as 16-byte vectors:
+// the run is a chain of dependent L2 accesses, so fewer, wider ones).
+__global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict__ tile_cnt,
+                                                            uint32_t *__restrict__ tile_head, int64_t tiles,
+                                                            uint32_t *__restrict__ out_total)
+{
+    __shared__ uint32_t lds[SPINE_THREADS / WAVE + 1];
+    const int64_t per = ((tiles + SPINE_THREADS - 1) / SPINE_THREADS + 3) & ~(int64_t)3;
+    int64_t b = (int64_t)threadIdx.x * per, e = b + per;
+    if (b > tiles) b = tiles;
+    if (e > tiles) e = tiles;
+    const int64_t ev = b + ((e - b) & ~(int64_t)3);           // end of the whole vectors
+    uint32_t s = 0, mx = 0;
+    for (int64_t i = b; i < ev; i += 4) {
+        const uint4 c = *(const uint4 *)(tile_cnt + i), h = *(const uint4 *)(tile_head + i);
+        s += c.x + c.y + c.z + c.w;
+        mx = max(max(mx, max(h.x, h.y)), max(h.z, h.w));
+    }
+    for (int64_t i = ev; i < e; ++i) { s += tile_cnt[i]; mx = max(mx, tile_head[i]); }
+    uint32_t tot, mtot;
+    uint32_t off = block_excl_sum<SPINE_THREADS>(s, lds, &tot);
+    uint32_t incm = block_incl_max<SPINE_THREADS>(mx, lds, &mtot);
+    // exclusive max for this thread = inclusive max of the previous thread
+    uint32_t prevm = __shfl_up(incm, 1, WAVE);
+    __shared__ uint32_t wlast[SPINE_THREADS / WAVE];
+    if (lane_id() == WAVE - 1) wlast[wave_id()] = incm;
+    __syncthreads();
+    if (lane_id() == 0) prevm = wave_id() ? wlast[wave_id() - 1] : 0u;
+    uint32_t run = prevm;
+    for (int64_t i = b; i < ev; i += 4) {
+        const uint4 c = *(const uint4 *)(tile_cnt + i), h = *(const uint4 *)(tile_head + i);
+        uint4 oc, oh;
+        oc.x = off; off += c.x; oc.y = off; off += c.y; oc.z = off; off += c.z; oc.w = off; off += c.w;
+        oh.x = run; run = max(run, h.x); oh.y = run; run = max(run, h.y); oh.z = run; run = max(run, h.z); oh.w = run; run = max(run, h.w);
+        *(uint4 *)(tile_cnt + i) = oc;
+        *(uint4 *)(tile_head + i) = oh;
+    }
+    for (int64_t i = ev; i < e; ++i) {
+        uint32_t c = tile_cnt[i], h = tile_head[i];
+        tile_cnt[i] = off; off += c;
+        tile_head[i] = run; run = run > h ? run : h;
+    }
+    if (threadIdx.x == 0) *out_total = tot;
+}
+
+// ISA_MODE: 0 = scatter ISA[suffix] = rank directly, 1 = the same plus the has_isa bitmap (sparse
+// refinement), 3 = no rank output at all (text-keyed rounds), 4 = like 3, but the still-tied suffixes are recorded by slot
+// (ISA = group heads, has_isa = bitmap, pair_v = counts per tile) instead of being listed, 2 = write (suffix, rank) pairs in slot order; the host bins them by suffix position
+// with one radix pass and k_scatter_pairs then writes the ISA window by window (a random 4-byte
+// store costs a whole 64-byte memory transaction, a binned one is merged in the caches).
+template <bool FIRST, bool WRITE_SA, int ISA_MODE, typename KeyT = uint64_t>
+__global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
+    const KeyT *__restrict__ keys, const uint32_t *__restrict__ V, const uint32_t *__restrict__ U, int64_t m,
+    const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_head, uint32_t *__restrict__ SA,
+    uint32_t *__restrict__ ISA, uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo,
+    uint32_t n_text, uint32_t *__restrict__ has_isa, int g_shift, uint64_t *__restrict__ pair_k,
+    uint32_t *__restrict__ pair_v, const uint32_t *__restrict__ tile_total, int key_shift)
+{
+    constexpr bool SPARSE = ISA_MODE == 1;
+    constexpr int NW = RR_THREADS / WAVE;
+    __shared__ uint32_t wcnt[NW], whead[NW];
+    if (FIRST && !WRITE_SA && SPARSE) {
+        // compaction-only pass (no SA, no ISA write): a tile without tied suffixes has nothing to do
+        const uint32_t here = tile_cnt[blockIdx.x];
+        const uint32_t next = (blockIdx.x + 1 < gridDim.x) ? tile_cnt[blockIdx.x + 1] : *tile_total;
+        if (next == here) return;
+    }
+    const int l = lane_id(), w = wave_id();
+    const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)w * RR_WAVE_ELEMS;
+    const WaveGroups g = rr_wave_classify(keys, m, wbase, key_shift);
+    uint32_t slot[RR_ITEMS], v[RR_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        const bool in = i < m;
+        slot[r] = FIRST ? (uint32_t)i : (in ? U[i] : 0u);
+        v[r] = in ? V[i] : 0u;
+    }
+    // this wave's totals -> offsets of the waves of the tile
+    {
+        uint32_t cnt = 0, lasthead = 0;
+#pragma unroll
+        for (int r = 0; r < RR_ITEMS; ++r) {
+            cnt += (uint32_t)__popcll(g.tied[r]);
+            if (g.head[r]) lasthead = (uint32_t)__shfl((int)slot[r], 63 - __builtin_clzll(g.head[r]), WAVE) + 1u;
+        }
+        if (l == 0) { wcnt[w] = cnt; whead[w] = lasthead; }
+    }
+    __syncthreads();
+    uint32_t run_cnt = tile_cnt[blockIdx.x], run_head = tile_head[blockIdx.x];     // carried in from the tiles before
+    for (int ww = 0; ww < w; ++ww) { run_cnt += wcnt[ww]; run_head = run_head > whead[ww] ? run_head : whead[ww]; }
+    const uint64_t le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);              // lanes <= l
+    const uint64_t lt_mask = le_mask >> 1;                                          // lanes <  l
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        // rank = (slot of the group's first element) + 1: the last head at or before this lane, else the carry
+        const uint64_t hle = g.head[r] & le_mask;
+        const int src = hle ? 63 - __builtin_clzll(hle) : 0;
+        const uint32_t hslot = (uint32_t)__shfl((int)slot[r], src, WAVE);
+        const uint32_t run = hle ? hslot + 1u : run_head;
+        const uint32_t off = run_cnt + (uint32_t)__popcll(g.tied[r] & lt_mask);
+        if (i < m) {
+            if (WRITE_SA && slot[r] < n_text) SA[slot[r]] = v[r];
+            if (ISA_MODE == 2) {
+                pair_k[i] = (uint64_t)v[r];
+                pair_v[i] = run;
+            } else if (ISA_MODE != 3 && ISA_MODE != 4 && v[r] < n_text) {
+                // refinement rounds: the key's high part is the old group head, i.e. the rank already in ISA;
+                // the first subgroup of a split group keeps its rank and is not rewritten
+                const uint32_t oldrank = (FIRST || ISA_MODE != 0) ? 0u : (uint32_t)((uint64_t)keys[i] >> g_shift) + 1u;
+                if (run != oldrank) {
+                    ISA[v[r]] = run;
+                    if (SPARSE) atomicOr(&has_isa[v[r] >> 5], 1u << (v[r] & 31u));   // this rank overrides the initial one
+                }
+            }
+            if ((g.tied[r] >> l) & 1ull) {
+                if (ISA_MODE == 4) {
+                    // survivors join those of k_finish_sorted: bitmap + group head by slot (k_surv_compact lists them in slot order)
+                    ISA[slot[r]] = run - 1u;
+                    atomicOr(&has_isa[slot[r] >> 5], 1u << (slot[r] & 31u));
+                    atomicAdd(&pair_v[slot[r] / RR_TILE], 1u);
+                } else {
+                    Uo[off] = slot[r]; Go[off] = run - 1u; Vo[off] = v[r];
+                }
+            }
+        }
+        run_cnt += (uint32_t)__popcll(g.tied[r]);
+        if (g.head[r]) run_head = (uint32_t)__shfl((int)slot[r], 63 - __builtin_clzll(g.head[r]), WAVE) + 1u;
+    }
+}
+
+}  // namespace sa

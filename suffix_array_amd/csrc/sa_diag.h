@@ -1,0 +1,29 @@
+/*
+ * sa_diag.h -- entry points of libsuffix_array_amd_diag.so ONLY (built with -DSA_AMD_DIAG from the same sources as the
+ * product library).  The diagnostic library additionally honours SA_AMD_SORT_VARIANT values that select timing
+ * ablations (kernels that skip ranking or stores and therefore produce WRONG orders) and
+ * SA_AMD_TIMING_ONLY_INITIAL_SORT (stops after the initial sort).  None of that exists in libsuffix_array_amd.so.
+ * Users: tools/ (profiles/*ablation*, phase stamps) and the primitive tests of tests/test_gpu_parity.py.
+ */
+#ifndef SUFFIX_ARRAY_AMD_DIAG_H
+#define SUFFIX_ARRAY_AMD_DIAG_H
+#include "../../include/suffix_array_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* cycles per phase of the stamped kernels, summed over tiles and workgroups; reading zeroes the counters */
+int32_t sa_amd_debug_phase_cycles(uint64_t *out, int32_t count);
+/* k_group_sort: switch its per-phase stamps on / off (entries 8..13 of the same array) */
+int32_t sa_amd_debug_group_sort_stamps(int32_t on);
+int32_t sa_amd_debug_sort_variant_count(void);
+const char *sa_amd_debug_sort_variant_name(int32_t index);
+/* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit); host buffers */
+int32_t sa_amd_test_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit, int32_t end_bit);
+/* the 32-bit-key form of the same sort (first stage of the two-stage initial sort) */
+int32_t sa_amd_test_sort_pairs32(uint32_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit, int32_t end_bit);
+/* initial packed keys of a text (host buffers; keys has n entries); returns bits in *bits, symbols in *k */
+int32_t sa_amd_test_build_keys(const uint8_t *T, int32_t n, uint64_t *keys, int32_t *bits, int32_t *k);
+#ifdef __cplusplus
+}
+#endif
+#endif

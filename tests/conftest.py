@@ -30,6 +30,8 @@ class Oracle:
         for fn in ("oracle_check_integrity", "oracle_verify_sa"):
             getattr(L, fn).argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
             getattr(L, fn).restype = ctypes.c_int32
+        L.oracle_verify_sa_mt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
+        L.oracle_verify_sa_mt.restype = ctypes.c_int32
         L.oracle_divsufsort.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
         L.oracle_divsufsort.restype = ctypes.c_int32
         L.oracle_bucket_table.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
@@ -62,6 +64,12 @@ class Oracle:
         t = self._u8(s)
         a = np.ascontiguousarray(sa, dtype=np.uint32)
         return self.L.oracle_verify_sa(t.ctypes.data, t.size, a.ctypes.data, a.size)
+
+    def verify_mt(self, s, sa, threads=16):
+        """oracle_verify_sa on several host threads (the 512 MiB / 1 GiB configs)"""
+        t = self._u8(s)
+        a = np.ascontiguousarray(sa, dtype=np.uint32)
+        return self.L.oracle_verify_sa_mt(t.ctypes.data, t.size, a.ctypes.data, a.size, threads)
 
     def bucket_table(self, s):
         t = self._u8(s)

@@ -40,7 +40,7 @@ def test_radix_sort_pairs(count, bits):
     field = (keys & mask) >> np.uint64(lo)
     order = np.argsort(field, kind="stable")
     k2, v2 = keys.copy(), vals.copy()
-    assert sa.lib().sa_amd_test_sort_pairs(k2.ctypes.data, v2.ctypes.data, count, lo, hi) == 0
+    assert sa.diag_lib().sa_amd_test_sort_pairs(k2.ctypes.data, v2.ctypes.data, count, lo, hi) == 0
     assert np.array_equal(v2, vals[order])          # stable: equal fields keep input order
     assert np.array_equal(k2, keys[order])
 
@@ -58,7 +58,7 @@ def test_radix_sort_pairs_32bit_keys(count, bits):
     field = (keys.astype(np.uint64) & np.uint64((1 << hi) - 1)) >> np.uint64(lo)
     order = np.argsort(field, kind="stable")
     k2, v2 = keys.copy(), vals.copy()
-    assert sa.lib().sa_amd_test_sort_pairs32(k2.ctypes.data, v2.ctypes.data, count, lo, hi) == 0
+    assert sa.diag_lib().sa_amd_test_sort_pairs32(k2.ctypes.data, v2.ctypes.data, count, lo, hi) == 0
     assert np.array_equal(v2, vals[order]) and np.array_equal(k2, keys[order])
 
 
@@ -69,7 +69,7 @@ def test_radix_sort_constant_and_skewed_digits():
     vals = np.arange(count, dtype=np.uint32)
     order = np.argsort(keys, kind="stable")
     k2, v2 = keys.copy(), vals.copy()
-    assert sa.lib().sa_amd_test_sort_pairs(k2.ctypes.data, v2.ctypes.data, count, 0, 64) == 0
+    assert sa.diag_lib().sa_amd_test_sort_pairs(k2.ctypes.data, v2.ctypes.data, count, 0, 64) == 0
     assert np.array_equal(v2, vals[order]) and np.array_equal(k2, keys[order])
 
 
@@ -80,7 +80,7 @@ def test_build_keys(gen, n):
             "english": lambda: corpus.english(n, 1), "unary": lambda: np.full(n, 65, dtype=np.uint8)}[gen]()
     keys = np.zeros(n, dtype=np.uint64)
     bits, k = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
-    assert sa.lib().sa_amd_test_build_keys(text.ctypes.data, n, keys.ctypes.data, bits.ctypes.data, k.ctypes.data) == 0
+    assert sa.diag_lib().sa_amd_test_build_keys(text.ctypes.data, n, keys.ctypes.data, bits.ctypes.data, k.ctypes.data) == 0
     exp, ebits, ek = pd_model.pack_keys(text)
     assert (int(bits[0]), int(k[0])) == (ebits, ek)
     assert np.array_equal(keys, exp)
@@ -344,9 +344,10 @@ def test_first_round_from_sorted_keys(oracle, monkeypatch, gen, n, seed, cap):
     assert np.array_equal(build(text), exp)
 
 
-@pytest.mark.parametrize("v64,v32", [("1", "1"), ("2", "2"), ("8", "3"), ("9", "4")])
+@pytest.mark.parametrize("v64,v32", [("1", "1"), ("2", "2"), ("3", "3"), ("3", "4"), ("99", "-7")])
 def test_sort_kernel_variants(oracle, monkeypatch, v64, v32):
-    """the non-default tile-scatter kernels (no prefetch, first-generation scatter, other shapes) give the same arrays"""
+    """the non-default tile-scatter kernel shapes of the product library (no prefetch, 512 x 16, granule 8; out-of-range
+    values fall back to the default) give the same arrays"""
     monkeypatch.setenv("SA_AMD_SORT_VARIANT", v64)
     monkeypatch.setenv("SA_AMD_SORT32_VARIANT", v32)
     for gen, n, seed in (("english", 400_000, 21), ("uniform", 300_000, 22)):
@@ -390,16 +391,100 @@ def test_randomised_inputs_and_regimes(oracle, monkeypatch):
         assert np.array_equal(build(s), oracle.sais(s)), (it, n, kind)
 
 
+# ---- the product library is bit-exact under ANY environment ---------------------------------------
+
+ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", "SA_AMD_GROUP_CAP", "SA_AMD_SPARSE_DIV",
+             "SA_AMD_FORCE_DENSE", "SA_AMD_NO_TEXT_ROUNDS", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TOP32", "SA_AMD_FORCE_TOP32",
+             "SA_AMD_NO_FUSED_FINISH", "SA_AMD_FUSED64", "SA_AMD_NO_PACKED_TEXT", "SA_AMD_NO_BINNED_ISA",
+             "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_FUSED_HIST", "SA_AMD_NO_RUN_SKIP", "SA_AMD_TIMING_ONLY_INITIAL_SORT",
+             "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
+             "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
+
+
+def test_knob_list_is_complete():
+    """every SA_AMD_* name the sources read is in ALL_KNOBS (SA_AMD_DEVICE picks the GPU; an ordinal that does not exist
+    is an error code, tested in test_abi.py, not a different array)"""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "suffix_array_amd", "csrc", "**", "*.*"), recursive=True):
+        if f.endswith((".hpp", ".hip", ".inc")):
+            names |= set(re.findall(r'"(SA_AMD_[A-Z0-9_]+)"', open(f).read()))
+    assert names - {"SA_AMD_DEVICE"} <= set(ALL_KNOBS), names - set(ALL_KNOBS)
+
+
+def test_any_environment_is_bit_exact(oracle, monkeypatch):
+    """no value of any SA_AMD_* variable may change a result of the SHIPPED library -- the timing
+    ablations and the truncated build exist only in libsuffix_array_amd_diag.so.  Random values (numbers in and out of
+    range, negative, huge, empty, text) for every knob at once, 40 rounds over texts that reach every regime."""
+    rng = np.random.default_rng(424242)
+    texts = [corpus.english(260_000, 3), corpus.uniform(180_000, 2), corpus.dna(300_000, 4), corpus.dna_repeats(250_000, 5),
+             np.resize(np.frombuffer(b"abcab", dtype=np.uint8), 90_001).copy(), np.full(40_000, 9, dtype=np.uint8),
+             corpus.sigma(120_000, 7, 3, 97), np.concatenate([corpus.english(70_000, 8)] * 2)]
+    expected = [oracle.sais(t) for t in texts]
+    pool = ["0", "1", "2", "3", "5", "7", "9", "16", "33", "64", "100", "1024", "4096", "-1", "-77", "999999999999",
+            "18446744073709551616", "", "abc", "1e9", " 4", "0x10", "yes"]
+    for it in range(40):
+        for k in ALL_KNOBS:
+            monkeypatch.delenv(k, raising=False)
+            if rng.random() < 0.55:
+                monkeypatch.setenv(k, str(rng.choice(pool)))
+        monkeypatch.setenv("SA_AMD_DEBUG_SYNC", "0")           # (read once per process; keep the suite fast)
+        monkeypatch.setenv("SA_AMD_VERBOSE", "0")
+        i = it % len(texts)
+        env = {k: os.environ[k] for k in ALL_KNOBS if k in os.environ}
+        assert np.array_equal(build(texts[i]), expected[i]), (it, i, env)
+
+
 # ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------
 
-@pytest.mark.parametrize("name", ["c2_uniform_64m", "c3_english_256m"])
+def _sampled_neighbours_ordered(text, arr, seed, samples=3000, width=256):
+    rng = np.random.default_rng(seed)
+    n = text.size
+    for i in rng.integers(1, n, samples):
+        a, b = int(arr[i]), int(arr[i + 1])
+        x, y = text[a:a + width].tobytes(), text[b:b + width].tobytes()
+        assert x < y or (x == y and len(x) == width), (i, a, b)
+
+
+@pytest.mark.parametrize("name", ["c2_uniform_64m", "c3_english_256m", "c3_iid_256m", "c4_dna_1g"])
 def test_full_size_configs(oracle, name):
+    """BASELINE.json configs 2-4 through the C ABI (host pointers): SA[0] = n, the linear-time form of reference
+    src/sa.rs:72-84 on the CPU (oracle) AND on the GPU (sa_amd_check_integrity), sampled direct comparisons;
+    the 64 MiB config also equals the oracle's array bit for bit"""
     text = corpus.workload(name)
     arr = build(text)
     assert arr[0] == text.size
-    assert oracle.verify(text, arr) == 1          # linear-time form of reference src/sa.rs:72-84
+    assert oracle.verify_mt(text, arr) == 1
+    assert sa.check_integrity(text, arr) is True
+    _sampled_neighbours_ordered(text, arr, 11)
     if text.size <= (64 << 20):
         assert np.array_equal(arr, oracle.sais(text))
+    sa.lib().sa_amd_release_cache()
+
+
+def test_dna_1g_with_planted_repeats(oracle):
+    """the harder C4 variant of SURVEY.md 8d: 1 GiB of DNA with copied segments of 1-100 KiB and 1 % point mutations"""
+    text = corpus.dna_repeats(1 << 30, 4, 0.2)
+    arr = build(text)
+    assert arr[0] == text.size
+    assert oracle.verify_mt(text, arr) == 1
+    assert sa.check_integrity(text, arr) is True
+    assert sa.last_stats()["rounds"] >= 2
+    sa.lib().sa_amd_release_cache()
+
+
+def test_c5_batch_of_512m_texts(oracle):
+    """BASELINE.json config 5 through sa_amd_saca_batch: independent 512 MiB texts (seeds 50, 51, 52), text i on device
+    i mod G over all visible devices, every array verified"""
+    texts = [corpus.workload("c5_uniform_512m", rank=r) for r in range(3)]
+    outs = sa.saca_batch(texts)
+    for t, o in zip(texts, outs):
+        assert o[0] == t.size
+        assert oracle.verify_mt(t, o) == 1
+        _sampled_neighbours_ordered(t, o, 5, samples=500)
+    assert sa.check_integrity(texts[2], outs[2]) is True
+    sa.lib().sa_amd_release_cache()
 
 
 # ---- next rows (SURVEY.md 8f): bucket table and integrity check --------------------------------

@@ -1,32 +1,28 @@
-"""End-to-end timing of the host-pointer entry point (sa_amd_saca_u8: hipMalloc + H2D + build + D2H)."""
-import sys, os, time
+"""End-to-end timing of the host-pointer entry point (sa_amd_saca_u8 = `saca()`, reference src/saca.rs:9-15) with the
+phase breakdown of sa_amd_last_host_timing.  Two callers' habits are timed: a REUSED output buffer (SuffixArray::set,
+src/sa.rs:30-33) and a FRESH zeroed one per call (SuffixArray::new, src/sa.rs:23-27: vec![0; n + 1], first touched by
+the download).  python tools/host_api_timing.py [workload ...]"""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import suffix_array_amd as sa
 from suffix_array_amd import corpus
-for name, n in (("c2_uniform_64m", None), ("c3_english_256m", None)):
+
+names = sys.argv[1:] or ["c2_uniform_64m", "c3_english_256m"]
+for name in names:
     t = corpus.workload(name)
     out = np.zeros(t.size + 1, dtype=np.uint32)
-    sa.saca(t, out)          # warm-up (context, code objects)
-    best = 1e9
-    for _ in range(3):
-        t0 = time.perf_counter(); sa.saca(t, out); best = min(best, time.perf_counter() - t0)
-    print(f"{name}: host-pointer end-to-end {best*1e3:.1f} ms = {t.size/1e6/best:.0f} MB/s (PCIe + allocation inclusive)")
-
-# batch entry point on one GPU: items alternate between host threads per device (SA_AMD_BATCH_THREADS);
-# output arrays allocated and touched beforehand (first-touch page faults are the caller's, not the library's)
-import ctypes
-texts = [corpus.workload("c2_uniform_64m", rank=r) for r in range(6)]
-outs = [np.zeros(t.size + 1, dtype=np.uint32) for t in texts]
-cnt = len(texts)
-T = (ctypes.c_void_p * cnt)(*[t.ctypes.data for t in texts])
-S = (ctypes.c_void_p * cnt)(*[o.ctypes.data for o in outs])
-N = (ctypes.c_int32 * cnt)(*[t.size for t in texts])
-stt = (ctypes.c_int32 * cnt)()
-L = sa.lib()
-for threads in ("1", "2", "3", "1", "2"):
-    os.environ["SA_AMD_BATCH_THREADS"] = threads
-    t0 = time.perf_counter(); rc = L.sa_amd_saca_batch(T, S, N, None, cnt, stt); dt = time.perf_counter() - t0
-    assert rc == 0
-    print(f"batch of {cnt} x 64 MiB, {threads} host thread(s) per device: {dt*1e3:.1f} ms = {sum(t.size for t in texts)/1e6/dt:.0f} MB/s end to end")
+    sa.saca(t, out)          # warm-up (context, code objects, pool)
+    for threads in ("0", "2", "4", "8"):
+        os.environ["SA_AMD_COPY_THREADS"] = threads
+        for mode in ("reused", "fresh"):
+            best, bt = 1e9, None
+            for _ in range(4):
+                if mode == "fresh":
+                    out = np.zeros(t.size + 1, dtype=np.uint32)      # calloc: untouched pages, like vec![0; n + 1]
+                t0 = time.perf_counter(); sa.saca(t, out); dt = time.perf_counter() - t0
+                if dt < best:
+                    best, bt = dt, sa.last_host_timing()
+            print(f"{name} copy_threads={threads} {mode:6s}: {best*1e3:7.1f} ms = {t.size/1e6/best:6.0f} MB/s | "
+                  + " ".join(f"{k} {v:.1f}" for k, v in bt.items()), flush=True)
