@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- suffix-array construction throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one complete SuffixArray::new-equivalent build (device-resident text in, device
-resident SA out) of one synthetic text.  Default workload: the configuration the metric is
-quoted on, C3 = 256 MiB English-like text.  With N ranks every rank
-builds its own independent text (seed + rank) on its own GPU: weak scaling, no data-path
-collective; torch.distributed is used for the barrier and the
-max-over-ranks time only.
+A "step" is one complete SuffixArray::new-equivalent build (device-resident text in, device-resident SA out) of one
+synthetic text.  Default workload: the configuration the metric is quoted on, C3 = 256 MiB English-like corpus
+(BASELINE.md section 2).  With N ranks every rank builds its own independent text (seed + rank) on its own GPU: weak
+scaling, no data-path collective; torch.distributed carries the barrier and the max-over-ranks
+time only.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(torch.distributed.run, before this process touches a GPU); under an external torchrun it runs as one rank.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside the
-timed region; the other kernels' table `kernels` comes from one extra build outside it, so that
-their event records do not sit in the measured time) and `cpu_baseline` (the oracle's
-single-thread SA-IS on a bounded sample).
+Prints ONE JSON line on rank 0:
+  value / ms_per_step   device-resident builds, whole job (all ranks), timed as the contract says
+  roofline              dominant kernel, HIP-event timed on the launch stream inside the timed region
+  kernels               per-kernel table from one extra build outside the timed region
+  verified              sa_amd_check_integrity_device (reference src/sa.rs:72-84, linear time) on the last array of
+                        EVERY rank, outside the timed region -- always on
+  end_to_end            median of 5 sa_amd_saca_u8 calls on host buffers (what the reference's `SuffixArray::new`
+                        hands over: src/sa.rs:23-27): H2D + build + D2H, all ranks concurrently
+  batch_c5              (N > 1) BASELINE config 5: one 512 MiB uniform text per rank, device-resident and end to end
+  cpu_baseline          the oracle's single-thread SA-IS on a bounded sample (N = 1 only)
 """
 from __future__ import annotations
 
@@ -21,6 +27,8 @@ import argparse
 import ctypes
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -36,35 +44,57 @@ ALGO_BYTES = {"k_byte_hist": 1, "k_build_keys": 9, "k_radix_upsweep": 8, "k_radi
               "k_radix_upsweep32": 4, "k_radix_downsweep32": 16}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3_english_256m",
-                    help="c2_uniform_64m | c3_english_256m | c4_dna_1g | c5_uniform_512m")
-    ap.add_argument("--n", type=int, default=None, help="override the text length (bytes)")
-    ap.add_argument("--verify", action="store_true", help="check the last SA with the oracle's linear verifier")
-    ap.add_argument("--verify-gpu", action="store_true", help="check the last SA with the HIP integrity check (any n)")
+                    help="c2_uniform_64m | c2_uniform_256m | c3_english_256m | c3_iid_256m | c4_dna_1g | c5_uniform_512m")
+    ap.add_argument("--text-bytes", "--n", dest="n", type=int, default=None, help="override the text length (bytes)")
+    ap.add_argument("--verify-cpu", action="store_true", help="additionally check the last SA with the oracle's linear verifier")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="N > 1: skip the config-5 batch leg")
     ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload timed on the CPU")
-    return ap.parse_args()
+    ap.add_argument("--e2e-calls", type=int, default=5)
+    return ap.parse_args(argv)
 
+
+# ---- rank launcher ---------------------------------------------------------------------------------
+
+def spawn_ranks(args, argv):
+    """--gpus N without an external launcher: start N ranks with torch.distributed.run as a CHILD process (this
+    process has not touched the GPU and never does) and pass its output and exit code through."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    # (torch.distributed.run's own parser would read a bare `--n` as an abbreviation of its --nnodes / --nproc-per-node)
+    argv = ["--text-bytes" if a == "--n" else a for a in argv]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ---- CPU side --------------------------------------------------------------------------------------
 
 def load_oracle():
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(path):
-        import subprocess
         subprocess.check_call(["make", "-s", "all"], cwd=os.path.join(ROOT, "oracle"))
     orc = ctypes.CDLL(path)
     orc.oracle_sais.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
-    orc.oracle_verify_sa.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+    orc.oracle_verify_sa_mt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
     return orc
 
 
 def cpu_baseline(text, sample):
-    """oracle SA-IS (single thread) on the first `sample` bytes of the same text -- a reported
-    baseline only; kind 'port' because the reference's divsufsort cannot be built offline."""
+    """oracle SA-IS (single thread) on the first `sample` bytes of the same text -- a reported baseline only; kind
+    'port' because the reference's divsufsort (external crate cdivsufsort) cannot be built offline."""
     import numpy as np
     orc = load_oracle()
     t = np.ascontiguousarray(text[:sample])
@@ -78,121 +108,235 @@ def cpu_baseline(text, sample):
                       f"(stand-in: divsufsort unavailable offline); {dt:.1f} s"}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def host_info():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
 
+
+def corpus_facts(workload, n, text):
+    """mean / max LCP of the benchmark text (profiles/r02_corpus_stats.json: oracle SA-IS + Kasai on the full text,
+    tools/corpus_stats.py) and its order-0 entropy, computed here"""
     import numpy as np
-    import torch
-    import suffix_array_amd as sa
+    c = np.bincount(text, minlength=256)
+    p = c[c > 0] / max(text.size, 1)
+    facts = {"H0_bits_per_byte": round(float(-(p * np.log2(p)).sum()), 4), "mean_lcp": None, "max_lcp": None}
+    path = os.path.join(ROOT, "profiles", "r02_corpus_stats.json")
+    if os.path.exists(path):
+        for row in json.load(open(path)):
+            if row.get("workload") == workload and row.get("n_bytes") == n:
+                facts["mean_lcp"], facts["max_lcp"] = row["mean_lcp"], row["max_lcp"]
+                facts["frac_lcp_ge_32"] = row.get("frac_lcp_ge", {}).get("32")
+    return facts
+
+
+# ---- the GPU backend: everything that touches the device goes through the C ABI ----------------------
+
+class HipBackend:
+    """device memory and streams from torch (plumbing), construction through libsuffix_array_amd.so"""
+
+    def __init__(self, device_index):
+        import torch
+        import suffix_array_amd as sa
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+        self.torch, self.sa = torch, sa
+        torch.cuda.set_device(device_index)
+        self.dev = torch.device("cuda", device_index)
+        self.L = sa.lib()
+        self.stats = sa.Stats()
+        self.name = "hip"
+
+    def load(self, text_h):
+        torch, sa = self.torch, self.sa
+        self.n = int(text_h.size)
+        self.text = torch.from_numpy(text_h).to(self.dev)
+        self.out = torch.empty(self.n + 1, dtype=torch.int32, device=self.dev)
+        self.wbytes = sa.workspace_bytes(self.n)
+        self.work = torch.empty(self.wbytes, dtype=torch.uint8, device=self.dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def unload(self):
+        self.text = self.out = self.work = None
+        self.torch.cuda.empty_cache()
+
+    def step(self):
+        self.sa.saca_device_ptr(self.text.data_ptr(), self.out.data_ptr(), self.n, self.work.data_ptr(), self.wbytes,
+                                self.stream, self.stats)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def kernel_names(self):
+        names = []
+        while True:
+            nm = self.L.sa_amd_profile_kernel_name(len(names)).decode()
+            if not nm:
+                return names
+            names.append(nm)
+
+    def profile_begin(self, mask):
+        self.L.sa_amd_profile_begin_classes(mask)
+
+    def profile_end(self):
+        cap = 32
+        ms, launches, units = (ctypes.c_double * cap)(), (ctypes.c_int64 * cap)(), (ctypes.c_int64 * cap)()
+        ncls = self.L.sa_amd_profile_end(ms, launches, units, cap)
+        return [(ms[i], launches[i], units[i]) for i in range(ncls)]
+
+    def verify(self):
+        """reference src/sa.rs:72-84 in linear time on the device (k_ci_scatter / k_ci_check), on the array the last
+        step left in HBM; outside the timed region"""
+        ci_bytes = 4 * (self.n + 1) + 256
+        ci_work = self.torch.empty(ci_bytes, dtype=self.torch.uint8, device=self.dev)
+        rc = self.L.sa_amd_check_integrity_device(self.text.data_ptr(), self.n, self.out.data_ptr(), ci_work.data_ptr(),
+                                                  ci_bytes, self.stream)
+        return rc == 1
+
+    def download(self):
+        import numpy as np
+        return self.out.cpu().numpy().view(np.uint32)
+
+    def build_host(self, text_h, out_h):
+        self.sa.saca(text_h, out_h)
+
+    def host_timing(self):
+        return self.sa.last_host_timing()
+
+    def stats_dict(self):
+        return self.stats.as_dict()
+
+    def ctl_device(self, share):
+        return self.torch.device("cpu") if share else self.dev
+
+
+def timed_steps(backend, barrier, steps, warmup, mask=0):
+    for _ in range(warmup):
+        backend.step()
+    backend.profile_begin(mask)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        backend.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    return dt, backend.profile_end()
+
+
+def end_to_end(backend, text_h, calls, barrier):
+    """host pointers in, host pointers out, as `saca()` is called by SuffixArray::new / ::set: one warm-up, then `calls`
+    timed calls into a REUSED output buffer (::set, src/sa.rs:30-33) and `calls` into a FRESH zeroed one each
+    (::new, src/sa.rs:23-27: vec![0; n + 1] is first touched by the download)"""
+    import numpy as np
+    n = int(text_h.size)
+    out = np.zeros(n + 1, dtype=np.uint32)
+    backend.build_host(text_h, out)
+    res = {}
+    for mode in ("reused_buffer", "fresh_buffer"):
+        times, phases = [], None
+        for _ in range(calls):
+            if mode == "fresh_buffer":
+                out = np.zeros(n + 1, dtype=np.uint32)
+            barrier()
+            t0 = time.perf_counter()
+            backend.build_host(text_h, out)
+            times.append(time.perf_counter() - t0)
+            phases = backend.host_timing()
+        med = statistics.median(times)
+        res[mode] = {"ms": round(med * 1e3, 3), "MB_per_s": round(n / 1e6 / med, 1),
+                     "phases_ms_last_call": {k: round(v, 2) for k, v in (phases or {}).items()}}
+    res["ok"] = bool(out[0] == n)
+    return res
+
+
+def run(args, backend, rank, world, dist=None, share=False):
+    """one rank of the benchmark; returns the result dict on rank 0 (None elsewhere).  `backend` is the HipBackend; the
+    world-size-2 CPU test of tests/test_dist.py injects its own object with the same methods."""
+    import numpy as np
     from suffix_array_amd import corpus
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    # rehearsal on a one-GPU box: SA_BENCH_SHARE_GPU=1 puts every rank on device 0 and uses gloo for the
-    # control plane (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank + nccl
-    share = os.environ.get("SA_BENCH_SHARE_GPU") == "1"
-    dev_index = 0 if share else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    ctl_dev = dev
-    if world > 1:
-        import torch.distributed as dist
-        if share:
-            dist.init_process_group(backend="gloo")
-            ctl_dev = torch.device("cpu")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+    def barrier():
+        backend.sync()
+        if dist is not None:
+            dist.barrier()
+        backend.sync()
+
+    def reduce(value, op):
+        if dist is None:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=torch.float64, device=backend.ctl_device(share))
+        dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
+        return float(t.item())
 
     # ---- synthetic input, resident in HBM before the timed region ----
     text_h = corpus.workload(args.workload, rank=rank, n_override=args.n)
     n = int(text_h.size)
-    text = torch.from_numpy(text_h).to(dev)
-    out = torch.empty(n + 1, dtype=torch.int32, device=dev)
-    wbytes = sa.workspace_bytes(n)
-    work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    stats = sa.Stats()
-
-    def step():
-        sa.saca_device_ptr(text.data_ptr(), out.data_ptr(), n, work.data_ptr(), wbytes, stream, stats)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    L = sa.lib()
-    L.sa_amd_profile_begin_classes.argtypes = [ctypes.c_uint64]
-    L.sa_amd_profile_begin_classes.restype = None
-    names = []
-    while True:
-        nm = L.sa_amd_profile_kernel_name(len(names)).decode()
-        if not nm:
-            break
-        names.append(nm)
+    backend.load(text_h)
+    names = backend.kernel_names()
     dom_mask = sum(1 << i for i, nm in enumerate(names) if nm in DOMINANT)
-    # timed region: HIP events (on the launch stream) around the launches of the dominant kernel only -- an event pair around
-    # each of the ~150 launches of a build costs ~0.7 ms of host time per step; the other kernels are timed below
-    L.sa_amd_profile_begin_classes(dom_mask)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    cap = 32
-    ms = (ctypes.c_double * cap)()
-    launches = (ctypes.c_int64 * cap)()
-    units = (ctypes.c_int64 * cap)()
-    ncls = L.sa_amd_profile_end(ms, launches, units, cap)
+    # timed region: HIP events (on the launch stream) around the launches of the dominant kernel only -- an event pair
+    # around each of the ~150 launches of a build costs ~0.7 ms of host time per step; the other kernels are timed below
+    dt, prof = timed_steps(backend, barrier, args.steps, args.warmup, dom_mask)
+    dt = reduce(dt, "MAX")
+    stats = backend.stats_dict()
     # per-kernel table: one extra, untimed build with events around every launch
-    ms_all = (ctypes.c_double * cap)()
-    launches_all = (ctypes.c_int64 * cap)()
-    units_all = (ctypes.c_int64 * cap)()
-    L.sa_amd_profile_begin()
-    step()
-    torch.cuda.synchronize()
-    L.sa_amd_profile_end(ms_all, launches_all, units_all, cap)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    verified = None
-    if args.verify:
+    backend.profile_begin(~0 & 0xFFFFFFFFFFFFFFFF)
+    backend.step()
+    backend.sync()
+    prof_all = backend.profile_end()
+    # correctness gate of every run, outside the timed region: every rank's last array
+    ok = bool(backend.verify())
+    if args.verify_cpu:
         orc = load_oracle()
-        got = out.cpu().numpy().view(np.uint32)
-        verified = bool(orc.oracle_verify_sa(text_h.ctypes.data, n, got.ctypes.data, n + 1) == 1)
+        got = backend.download()
+        ok = ok and orc.oracle_verify_sa_mt(text_h.ctypes.data, n, got.ctypes.data, n + 1, 16) == 1
+    verified = reduce(1.0 if ok else 0.0, "MIN") == 1.0
 
-    if args.verify_gpu:
-        ci_bytes = 4 * (n + 1) + 256
-        ci_work = torch.empty(ci_bytes, dtype=torch.uint8, device=dev)
-        L.sa_amd_check_integrity_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
-                                                    ctypes.c_int64, ctypes.c_void_p]
-        L.sa_amd_check_integrity_device.restype = ctypes.c_int32
-        rc = L.sa_amd_check_integrity_device(text.data_ptr(), n, out.data_ptr(), ci_work.data_ptr(), ci_bytes, stream)
-        verified = bool(rc == 1) if verified is None else (verified and rc == 1)
+    e2e = None
+    if not args.no_end_to_end:
+        e = end_to_end(backend, text_h, args.e2e_calls, barrier)
+        # whole job: all ranks run their calls concurrently (shared PCIe switches / host DRAM are part of the figure)
+        e2e = {}
+        for mode in ("reused_buffer", "fresh_buffer"):
+            ms = reduce(e[mode]["ms"], "MAX")
+            e2e[mode] = {"ms": round(ms, 3), "MB_per_s": round(world * n / 1e3 / ms, 1),
+                         "phases_ms_rank0_last_call": e[mode]["phases_ms_last_call"]}
+        e2e["calls"] = args.e2e_calls
+        e2e["what"] = "median wall time of sa_amd_saca_u8 (host text in, host SA out: n bytes up, 4(n+1) bytes down), max over ranks"
+
+    batch = None
+    if world > 1 and not args.no_batch:
+        # BASELINE config 5: one independent 512 MiB uniform text per rank (seeds 50 + rank), no collective
+        backend.unload()
+        t5 = corpus.workload("c5_uniform_512m", rank=rank, n_override=args.n)
+        backend.load(t5)
+        dt5, _ = timed_steps(backend, barrier, max(args.steps // 2, 2), 1)
+        dt5 = reduce(dt5, "MAX")
+        ok5 = reduce(1.0 if backend.verify() else 0.0, "MIN") == 1.0
+        e5 = end_to_end(backend, t5, 3, barrier)
+        ms5 = reduce(e5["reused_buffer"]["ms"], "MAX")
+        k5 = max(args.steps // 2, 2)
+        batch = {"workload": f"c5_uniform_512m: {t5.size} bytes per GPU, seeds 50 + rank", "texts": world,
+                 "device_resident": {"ms_per_text": round(dt5 / k5 * 1e3, 3), "MB_per_s": round(world * t5.size / 1e6 / (dt5 / k5), 1)},
+                 "end_to_end": {"ms_per_text": round(ms5, 3), "MB_per_s": round(world * t5.size / 1e3 / ms5, 1)},
+                 "verified": ok5}
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
-    kernels = {}                      # from the extra build (one step)
-    for i in range(ncls):
-        name = L.sa_amd_profile_kernel_name(i).decode()
-        if launches_all[i]:
-            kernels[name] = {"ms_per_step": round(ms_all[i], 3), "launches_per_step": float(launches_all[i]),
-                             "units_per_step": int(units_all[i])}
-    d_ms, d_launch, d_units, dom = max((ms[i], launches[i], units[i], L.sa_amd_profile_kernel_name(i).decode())
-                                       for i in range(ncls) if L.sa_amd_profile_kernel_name(i).decode() in DOMINANT)
+    kernels = {}
+    for i, (ms, launches, units) in enumerate(prof_all):
+        if launches:
+            kernels[names[i]] = {"ms_per_step": round(ms, 3), "launches_per_step": float(launches), "units_per_step": int(units)}
+    cand = [(prof[i][0], prof[i][1], prof[i][2], names[i]) for i in range(len(prof)) if names[i] in DOMINANT]
+    d_ms, d_launch, d_units, dom = max(cand) if cand else (0.0, 0, 0, DOMINANT[0])
     avg_ms = d_ms / max(d_launch, 1)
     achieved = (ALGO_BYTES[dom] * d_units) / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
     # HBM traffic of the dominant kernel from the committed PMC passes of this same command (if any)
@@ -203,8 +347,9 @@ def main():
         if tj.get("workload") == args.workload and tj.get("n_bytes") == n and dom in tj.get("kernels", {}):
             traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
     per_step = dt / args.steps
-    device_ms = sum(ms_all[i] for i in range(ncls))
+    device_ms = sum(ms for ms, _, _ in prof_all)
     job_gbs = (5 * n + 4) / per_step / 1e9
+    facts = corpus_facts(args.workload, n, text_h)
     result = {
         "metric": "input MB/s indexed (SA build)",
         "value": round(world * n / 1e6 / per_step, 3),
@@ -219,28 +364,60 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {n} bytes per GPU, seed base + rank, one independent text per GPU",
-                   "n_bytes": n, "sigma": stats.sigma, "bits_per_symbol": stats.bits_per_symbol,
-                   "symbols_per_key": stats.symbols_per_key, "doubling_rounds": stats.rounds,
-                   "radix_passes": stats.sort_passes, "unresolved_after_initial_sort": stats.unresolved_after_initial},
+                   "n_bytes": n, "sigma": stats["sigma"], "bits_per_symbol": stats["bits_per_symbol"],
+                   "symbols_per_key": stats["symbols_per_key"], "refinement_rounds": stats["rounds"],
+                   "text_rounds": stats["text_rounds"], "radix_passes": stats["sort_passes"],
+                   "unresolved_after_initial_sort": stats["unresolved_after_initial"], **facts},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": round(ALGO_BYTES[dom] * d_units / max(d_launch, 1)),
                      "algorithmic_bytes_per_element": ALGO_BYTES[dom], "avg_launch_ms": round(avg_ms, 4),
-                     "launches_per_step": d_launch / args.steps,
+                     "launches_per_step": d_launch / max(args.steps, 1),
                      "whole_job": {"algorithmic_bytes": 5 * n + 4, "achieved": round(job_gbs, 3),
                                    "frac": round(job_gbs / HBM_PEAK_GBS, 6)}},
         "kernels": kernels,
         "device_ms_per_step": round(device_ms, 3),
         "verified": verified,
+        "end_to_end": e2e,
+        "batch_c5": batch,
+        "host": host_info(),
     }
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(text_h, min(args.cpu_sample, n))
     else:
         result["cpu_baseline"] = None
-    print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    return result
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)                       # (nothing above this line initialises the GPU)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal on a one-GPU box: SA_BENCH_SHARE_GPU=1 puts every rank on device 0 and uses gloo for the
+    # control plane (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank + nccl
+    share = os.environ.get("SA_BENCH_SHARE_GPU") == "1"
+    backend = HipBackend(0 if share else local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=backend.dev)
+    try:
+        result = run(args, backend, rank, world, dist, share)
+        if result is not None:
+            print(json.dumps(result), flush=True)
+    finally:
+        if dist is not None:
+            dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -201,7 +201,7 @@ static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipSt
                 if (hipEventSynchronize(ev[c % STAGE_COUNT]) != hipSuccess) {
                     std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); return;
                 }
-                const size_t L = len(c), per = ((L / T) + 4095) & ~(size_t)4095;
+                const size_t L = len(c), per = (((L + T - 1) / T) + 4095) & ~(size_t)4095;     // whole pages per helper, the last one takes the rest
                 const size_t b = (size_t)t * per, e = b + per < L ? b + per : L;
                 if (b < e) memcpy((char *)dst_host + c * STAGE_BYTES + b, (const char *)stage[c % STAGE_COUNT].p + b, e - b);
                 { std::lock_guard<std::mutex> lk(mu); ++drained[c]; }

@@ -266,18 +266,18 @@ static bool binned(int64_t n, int64_t count, const Tuning &tn)
     return n >= ((int64_t)1 << 25) && count >= ((int64_t)1 << 22);
 }
 
-// (suffix, rank) pairs -> one radix pass on the top 8 bits of the suffix position -> windowed scatter
-static int scatter_binned(uint64_t *pk, uint32_t *pv, uint64_t *altk, uint32_t *altv, int64_t count, int64_t n,
-                          const Workspace &w, hipStream_t st, sa_amd_stats *local, const Tuning &tn)
+// (suffix, rank) pairs (both 32 bits) -> one radix pass on the top 8 bits of the suffix position -> windowed scatter
+static int scatter_binned(uint32_t *pk, uint32_t *pv, uint32_t *altk, uint32_t *altv, int64_t count, int64_t n,
+                          const Workspace &w, hipStream_t st, sa_amd_stats *local, const Tuning &tn, bool iota = false)
 {
-    const int nb = bit_length((uint64_t)(n - 1));
+    const int nb = bit_length((uint64_t)(n > 1 ? n : 1));          // (the sentinel value n may be among the keys)
     const int shift = nb > RADIX_BITS ? nb - RADIX_BITS : 0;
-    SortResult pr;
-    int rc = sort_pairs(pk, pv, altk, altv, count, shift, shift + RADIX_BITS, w.spine, w.digit_tot, nullptr, st, &pr, tn);
+    SortResult32 pr;
+    int rc = sort_pairs32(pk, pv, altk, altv, count, shift, shift + RADIX_BITS, w.spine, w.digit_tot, nullptr, st, &pr, tn, iota);
     if (rc) return rc;
     local->sort_passes += pr.passes; local->sorted_elements += (int64_t)pr.passes * count;
-    PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_pairs), dim3((unsigned)ceil_div(count, 1024)), dim3(256), 0, st,
-                                                   (const uint64_t *)pr.keys, (const uint32_t *)pr.vals, w.isa, count, (uint32_t)n));
+    PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_pairs<uint32_t>), dim3((unsigned)ceil_div(count, 1024)), dim3(256), 0, st,
+                                                   (const uint32_t *)pr.keys, (const uint32_t *)pr.vals, w.isa, count, (uint32_t)n));
     return SA_AMD_OK;
 }
 
@@ -376,6 +376,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
 {
     const int64_t n = n32;
     const Tuning tn = Tuning::from_env(N_SORT_VARIANTS, N_SORT32_VARIANTS);
+    const bool trace = env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 3;      // one line per refinement round on stderr
     sa_amd_stats local;
     memset(&local, 0, sizeof(local));
     if (n == 0) {
@@ -657,7 +658,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
                                                         SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total, 0));
-            rc = scatter_binned(pk, w.U1, sr.keys, w.G1, n, n, w, st, &local, tn);
+            rc = scatter_binned((uint32_t *)pk, w.U1, (uint32_t *)sr.keys, w.G1, n, n, w, st, &local, tn);
             if (rc) return rc;
         } else {
             PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
@@ -708,12 +709,22 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             local.text_rounds++;
             local.rounds++;
             progressing = m * 4 <= m_before * 3;
+            if (trace) fprintf(stderr, "suffix_array_amd: text round %d depth %lld: tied %lld -> %lld\n", local.text_rounds, (long long)depth, (long long)m_before, (long long)m);
         }
         if (m > sparse_limit) {
             // still many ties (repetitive text): build the ISA of the current order and double densely
             int64_t blocks = ceil_div(n, 256);
             if (blocks > 16384) blocks = 16384;
-            PROF(KC_SCATTER, n, st, hipLaunchKernelGGL((k_isa_from_sa), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)SA, w.isa, n));
+            if (binned(n, n, tn) && (((uintptr_t)dSA) & 15) == 0) {
+                // inverse permutation without n random 4-byte stores: dSA[0 .. n] itself is the key array (dSA[0] = n, the
+                // sentinel, is skipped by the scatter), the value is the index = rank; one 32-bit radix pass bins the pairs by
+                // the top 8 bits of the suffix position, the scatter then works window by window (10.0 -> ~2.5 ms at 256 MiB)
+                hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);
+                LAUNCH_CHECK(st);
+                rc = scatter_binned(dSA, nullptr, (uint32_t *)rkB, (uint32_t *)rkA, n + 1, n, w, st, &local, tn, true);
+                if (rc) return rc;
+            } else
+                PROF(KC_SCATTER, n, st, hipLaunchKernelGGL((k_isa_from_sa), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)SA, w.isa, n));
             blocks = ceil_div(m, 256);
             if (blocks > 16384) blocks = 16384;
             PROF(KC_SCATTER, m, st, hipLaunchKernelGGL((k_isa_tied), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)Vcur,
@@ -754,7 +765,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
                                                         (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total, 0));
-            rc = scatter_binned(pk, Gcur, (uint64_t *)keysS, (uint32_t *)valsS, m, n, w, st, &local, tn);
+            rc = scatter_binned((uint32_t *)pk, Gcur, (uint32_t *)keysS, (uint32_t *)valsS, m, n, w, st, &local, tn);
             if (rc) return rc;
         } else {
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
@@ -763,6 +774,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                         (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
         }
         { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+        if (trace) fprintf(stderr, "suffix_array_amd: doubling round %d h %lld (%s): tied %lld -> %u\n", local.rounds + 1, (long long)h, sparse ? "sparse" : "dense", (long long)m, m32);
         m = m32;
         uint32_t *t;
         t = Ucur; Ucur = Unext; Unext = t;

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void k_isa_tied(const uint32_t *__restrict__ V
 
 // ISA[suffix] = rank for pairs that one radix pass has binned by suffix position: consecutive
 // pairs fall into the same few-MiB window of the ISA, so the stores merge in L2 / Infinity Cache.
-__global__ __launch_bounds__(256) void k_scatter_pairs(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pv,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_scatter_pairs(const KeyT *__restrict__ pk, const uint32_t *__restrict__ pv,
                                                         uint32_t *__restrict__ ISA, int64_t count, uint32_t n_text)
 {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;

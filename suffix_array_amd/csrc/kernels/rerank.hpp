@@ -203,7 +203,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         if (i < m) {
             if (WRITE_SA && slot[r] < n_text) SA[slot[r]] = v[r];
             if (ISA_MODE == 2) {
-                pair_k[i] = (uint64_t)v[r];
+                ((uint32_t *)pair_k)[i] = v[r];          // (suffix, rank) as 32-bit pairs: binned by one 32-bit radix pass
                 pair_v[i] = run;
             } else if (ISA_MODE != 3 && ISA_MODE != 4 && v[r] < n_text) {
                 // refinement rounds: the key's high part is the old group head, i.e. the rank already in ISA;

@@ -161,7 +161,9 @@ GEN_API int32_t sa_gen_english(uint8_t *out, int64_t n, uint64_t seed, int32_t v
  *   2. word-bigram structure: every word has 8 preferred successors; with probability 0.5 the next word is one of them;
  *   3. a pool of 20 000 stock sentences (5-24 words); 3 % of the sentences are drawn from it;
  *   4. passages copied from earlier text: length Pareto(1.1) from 200 bytes to min(4 MiB, n / 8), about `dup_fraction`
- *      of the text, each copy with a word-substitution rate of 0 (exact), 1e-4, 1e-3 or 1e-2 per byte.
+ *      of the text, each copy with a word-substitution rate of 0 (exact), 1e-4, 1e-3 or 1e-2 per byte;
+ *   5. two "second printings": at 55 % of the text a passage of n / 256 bytes is repeated verbatim, at 80 % one of
+ *      n / 128 bytes with one substituted word per 100 000 bytes (what gives the real file its maximum LCP near 10^6).
  * Statistics of the benchmark instance (256 MiB, seed 3) are measured, not assumed: profiles/r02_corpus_stats.json.
  */
 typedef struct {
@@ -283,8 +285,10 @@ GEN_API int32_t sa_gen_english_corpus(uint8_t *out, int64_t n, uint64_t seed, in
     const double p_copy = (mean_len > 0 && dup_fraction > 0) ? (dup_fraction / (1.0 - dup_fraction)) * mean_sentence / mean_len : 0.0;
     int64_t i = 0;
     int32_t prev = -1;
+    int printings = 0;                              /* layer 5: done so far */
     while (i < n) {
-        if (i > 4 * lmin && lmax > lmin && rng_unit(&m.r) < p_copy) {
+        const int reprint = (n >= ((int64_t)1 << 20)) && ((printings == 0 && i >= n / 100 * 55) || (printings == 1 && i >= n / 100 * 80));
+        if (reprint || (i > 4 * lmin && lmax > lmin && rng_unit(&m.r) < p_copy)) {
             /* passage copied from earlier text, with word substitutions */
             const double u = rng_unit(&m.r);
             const double a = 1.1, lo_a = pow((double)lmin, -a), hi_a = pow((double)lmax, -a);
@@ -293,7 +297,13 @@ GEN_API int32_t sa_gen_english_corpus(uint8_t *out, int64_t n, uint64_t seed, in
             if (L < lmin) L = lmin;
             int64_t src = (int64_t)(rng_next(&m.r) % (uint64_t)(i - L + 1));
             static const double rates[4] = { 0.0, 1e-4, 1e-3, 1e-2 };
-            const double rate = rates[rng_next(&m.r) & 3];
+            double rate = rates[rng_next(&m.r) & 3];
+            if (reprint) {
+                L = printings == 0 ? n / 256 : n / 128;
+                src = printings == 0 ? n / 10 : n / 10 * 3;
+                rate = printings == 0 ? 0.0 : 1e-5;
+                ++printings;
+            }
             const int64_t end_src = src + L;
             int64_t next_edit = rate > 0 ? src + (int64_t)(-log(1.0 - rng_unit(&m.r)) / rate) : end_src + 1;
             while (src < end_src && i < n) {

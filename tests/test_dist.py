@@ -1,7 +1,13 @@
-"""CPU suite: the N > 1 path (sharding of independent texts over ranks, barrier + max-over-ranks
-timing, summed bytes) under torch.distributed with the gloo backend, world size 2.  The builder
-injected here is the CPU oracle -- the host logic is what is under test; the GPU builder is
-covered by the -m gpu suite."""
+"""CPU suite: the N > 1 path of bench.py itself -- rank launcher, per-rank independent texts (weak scaling, no data-path
+collective: SURVEY.md section 8e), barrier + max-over-ranks timing, whole-job aggregation, the config-5 batch leg --
+under torch.distributed with the gloo backend, world size 2.
+
+bench.run() takes the object that touches the device as a parameter.  The real one (bench.HipBackend) needs a GPU; here
+a stand-in DEFINED IN THIS TEST FILE builds the arrays with the CPU oracle, so that the host logic of the benchmark can
+run without a GPU.  Nothing of the kind exists in bench.py or in the package: the product path has no CPU builder.  The
+same code with the real backend and two ranks is exercised on the GPU box by
+tests/test_gpu_parity.py::test_bench_two_ranks_share_one_gpu."""
+import json
 import os
 import socket
 import sys
@@ -20,31 +26,75 @@ def _free_port():
     return p
 
 
+class OracleStandIn:
+    """test double for bench.HipBackend: same methods, arrays from the oracle"""
+    name = "oracle stand-in (tests/test_dist.py)"
+
+    def __init__(self):
+        from conftest import Oracle
+        self.orc = Oracle()
+        self.builds = 0
+
+    def load(self, text_h):
+        self.text, self.n, self.out = text_h, int(text_h.size), None
+
+    def unload(self):
+        self.text = self.out = None
+
+    def step(self):
+        self.out = self.orc.sais(self.text)
+        self.builds += 1
+
+    def sync(self):
+        pass
+
+    def kernel_names(self):
+        return ["k_radix_downsweep", "k_radix_downsweep32"]
+
+    def profile_begin(self, mask):
+        self.mask = mask
+
+    def profile_end(self):
+        return [(2.0, 4, 4 * self.n), (0.0, 0, 0)]
+
+    def verify(self):
+        return self.orc.verify(self.text, self.out) == 1
+
+    def download(self):
+        return self.out
+
+    def build_host(self, text_h, out_h):
+        out_h[:] = self.orc.sais(text_h)
+
+    def host_timing(self):
+        return {"h2d": 0.0, "build": 0.0, "d2h": 0.0}
+
+    def stats_dict(self):
+        return {"sigma": 256, "bits_per_symbol": 8, "symbols_per_key": 8, "rounds": 0, "text_rounds": 0, "sort_passes": 4,
+                "unresolved_after_initial": 0}
+
+    def ctl_device(self, share):
+        import torch
+        return torch.device("cpu")
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
-    from conftest import Oracle
-    from suffix_array_amd import batch, corpus
+    import bench
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    orc = Oracle()
-    texts = [corpus.uniform(20_000 + 1000 * i, 50 + i) for i in range(5)]
-    out, nbytes, dt = batch.run_sharded(texts, orc.sais, dist)
-    ok = all(orc.verify(texts[i], sa) == 1 for i, sa in out.items())
-    q.put((rank, sorted(out), nbytes, dt, ok))
+    args = bench.parse(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "c2_uniform_64m", "--n", "40000",
+                        "--e2e-calls", "2"])
+    backend = OracleStandIn()
+    res = bench.run(args, backend, rank, world, dist, share=True)
+    q.put((rank, res, backend.builds))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_shard_assignment():
-    from suffix_array_amd import batch
-    assert batch.shard(8, 8, 3) == [3]
-    assert batch.shard(5, 2, 0) == [0, 2, 4] and batch.shard(5, 2, 1) == [1, 3]
-    assert sorted(sum((batch.shard(11, 4, r) for r in range(4)), [])) == list(range(11))
-
-
-def test_world_size_2_gloo():
+def test_world_size_2_gloo_runs_bench_rank_logic():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -52,19 +102,60 @@ def test_world_size_2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, idx0, b0, t0, ok0), (r1, idx1, b1, t1, ok1) = res
-    assert idx0 == [0, 2, 4] and idx1 == [1, 3] and ok0 and ok1
-    assert b0 == b1 == sum(20_000 + 1000 * i for i in range(5))      # whole-job bytes on every rank
-    assert t0 == t1 > 0                                               # max over ranks, identical everywhere
+    (r0, out0, b0), (r1, out1, b1) = res
+    assert out1 is None and out0 is not None                 # one JSON line, from rank 0
+    assert out0["n_gpus"] == 2 and out0["steps"] == 3 and out0["scaling"] == "weak" and out0["verified"] is True
+    n = 40000
+    # whole-job value: both ranks' bytes over the max-over-ranks time
+    assert out0["value"] == pytest.approx(2 * n / 1e6 / (out0["ms_per_step"] / 1e3), rel=1e-3)
+    assert out0["config"]["n_bytes"] == n and out0["cpu_baseline"] is None
+    assert out0["end_to_end"]["reused_buffer"]["MB_per_s"] > 0 and out0["end_to_end"]["fresh_buffer"]["ms"] > 0
+    assert out0["batch_c5"]["texts"] == 2 and out0["batch_c5"]["verified"] is True
+    assert out0["roofline"]["kernel"] == "k_radix_downsweep" and out0["roofline"]["bound"] == "hbm"
+    json.dumps(out0)                                          # serialisable as the one line the driver reads
+    assert b0 == b1 and b0 >= 1 + 3 + 1                       # warm-up + timed + the extra profiled build, on every rank
 
 
-def test_single_process_path(oracle):
-    from suffix_array_amd import batch, corpus
-    texts = [corpus.dna(3000, 1), corpus.uniform(10, 2)]
-    out, nbytes, dt = batch.run_sharded(texts, oracle.sais)
-    assert sorted(out) == [0, 1] and nbytes == 3010 and dt > 0
-    assert np.array_equal(out[1], oracle.naive(texts[1]))
+def test_single_rank_path_with_stand_in():
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse(["--steps", "2", "--warmup", "0", "--workload", "c4_dna_1g", "--n", "30000", "--cpu-sample", "20000",
+                        "--e2e-calls", "1"])
+    out = bench.run(args, OracleStandIn(), 0, 1)
+    assert out["n_gpus"] == 1 and out["verified"] is True and out["batch_c5"] is None
+    assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port"
+    assert out["host"]["nproc"] >= 1 and "H0_bits_per_byte" in out["config"]
+
+
+def test_gpus_flag_starts_the_ranks_itself(monkeypatch):
+    """`python bench.py --gpus 2` without WORLD_SIZE launches torch.distributed.run as a child process and never builds a
+    backend (= never touches the GPU) in the parent"""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(bench, "HipBackend", lambda *a, **k: (_ for _ in ()).throw(AssertionError("parent touched the GPU")))
+    assert bench.main(["--gpus", "2", "--steps", "4"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "4"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_per_rank_texts_are_independent():
+    from suffix_array_amd import corpus
+    a, b = corpus.workload("c5_uniform_512m", rank=0, n_override=5000), corpus.workload("c5_uniform_512m", rank=1, n_override=5000)
+    assert a.size == b.size == 5000 and not np.array_equal(a, b)
+    assert np.array_equal(a, corpus.workload("c5_uniform_512m", rank=0, n_override=5000))       # seeded: reproducible

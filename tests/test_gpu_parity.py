@@ -155,6 +155,24 @@ def test_medium_sizes_bit_exact(oracle, gen, n, seed):
     assert np.array_equal(build(text), oracle.sais(text))
 
 
+@pytest.mark.parametrize("n", [(16 << 20) - 1, 16 << 20, (16 << 20) + 1, (20 << 20) + 4099])
+def test_staged_download_sizes(oracle, monkeypatch, n):
+    """the suffix array of a large text travels back through pinned staging chunks split over helper threads: sizes around
+    the chunk boundaries (a last chunk of 4 bytes, a ragged one), few and many helpers, and the plain-copy route"""
+    text = corpus.uniform(n, 12)
+    exp = oracle.sais(text)
+    for threads in ("8", "3", "1", "0"):
+        monkeypatch.setenv("SA_AMD_COPY_THREADS", threads)
+        monkeypatch.setenv("SA_AMD_STAGED_MIN_BYTES", "0" if threads == "3" else str(64 << 20))
+        out = np.full(n + 1, 0xFFFFFFFF, dtype=np.uint32)
+        sa.saca(text, out)
+        assert np.array_equal(out, exp), (n, threads)
+        assert sa.last_host_timing()["staged_threads"] == (int(threads) if (n + 1) * 4 >= (64 << 20) or threads == "3" else 0)
+    div = np.full(n, -1, dtype=np.int32)
+    sa.divsufsort(text, div)                      # n entries, no sentinel slot: nothing may be written past them
+    assert np.array_equal(div.astype(np.uint32), exp[1:])
+
+
 def test_batch_entry_point(oracle):
     texts = [corpus.uniform(50_000, 50 + i) for i in range(3)] + [np.zeros(0, dtype=np.uint8), corpus.dna(30_000, 1)]
     outs = sa.saca_batch(texts)
@@ -485,6 +503,30 @@ def test_c5_batch_of_512m_texts(oracle):
         _sampled_neighbours_ordered(t, o, 5, samples=500)
     assert sa.check_integrity(texts[2], outs[2]) is True
     sa.lib().sa_amd_release_cache()
+
+
+# ---- bench.py: the N > 1 path with the real backend, two ranks rehearsed on this one GPU --------------
+
+def test_bench_two_ranks_share_one_gpu():
+    """`python bench.py --gpus 2` starts its own ranks (torch.distributed.run, gloo control plane because both ranks sit on
+    device 0: SA_BENCH_SHARE_GPU=1), every rank builds its own text through libsuffix_array_amd.so, both arrays are
+    verified on the device, and rank 0 prints one JSON line for the whole job"""
+    import subprocess
+    import sys
+    env = dict(os.environ, SA_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                           "--workload", "c2_uniform_64m", "--n", str(8 << 20), "--e2e-calls", "2"],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["verified"] is True and out["config"]["n_bytes"] == 8 << 20
+    assert out["value"] == pytest.approx(2 * (8 << 20) / 1e6 / (out["ms_per_step"] / 1e3), rel=1e-3)
+    assert out["batch_c5"]["verified"] is True and out["batch_c5"]["texts"] == 2
+    assert out["end_to_end"]["reused_buffer"]["MB_per_s"] > 0
+    assert out["roofline"]["kernel"].startswith("k_radix_downsweep") and out["roofline"]["achieved"] > 0
 
 
 # ---- next rows (SURVEY.md 8f): bucket table and integrity check --------------------------------

@@ -25,7 +25,7 @@ static void par_memcpy(char *dst, const char *src, size_t bytes, int T)
 {
     if (T <= 1) { memcpy(dst, src, bytes); return; }
     std::vector<std::thread> th;
-    const size_t per = (bytes / T + 4095) & ~(size_t)4095;
+    const size_t per = ((bytes + T - 1) / T + 4095) & ~(size_t)4095;
     for (int t = 0; t < T; ++t) {
         const size_t b = (size_t)t * per, e = b + per < bytes ? b + per : bytes;
         if (b >= e) break;
