@@ -151,6 +151,25 @@ ORACLE_API int32_t oracle_lcp_stats(const uint8_t *s, int64_t n, const uint32_t 
     return 0;
 }
 
+/* the LCP array itself (lcp[i] = LCP of the suffixes at SA slots i-1 and i, lcp[0] = lcp[1] = 0): tools/ only */
+ORACLE_API int32_t oracle_lcp_array(const uint8_t *s, int64_t n, const uint32_t *sa, uint32_t *lcp)
+{
+    if (n < 0) return -1;
+    uint32_t *rank = (uint32_t *)malloc(((size_t)n + 1) * sizeof(uint32_t));
+    if (!rank) return -2;
+    for (int64_t i = 0; i <= n; ++i) rank[sa[i]] = (uint32_t)i;
+    lcp[0] = 0;
+    int64_t h = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = rank[i], j = sa[r - 1];
+        while (i + h < n && j + h < n && s[i + h] == s[j + h]) ++h;
+        lcp[r] = (uint32_t)h;
+        if (h > 0) --h;
+    }
+    free(rank);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* the same linear-time check on `threads` host threads, for the        */
 /* full-size configs (1 GiB: four random accesses per entry).  The      */

@@ -7,7 +7,6 @@
 
 namespace sa {
 
-constexpr int MAX_TEXT_ROUNDS = 4;   // text-keyed rounds before falling back to rank doubling with a full ISA
 constexpr int SORT_MAX_WG = 1024;   // spine rows are scanned by one 1024-thread block
 static_assert(GROUP_CAP_MAX == GS_CAP, "Tuning clamps SA_AMD_GROUP_CAP to the kernel's cap");
 
@@ -258,12 +257,14 @@ static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)
     return SA_AMD_OK;
 }
 
-// binned ISA update pays off once the ISA is far larger than the caches and there is enough to write
+// Binned ISA writes (one radix pass on the top bits of the suffix position, then a windowed scatter) pay off once the ISA is
+// far larger than the caches: always for the full build (n entries), for a round's update only when it rewrites at least
+// binned_min entries (measured on C3: direct stores of the CHANGED ranks win below 64 M pairs)
 static bool binned(int64_t n, int64_t count, const Tuning &tn)
 {
     if (tn.no_binned_isa) return false;
     if (tn.binned_isa_always) return count > 0;      // tests: exercise the path at small sizes
-    return n >= ((int64_t)1 << 25) && count >= ((int64_t)1 << 22);
+    return n >= ((int64_t)1 << 25) && (count >= n || count >= tn.binned_min);
 }
 
 // (suffix, rank) pairs (both 32 bits) -> one radix pass on the top 8 bits of the suffix position -> windowed scatter
@@ -281,7 +282,7 @@ static int scatter_binned(uint32_t *pk, uint32_t *pv, uint32_t *altk, uint32_t *
     return SA_AMD_OK;
 }
 
-struct Refined { const uint64_t *keys; const uint32_t *vals; uint32_t *vnext; };
+struct Refined { const uint64_t *keys; const uint32_t *vals; uint32_t *vnext; int64_t m_global; };   // m_global: members ordered by the global sort
 
 // One refinement round of the tied list with a secondary key taken from the text (KeySrc): afterwards every
 // group is ordered by (group head << kb) | key2.  Small groups: gather fused with the in-LDS group sort
@@ -309,6 +310,9 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         else if (K.mode == KS_RANK)
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_RANK>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
                                                      Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+        else if (K.mode == KS_CHASE)
+            PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_CHASE>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
         else {
             // sparse look-up: its own kernel, one suffix per thread (a chain of ~60 dependent loads each), then the sort on those keys
             int64_t gblocks = ceil_div(m, GK_THREADS);
@@ -320,7 +324,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         }
         if (gs_blocks > 1)
             PROF(KC_LOCAL, 0, st, hipLaunchKernelGGL((k_group_sort_straddle), dim3(gs_blocks - 1), dim3(GX_THREADS), 0, st, rkA, Vcur, Gcur,
-                                                     Ucur, m, flags, cap));
+                                                     Ucur, m, flags, cap, K, n));
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     (const uint8_t *)flags, m, w.tcnt));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
@@ -341,7 +345,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
                                                                (const uint64_t *)sr.keys, (const uint32_t *)sr.vals,
                                                                (const uint32_t *)scratchU, m_big, rkA, Vcur));
             }
-            out->keys = rkA; out->vals = Vcur; out->vnext = Valt;
+            out->keys = rkA; out->vals = Vcur; out->vnext = Valt; out->m_global = m_big;
             local->locally_sorted += m - m_big;
             if (m_big * 2 > m) *local_ok = false;           // mostly large groups: not worth another local pass
             return SA_AMD_OK;
@@ -356,7 +360,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         else if (K.mode == KS_LOWKEY)
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_LOWKEY>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
-        else if (K.mode == KS_RANK)
+        else if (K.mode == KS_RANK || K.mode == KS_CHASE)
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_RANK>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
         else
@@ -366,7 +370,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
     rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, kb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn);
     if (rc) return rc;
     local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m;
-    out->keys = sr.keys; out->vals = sr.vals;
+    out->keys = sr.keys; out->vals = sr.vals; out->m_global = m;
     out->vnext = (sr.vals == Vcur) ? Valt : Vcur;
     return SA_AMD_OK;
 }
@@ -377,6 +381,8 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     const int64_t n = n32;
     const Tuning tn = Tuning::from_env(N_SORT_VARIANTS, N_SORT32_VARIANTS);
     const bool trace = env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 3;      // one line per refinement round on stderr
+    double trace_t = now_ms();
+    auto lap = [&]() { const double t = now_ms(), d = t - trace_t; trace_t = t; return d; };
     sa_amd_stats local;
     memset(&local, 0, sizeof(local));
     if (n == 0) {
@@ -434,6 +440,27 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         if (use) top_shift = key_bits - 32;
     }
     local.top32_first = top_shift ? 1 : 0;
+    // 2b. repeat probe (texts the first probe did not send to the 32-bit route): the fraction of suffixes that share
+    //     2k symbols with another suffix.  Many (copied passages, a corpus): the text-keyed rounds cannot finish, so rank
+    //     doubling starts right after the initial sort (measured on C3: 64 ms against 68 ms); few: text-keyed rounds.
+    bool probe_dense = false;
+    if (text_ok && local_ok && !top_shift && !force_dense && !tn.no_repeat_probe && n >= ((int64_t)1 << 24)) {
+        const int64_t S = (int64_t)1 << 20;
+        PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_repeat_keys), dim3((unsigned)ceil_div(S, GK_THREADS)), dim3(GK_THREADS), 0, st, dT, P, n, S,
+                                                w.keysA));
+        const uint32_t H = (uint32_t)S * 4u;
+        HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
+        HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
+        PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
+                                                (unsigned long long *)w.keysB, H - 1u, w.total));
+        uint32_t dups = 0;
+        { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
+        const double chance = (double)S * (double)S / 8589934592.0;           // 32-bit hash collisions among S samples
+        const double frac = ((double)dups - chance) * (double)n / ((double)S * (double)S);
+        probe_dense = frac > 0.04;
+        if (trace) fprintf(stderr, "suffix_array_amd: repeat probe: %u duplicates among %lld samples -> %.3f of the suffixes in long repeats -> %s\n",
+                           dups, (long long)S, frac, probe_dense ? "rank doubling from the start" : "text-keyed rounds");
+    }
 
     // 3. packed keys, 4. initial sort: all key bits as (u64 key, u32 suffix) pairs, or only the top 32 bits as
     //    (u32, u32) pairs in 12 Ki-element tiles -- two thirds of the bytes per pass and half the passes
@@ -650,7 +677,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     const int64_t sparse_div = tn.sparse_div;      // (SA_AMD_SPARSE_DIV moves the boundary for tests / A-B)
     const int64_t sparse_limit = n / sparse_div;
     bool sparse = false;
-    const bool dense_first = m > 0 && !lists_ready && (force_dense || (!text_ok && m > sparse_limit));
+    const bool dense_first = m > 0 && !lists_ready && (force_dense || (!text_ok && m > sparse_limit) || (probe_dense && m > sparse_limit));
     if (m > 0 && dense_first) {
         // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
         if (binned(n, n, tn)) {
@@ -680,7 +707,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         // ---- text-keyed rounds ----
         bool progressing = true;     // a text round that resolves little (runs, long repeats) is the last one
 
-        while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < MAX_TEXT_ROUNDS && progressing) {
+        while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < tn.max_text_rounds && progressing) {
             const int64_t m_before = m;
             uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
             Refined rf;
@@ -709,7 +736,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             local.text_rounds++;
             local.rounds++;
             progressing = m * 4 <= m_before * 3;
-            if (trace) fprintf(stderr, "suffix_array_amd: text round %d depth %lld: tied %lld -> %lld\n", local.text_rounds, (long long)depth, (long long)m_before, (long long)m);
+            if (trace) fprintf(stderr, "suffix_array_amd: text round %d depth %lld: tied %lld -> %lld  (%.2f ms)\n", local.text_rounds, (long long)depth, (long long)m_before, (long long)m, lap());
         }
         if (m > sparse_limit) {
             // still many ties (repetitive text): build the ISA of the current order and double densely
@@ -734,10 +761,12 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         }
     }
     local.sparse_mode = sparse ? 1 : 0;
+    if (trace) fprintf(stderr, "suffix_array_amd: initial sort + text rounds + rank set-up done, %lld tied (%.2f ms since the last line)\n", (long long)m, lap());
 
     // prefix doubling on what is still tied; `depth` symbols are sorted, so the first offset is `depth`
     const int64_t depth_text = depth;
     int64_t h = depth;
+    bool chase_ok = false;
     while (m > 0) {
         if (local.rounds >= 48) return SA_AMD_EINTERNAL;
         uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
@@ -746,6 +775,10 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         // looked up without one (sparse_key2)
         KeySrc K = KeySrc();
         K.mode = sparse ? KS_SPARSE : KS_RANK; K.h = h; K.kb = key2_bits; K.isa = w.isa;
+        // dense rounds chase (up to `chase` rank look-ups per member inside one launch) once a round has had no group left
+        // for the global sort: from then on every surviving group is known to share (iters + 1) * h symbols
+        K.iters = (!sparse && local_ok && chase_ok) ? tn.chase : 1;
+        if (K.iters > 1) K.mode = KS_CHASE;
         K.has_isa = w.has_isa; K.sorted_keys = sorted0; K.sorted_top32 = sorted32; K.sa = SA; K.depth = depth_text; K.top_shift = top_shift;
         Refined rf;
         rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn);
@@ -774,13 +807,15 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                         (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
         }
         { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
-        if (trace) fprintf(stderr, "suffix_array_amd: doubling round %d h %lld (%s): tied %lld -> %u\n", local.rounds + 1, (long long)h, sparse ? "sparse" : "dense", (long long)m, m32);
+        if (trace) fprintf(stderr, "suffix_array_amd: doubling round %d h %lld (%s, %d look-ups, %lld through the global sort): tied %lld -> %u\n", local.rounds + 1, (long long)h, sparse ? "sparse" : "dense", K.iters, (long long)rf.m_global, (long long)m, m32), fprintf(stderr, "    (%.2f ms)\n", lap());
         m = m32;
         uint32_t *t;
         t = Ucur; Ucur = Unext; Unext = t;
         t = Gcur; Gcur = Gnext; Gnext = t;
         Vcur = Vnext;
-        h *= 2;
+        // every group that is still tied went through K.iters look-ups -- unless some went through the global sort (one look-up)
+        h *= (K.iters > 1 && rf.m_global == 0) ? (int64_t)(K.iters + 1) : 2;
+        chase_ok = rf.m_global == 0;
         local.rounds++;
     }
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);   // reference src/saca.rs:13

@@ -19,8 +19,14 @@
 #include <atomic>
 #include <thread>
 #include <vector>
+#include <chrono>
 
 namespace sa {
+
+static inline double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static bool debug_sync()
 {

@@ -50,6 +50,10 @@ struct Tuning {
     bool binned_isa_always = false;  // SA_AMD_BINNED_ISA_ALWAYS
     bool no_fused_hist = false;      // SA_AMD_NO_FUSED_HIST: every radix pass runs its own histogram kernel
     bool no_run_skip = false;        // SA_AMD_NO_RUN_SKIP
+    bool no_repeat_probe = false;    // SA_AMD_NO_REPEAT_PROBE: never start rank doubling right after the initial sort
+    int64_t binned_min = (int64_t)1 << 26;   // SA_AMD_BINNED_MIN: fewest (suffix, rank) pairs a round bins before scattering
+    int chase = 7;                   // SA_AMD_CHASE: rank look-ups per member and dense doubling round (1 = plain doubling), 1..15
+    int max_text_rounds = 4;         // SA_AMD_MAX_TEXT_ROUNDS: text-keyed rounds before rank doubling with a full ISA, 0..8
 #ifdef SA_AMD_DIAG
     bool timing_only_initial_sort = false;     // SA_AMD_TIMING_ONLY_INITIAL_SORT (diag library only: the array is NOT finished)
 #endif
@@ -77,6 +81,10 @@ struct Tuning {
         t.binned_isa_always = env_flag("SA_AMD_BINNED_ISA_ALWAYS");
         t.no_fused_hist = env_flag("SA_AMD_NO_FUSED_HIST");
         t.no_run_skip = env_flag("SA_AMD_NO_RUN_SKIP");
+        t.no_repeat_probe = env_flag("SA_AMD_NO_REPEAT_PROBE");
+        t.max_text_rounds = (int)env_int("SA_AMD_MAX_TEXT_ROUNDS", 4, 0, 8);
+        t.chase = (int)env_int("SA_AMD_CHASE", 7, 1, 15);
+        t.binned_min = env_int("SA_AMD_BINNED_MIN", (int64_t)1 << 26, 1, (int64_t)1 << 40);
 #ifdef SA_AMD_DIAG
         t.timing_only_initial_sort = env_flag("SA_AMD_TIMING_ONLY_INITIAL_SORT");
 #endif

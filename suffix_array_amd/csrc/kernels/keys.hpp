@@ -230,6 +230,29 @@ __global__ __launch_bounds__(GK_THREADS) void k_sample_keys(const uint8_t *__res
     out[i] = ((kq >> top_shift) << 32) | (uint64_t)(uint32_t)p;      // position in the low half: equal positions are not collisions
 }
 
+// Repeat probe: how much of the text lies in repeats longer than a few words?  The first 2k symbols of SAMPLE pseudo-random
+// suffixes are hashed to 32 bits; duplicates among the samples (k_count_sample_dups) estimate the fraction of suffixes
+// that share 2k symbols with another one.  The host routes texts with many such suffixes (a corpus with copied passages)
+// straight to rank doubling, texts without (iid words, random bytes) through the text-keyed rounds.
+__global__ __launch_bounds__(GK_THREADS) void k_sample_repeat_keys(const uint8_t *__restrict__ T, KeyParams P, int64_t n, int64_t samples,
+                                                                    uint64_t *__restrict__ out)
+{
+    __shared__ uint8_t lcode[256];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x;
+    if (i >= samples) return;
+    const uint64_t r = ((uint64_t)i + 1u) * 0xD1B54A32D192ED03ull;
+    const int64_t p = (int64_t)((r >> 11) % (uint64_t)n);
+    const bool al = (((uintptr_t)T) & 7) == 0;
+    uint64_t h = text_key(T, lcode, P, n, p, P.k, al) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    h += text_key(T, lcode, P, n, p + P.k, P.k, al) * 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    h *= 0x94D049BB133111EBull;
+    out[i] = (h & 0xffffffff00000000ull) | (uint64_t)(uint32_t)p;
+}
+
 // Duplicates of the top 32 key bits among the samples, without sorting them: every sample ((top bits << 32) | position)
 // is inserted into an open-addressing hash table of 64-bit entries (all ones = empty).  Meeting an entry with the
 // same top bits and another position counts one duplicate (a value seen c times counts c - 1, as adjacent equal

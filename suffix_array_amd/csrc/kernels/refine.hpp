@@ -27,7 +27,7 @@ namespace sa {
 // KS_SPARSE is the same key when few suffixes are tied and no full ISA exists: the rank is looked up (sparse_rank below).
 // KS_PRE (k_group_sort only): the secondary keys have been gathered into the key array already (the sparse look-up is a long
 // chain of dependent loads per suffix: one thread per suffix in its own kernel, not eight per thread in the sort).
-enum { KS_TEXT = 0, KS_LOWKEY = 1, KS_RANK = 2, KS_SPARSE = 3, KS_PRE = 4 };
+enum { KS_TEXT = 0, KS_LOWKEY = 1, KS_RANK = 2, KS_SPARSE = 3, KS_PRE = 4, KS_CHASE = 5 };   // KS_CHASE: KS_RANK keys, several look-ups per launch (k_group_sort)
 struct KeySrc {
     int mode;          // KS_TEXT / KS_LOWKEY / KS_RANK / KS_SPARSE
     int64_t h;         // KS_TEXT, KS_RANK, KS_SPARSE: symbols already sorted (offset of the secondary key)
@@ -41,6 +41,7 @@ struct KeySrc {
     const uint32_t *sa;             // SA[1..]
     int64_t depth;                  // symbols the initial sort and the text-keyed rounds have ordered
     int top_shift;
+    int iters;                      // KS_RANK: rank look-ups per round (1 = plain doubling), see k_group_sort
 };
 
 // Sparse rank lookup (few tied suffixes): no ISA is built.  rank(q) of suffix q under the current order:
@@ -94,7 +95,7 @@ __device__ __forceinline__ uint64_t text_key2(const uint8_t *__restrict__ T, con
 {
     if (MODE == KS_PRE) return 0;
     if (MODE == KS_SPARSE) return sparse_key2(T, lcode, P, n, K, v, aligned8);
-    if (MODE == KS_RANK) {
+    if (MODE == KS_RANK || MODE == KS_CHASE) {
         const int64_t p = (int64_t)v + K.h;
         return p < n ? (uint64_t)n + (uint64_t)K.isa[p] : (uint64_t)(n - 1 - (int64_t)v);
     }
@@ -225,6 +226,18 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
     stamp(2);      // keys + group-start bitmap in LDS, next-start table (3 barriers)
     int dest[GS_ITEMS];
     bool big[GS_ITEMS];
+    // KS_CHASE ("chasing", K.iters > 1): a group whose members tie on rank[v + h] is refined further inside this launch by
+    // rank[v + 2h], rank[v + 3h], ... -- members that tie on the ranks at v + h .. v + (j-1)h share j * h symbols, so the
+    // look-up at v + j * h is as valid as the first one.  After the first step the members sit in LDS in sorted order with
+    // the extent (first place, size) of their subgroup; every further step touches only members whose subgroup still has
+    // more than one member: they fetch the next rank, count inside their subgroup (not the whole group) and move to their
+    // new place.  A group that is still tied after K.iters steps shares (K.iters + 1) * h symbols: when no group of the
+    // round went through the global sort, the host multiplies h by K.iters + 1 instead of 2 (long repeats: 15 rounds -> 6).
+    constexpr bool CHASE = MODE == KS_CHASE;
+    __shared__ uint32_t s_val2[CHASE ? GS_TILE : 1];              // second value buffer + subgroup extents (first << 16 | size)
+    __shared__ uint32_t s_rng[CHASE ? 2 : 1][CHASE ? GS_TILE : 1];
+    int start_[GS_ITEMS];
+    uint32_t owned_mask = 0;
 #pragma unroll
     for (int r = 0; r < GS_ITEMS; ++r) {
         const int jl = r * GS_THREADS + t;
@@ -239,7 +252,19 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         }
         const bool owned = valid && start >= 0 && end >= 0 && end - start <= cap;
         int rank = 0;
-        if (owned && packed) {
+        start_[r] = start;
+        uint32_t rng = ((uint32_t)jl << 16) | 1u;                // not owned: stays where it is, never tied
+        if (owned && CHASE) {
+            const uint64_t mine = (key[r] << 11) | (uint64_t)jl;
+            int lt = 0, le = 0;
+            for (int i = start; i < end; ++i) {
+                const uint64_t k = s_key[i];
+                rank += k < mine ? 1 : 0;
+                lt += (k >> 11) < key[r] ? 1 : 0;
+                le += (k >> 11) <= key[r] ? 1 : 0;
+            }
+            rng = ((uint32_t)(start + lt) << 16) | (uint32_t)(le - lt);
+        } else if (owned && packed) {
             const uint64_t mine = (key[r] << 11) | (uint64_t)jl;
             for (int i = start; i < end; ++i) rank += s_key[i] < mine ? 1 : 0;
         } else if (owned) {
@@ -249,10 +274,84 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
                 rank += (k < mine || (k == mine && i < jl)) ? 1 : 0;
             }
         }
+        if (owned) owned_mask |= 1u << r;
         dest[r] = owned ? start + rank : jl;
         big[r] = valid && !owned;
+        if (CHASE) { s_val[dest[r]] = v[r]; s_rng[0][dest[r]] = rng; }      // (s_val / s_rng are not read by the counts above)
     }
     stamp(3);      // group extents + rank loops
+    if (CHASE) {
+        // from here on a thread works on PLACES jl = r * GS_THREADS + t of the sorted tile, not on the members it loaded
+        static_assert(!CHASE || GS_TILE <= 2048, "subgroup extents are packed as 16 + 16 bits, places as 11");
+        uint32_t *val_cur = s_val, *val_nxt = s_val2;
+        int cur = 0;
+        __syncthreads();
+        for (int it = 2; it <= K.iters; ++it) {
+            uint32_t rg[GS_ITEMS], vq[GS_ITEMS];
+            uint64_t mine[GS_ITEMS];
+            bool any = false;
+#pragma unroll
+            for (int r = 0; r < GS_ITEMS; ++r) {
+                const int q = r * GS_THREADS + t;
+                rg[r] = s_rng[cur][q];
+                vq[r] = val_cur[q];
+                any |= (rg[r] & 0xffffu) > 1u;
+            }
+            if (!__syncthreads_or(any)) break;
+#pragma unroll
+            for (int r = 0; r < GS_ITEMS; ++r) {
+                const int q = r * GS_THREADS + t;
+                mine[r] = 0;
+                if ((rg[r] & 0xffffu) > 1u) {
+                    const int64_t p = (int64_t)vq[r] + (int64_t)it * K.h;
+                    const uint64_t comp = p < n ? (uint64_t)n + (uint64_t)K.isa[p] : (uint64_t)(n - 1 - (int64_t)vq[r]);
+                    mine[r] = (comp << 11) | (uint64_t)q;
+                    s_key[q] = mine[r];
+                }
+            }
+            __syncthreads();
+            const int nxt = cur ^ 1;
+#pragma unroll
+            for (int r = 0; r < GS_ITEMS; ++r) {
+                const int q = r * GS_THREADS + t;
+                const int e = (int)(rg[r] & 0xffffu), a = (int)(rg[r] >> 16);
+                if (e > 1) {
+                    int rank = 0, lt = 0, le = 0;
+                    const uint64_t comp = mine[r] >> 11;
+                    for (int i = a; i < a + e; ++i) {
+                        const uint64_t k = s_key[i];
+                        rank += k < mine[r] ? 1 : 0;
+                        lt += (k >> 11) < comp ? 1 : 0;
+                        le += (k >> 11) <= comp ? 1 : 0;
+                    }
+                    val_nxt[a + rank] = vq[r];
+                    s_rng[nxt][a + rank] = ((uint32_t)(a + lt) << 16) | (uint32_t)(le - lt);
+                } else {
+                    val_nxt[q] = vq[r];
+                    s_rng[nxt][q] = rg[r];
+                }
+            }
+            __syncthreads();
+            { uint32_t *tmp = val_cur; val_cur = val_nxt; val_nxt = tmp; }
+            cur = nxt;
+        }
+        stamp(4);
+#pragma unroll
+        for (int r = 0; r < GS_ITEMS; ++r) {
+            const int jl = r * GS_THREADS + t;
+            const int64_t j = base + jl;
+            if (j < m) {
+                // place jl belongs to the group the member loaded from jl belongs to (a group keeps its places); members of
+                // one final subgroup share its first place, every other member of the group has another one
+                const uint64_t low = ((owned_mask >> r) & 1u) ? (uint64_t)((int)(s_rng[cur][jl] >> 16) - start_[r]) : key[r];
+                keys[j] = ((uint64_t)g[r] << K.kb) | low;
+                Vout[j] = val_cur[jl];
+                bigflag[j] = big[r] ? 1 : 0;
+            }
+        }
+        stamp(5);
+        return;
+    }
     __syncthreads();                                             // every rank is known: the key slots can be reused
 #pragma unroll
     for (int r = 0; r < GS_ITEMS; ++r) {
@@ -277,7 +376,7 @@ constexpr int GX_THREADS = 256;
 constexpr int GX_ITEMS = GS_CAP / GX_THREADS;
 __global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__restrict__ keys, uint32_t *__restrict__ V,
                                                                      const uint32_t *__restrict__ G, const uint32_t *__restrict__ U,
-                                                                     int64_t m, uint8_t *__restrict__ bigflag, int cap)
+                                                                     int64_t m, uint8_t *__restrict__ bigflag, int cap, KeySrc K, int64_t n)
 {
     __shared__ uint64_t s_key[GS_CAP];
     __shared__ int s_end;
@@ -303,25 +402,113 @@ __global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__
     }
     const int size = s_end;
     if (size > cap) return;
+    // K.mode == KS_CHASE: the same chase as in k_group_sort, places relative to the group's first member
+    const bool chase = K.mode == KS_CHASE;
+    const uint64_t kmask = K.kb >= 64 ? ~0ull : ((1ull << K.kb) - 1ull);
+    __shared__ uint32_t s_v[2][GS_CAP], s_rg[2][GS_CAP];
     uint64_t key[GX_ITEMS]; uint32_t v[GX_ITEMS];
+    static_assert(GS_CAP <= 1024, "10 bits of member index");
 #pragma unroll
     for (int r = 0; r < GX_ITEMS; ++r) {
         const int i = r * GX_THREADS + t;
         key[r] = 0; v[r] = 0;
-        if (i < size) { key[r] = keys[start + i]; v[r] = V[start + i]; s_key[i] = key[r]; }
+        if (i < size) {
+            key[r] = keys[start + i]; v[r] = V[start + i];
+            s_key[i] = chase ? (((key[r] & kmask) << 10) | (uint64_t)i) : key[r];
+        }
     }
     __syncthreads();
+    if (!chase) {
+#pragma unroll
+        for (int r = 0; r < GX_ITEMS; ++r) {
+            const int i = r * GX_THREADS + t;
+            if (i < size) {
+                int rank = 0;
+                for (int q = 0; q < size; ++q) {
+                    const uint64_t k = s_key[q];
+                    rank += (k < key[r] || (k == key[r] && q < i)) ? 1 : 0;
+                }
+                keys[start + rank] = key[r];
+                V[start + rank] = v[r];
+                bigflag[start + i] = 0;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < GX_ITEMS; ++r) {
         const int i = r * GX_THREADS + t;
         if (i < size) {
-            int rank = 0;
+            const uint64_t comp = key[r] & kmask, mine = (comp << 10) | (uint64_t)i;
+            int rank = 0, lt = 0, le = 0;
             for (int q = 0; q < size; ++q) {
                 const uint64_t k = s_key[q];
-                rank += (k < key[r] || (k == key[r] && q < i)) ? 1 : 0;
+                rank += k < mine ? 1 : 0;
+                lt += (k >> 10) < comp ? 1 : 0;
+                le += (k >> 10) <= comp ? 1 : 0;
             }
-            keys[start + rank] = key[r];
-            V[start + rank] = v[r];
+            s_v[0][rank] = v[r];
+            s_rg[0][rank] = ((uint32_t)lt << 16) | (uint32_t)(le - lt);
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int it = 2; it <= K.iters; ++it) {
+        uint32_t rg[GX_ITEMS], vq[GX_ITEMS];
+        uint64_t mine[GX_ITEMS];
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < GX_ITEMS; ++r) {
+            const int q = r * GX_THREADS + t;
+            rg[r] = q < size ? s_rg[cur][q] : 1u;
+            vq[r] = q < size ? s_v[cur][q] : 0u;
+            any |= (rg[r] & 0xffffu) > 1u;
+        }
+        if (!__syncthreads_or(any)) break;
+#pragma unroll
+        for (int r = 0; r < GX_ITEMS; ++r) {
+            const int q = r * GX_THREADS + t;
+            mine[r] = 0;
+            if ((rg[r] & 0xffffu) > 1u) {
+                const int64_t p = (int64_t)vq[r] + (int64_t)it * K.h;
+                const uint64_t comp = p < n ? (uint64_t)n + (uint64_t)K.isa[p] : (uint64_t)(n - 1 - (int64_t)vq[r]);
+                mine[r] = (comp << 10) | (uint64_t)q;
+                s_key[q] = mine[r];
+            }
+        }
+        __syncthreads();
+        const int nxt = cur ^ 1;
+#pragma unroll
+        for (int r = 0; r < GX_ITEMS; ++r) {
+            const int q = r * GX_THREADS + t;
+            if (q >= size) continue;
+            const int e = (int)(rg[r] & 0xffffu), a = (int)(rg[r] >> 16);
+            if (e > 1) {
+                int rank = 0, lt = 0, le = 0;
+                const uint64_t comp = mine[r] >> 10;
+                for (int i = a; i < a + e; ++i) {
+                    const uint64_t k = s_key[i];
+                    rank += k < mine[r] ? 1 : 0;
+                    lt += (k >> 10) < comp ? 1 : 0;
+                    le += (k >> 10) <= comp ? 1 : 0;
+                }
+                s_v[nxt][a + rank] = vq[r];
+                s_rg[nxt][a + rank] = ((uint32_t)(a + lt) << 16) | (uint32_t)(le - lt);
+            } else {
+                s_v[nxt][q] = vq[r];
+                s_rg[nxt][q] = rg[r];
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+    const uint64_t ghead = ((uint64_t)gb) << K.kb;
+#pragma unroll
+    for (int r = 0; r < GX_ITEMS; ++r) {
+        const int i = r * GX_THREADS + t;
+        if (i < size) {
+            keys[start + i] = ghead | (uint64_t)(s_rg[cur][i] >> 16);
+            V[start + i] = s_v[cur][i];
             bigflag[start + i] = 0;
         }
     }
