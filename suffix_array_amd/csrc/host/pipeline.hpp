@@ -277,7 +277,7 @@ static int scatter_binned(uint32_t *pk, uint32_t *pv, uint32_t *altk, uint32_t *
     int rc = sort_pairs32(pk, pv, altk, altv, count, shift, shift + RADIX_BITS, w.spine, w.digit_tot, nullptr, st, &pr, tn, iota);
     if (rc) return rc;
     local->sort_passes += pr.passes; local->sorted_elements += (int64_t)pr.passes * count;
-    PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_pairs<uint32_t>), dim3((unsigned)ceil_div(count, 1024)), dim3(256), 0, st,
+    PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_pairs<uint32_t>), dim3((unsigned)(ceil_div(ceil_div(count, 1024), 8) * 8)), dim3(256), 0, st,
                                                    (const uint32_t *)pr.keys, (const uint32_t *)pr.vals, w.isa, count, (uint32_t)n));
     return SA_AMD_OK;
 }
@@ -458,7 +458,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         const double chance = (double)S * (double)S / 8589934592.0;           // 32-bit hash collisions among S samples
         const double frac = ((double)dups - chance) * (double)n / ((double)S * (double)S);
         probe_dense = frac > 0.04;
-        if (trace) fprintf(stderr, "suffix_array_amd: repeat probe: %u duplicates among %lld samples -> %.3f of the suffixes in long repeats -> %s\n",
+        if (trace) fprintf(stderr, "suffix_array_amd: repeat probe: %u duplicates among %lld samples (repeat index %.3f, threshold 0.04) -> %s\n",
                            dups, (long long)S, frac, probe_dense ? "rank doubling from the start" : "text-keyed rounds");
     }
 

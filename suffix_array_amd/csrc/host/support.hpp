@@ -9,6 +9,7 @@
 #include "../kernels/extras.hpp"
 #ifdef SA_AMD_DIAG
 #include "../kernels/radix_sort_diag.hpp"
+#include "../kernels/induce_proto.hpp"
 #endif
 #include "../../../include/suffix_array_amd.h"
 

@@ -23,6 +23,12 @@ int32_t sa_amd_test_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t count, in
 int32_t sa_amd_test_sort_pairs32(uint32_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit, int32_t end_bit);
 /* initial packed keys of a text (host buffers; keys has n entries); returns bits in *bits, symbols in *k */
 int32_t sa_amd_test_build_keys(const uint8_t *T, int32_t n, uint64_t *keys, int32_t *bits, int32_t *k);
+/* micro-prototype for DESIGN.md section 2 / VERDICT r1 row (g): one exact level-0 L-type induce sweep of SA-IS executed by a
+ * single wavefront with the bucket heads in LDS; SA (n + 1 slots) holds the LMS suffixes at their places and 0xffffffff
+ * elsewhere and is completed in place; typeL: bit j = suffix j is L-type; head: 256 bucket starts; counters[0] = induced
+ * suffixes, counters[1] = 64-slot blocks that had to be re-read */
+int32_t sa_amd_proto_induce_l(const uint8_t *T, const uint8_t *typeL, uint32_t *SA, int32_t n, const uint32_t *head,
+                              double *ms, uint64_t *counters);
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st
 
-from conftest import KNOWN_ANSWERS, adversarial_cases
+from conftest import KNOWN_ANSWERS, ROOT, adversarial_cases
 
 import pd_model
 
@@ -122,3 +122,16 @@ def test_pack_model_round_trip_and_layout():
     assert lane0_word0 & 0x7F == 0 and (lane0_word0 >> 7) & 0x7F == 4 and (lane0_word0 >> 14) & 0x7F == 8
     lane1_word0 = int.from_bytes(blob[20:24], "little")
     assert lane1_word0 & 0x7F == 1 and (lane1_word0 >> 7) & 0x7F == 5
+
+
+def test_sanitized_selftest():
+    """the oracle and the corpus generators under AddressSanitizer + UndefinedBehaviorSanitizer (`make -C oracle sanitize`):
+    known answers, naive sort == SA-IS == both integrity checks, the threaded verifier, every generator at ragged sizes.
+    (GPU sanitizers are unavailable on this pool: the CPU side of the test infrastructure is what gets sanitized.)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None and shutil.which("cc") is None:
+        pytest.skip("no C compiler")
+    proc = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "sanitize"], stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert proc.returncode == 0 and "selftest ok" in proc.stdout, proc.stdout[-3000:]
