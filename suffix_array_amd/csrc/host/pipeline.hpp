@@ -326,7 +326,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
             PROF(KC_LOCAL, 0, st, hipLaunchKernelGGL((k_group_sort_straddle), dim3(gs_blocks - 1), dim3(GX_THREADS), 0, st, rkA, Vcur, Gcur,
                                                      Ucur, m, flags, cap, K, n));
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                    (const uint8_t *)flags, m, w.tcnt));
+                                                    (const uint8_t *)flags, Ucur, Gcur, m, w.tcnt, w.ft_cnt));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
         uint32_t big32 = 0;
         { const int rcw = read_words(&big32, w.total, 4, st); if (rcw) return rcw; }
@@ -334,16 +334,19 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         const size_t half = (((size_t)n / 2 + 1) & ~(size_t)1);
         if ((size_t)m_big <= half) {
             if (m_big > 0) {
-                // groups no tile owns: global sort of (group head, key2), then back to their list positions
+                // groups no tile owns: global sort of (index of the group among them, key2), then back to their list positions.
+                // Every such group has more than `cap` members, so there are at most m_big / (cap + 1) of them.
+                PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.thead, tiles, w.total + 8));
+                const int idx_bits = bit_length((uint64_t)(m_big / (cap + 1) + 1));
                 PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_flag_gather), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                            (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, m,
-                                                            (const uint32_t *)w.tcnt, rkB, Valt, scratchU));
-                rc = sort_pairs(rkB, Valt, rkB + half, Valt + half, m_big, 0, kb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn);
+                                                            (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, Ucur, Gcur, m,
+                                                            (const uint32_t *)w.tcnt, (const uint32_t *)w.ft_cnt, kb, rkB, Valt, scratchU));
+                rc = sort_pairs(rkB, Valt, rkB + half, Valt + half, m_big, 0, kb + idx_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn);
                 if (rc) return rc;
                 local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m_big;
                 PROF(KC_SCATTER, m_big, st, hipLaunchKernelGGL((k_scatter_back), dim3((unsigned)ceil_div(m_big, 256)), dim3(256), 0, st,
                                                                (const uint64_t *)sr.keys, (const uint32_t *)sr.vals,
-                                                               (const uint32_t *)scratchU, m_big, rkA, Vcur));
+                                                               (const uint32_t *)scratchU, Gcur, kb, m_big, rkA, Vcur));
             }
             out->keys = rkA; out->vals = Vcur; out->vnext = Valt; out->m_global = m_big;
             local->locally_sorted += m - m_big;
