@@ -63,9 +63,9 @@ static Workspace carve(void *base, int64_t n)
     const size_t N = (size_t)(n > 0 ? n : 1);
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off = align_up(off + b, 256); return (char *)base + o; };
-    w.keysA = (uint64_t *)take(N * 8);
-    w.keysB = (uint64_t *)take(N * 8);
-    w.keysC = (uint64_t *)take(N * 8);
+    w.keysA = (uint64_t *)take((N + 64) * 8);         // (+64: as two halves of n + 1 32-bit entries each, see scatter_binned)
+    w.keysB = (uint64_t *)take((N + 64) * 8);
+    w.keysC = (uint64_t *)take((N + 64) * 8);
     w.valsA = (uint32_t *)take(N * 4);
     w.valsB = (uint32_t *)take(N * 4);
     w.isa = (uint32_t *)take(N * 4);
@@ -267,17 +267,54 @@ static bool binned(int64_t n, int64_t count, const Tuning &tn)
     return n >= ((int64_t)1 << 25) && (count >= n || count >= tn.binned_min);
 }
 
-// (suffix, rank) pairs (both 32 bits) -> one radix pass on the top 8 bits of the suffix position -> windowed scatter
+// (suffix, rank) pairs (both 32 bits) -> ISA.  Large batches: two radix passes on the top 16 bits of the suffix position, then
+// windows of the ISA are assembled in LDS and stored in address order (k_scatter_windows); smaller ones: one pass on the top
+// 8 bits and a plain scatter inside 2^(nb-8)-entry windows.  SA_AMD_SCATTER_LEVELS = 1 / 2 forces either.
+// iota: the value of pair i is i and pk is READ-ONLY (the suffix array itself): the passes then go pk -> (altk, altv) ->
+// (altk2, altv2) and never write into pk.
 static int scatter_binned(uint32_t *pk, uint32_t *pv, uint32_t *altk, uint32_t *altv, int64_t count, int64_t n,
-                          const Workspace &w, hipStream_t st, sa_amd_stats *local, const Tuning &tn, bool iota = false)
+                          const Workspace &w, hipStream_t st, sa_amd_stats *local, const Tuning &tn, bool iota = false,
+                          uint32_t *altk2 = nullptr, uint32_t *altv2 = nullptr)
 {
     const int nb = bit_length((uint64_t)(n > 1 ? n : 1));          // (the sentinel value n may be among the keys)
-    const int shift = nb > RADIX_BITS ? nb - RADIX_BITS : 0;
+    const bool two = tn.scatter_levels == 2 || (tn.scatter_levels == 0 && count >= ((int64_t)1 << 25));
     SortResult32 pr;
+    if (two) {
+        int wlog = nb - 16;
+        const int small = nb < 10 ? nb : 10;
+        if (wlog < small) wlog = small;                              // small texts: one pass (or none) covers the bits above the window
+        if (wlog > 15) wlog = 15;                                    // (n < 2^31, so nb <= 31)
+        int rc;
+        if (iota) {
+            const int mid = wlog + RADIX_BITS < nb ? wlog + RADIX_BITS : nb;
+            rc = sort_pairs32(pk, nullptr, altk, altv, count, wlog, mid, w.spine, w.digit_tot, nullptr, st, &pr, tn, true);
+            if (rc) return rc;
+            if (pr.passes != 1) return SA_AMD_EINTERNAL;            // (cannot happen: nb > wlog whenever count > 1)
+            local->sort_passes += 1; local->sorted_elements += count;
+            if (mid < nb) {
+                rc = sort_pairs32(altk, altv, altk2, altv2, count, mid, nb, w.spine, w.digit_tot, nullptr, st, &pr, tn);
+                if (rc) return rc;
+                local->sort_passes += pr.passes; local->sorted_elements += (int64_t)pr.passes * count;
+            }
+        } else {
+            rc = sort_pairs32(pk, pv, altk, altv, count, wlog, nb, w.spine, w.digit_tot, nullptr, st, &pr, tn);
+            if (rc) return rc;
+            local->sort_passes += pr.passes; local->sorted_elements += (int64_t)pr.passes * count;
+        }
+        const unsigned grid = (unsigned)ceil_div(count, SW_CHUNK);
+        if (wlog <= 13)
+            PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_windows<13>), dim3(grid), dim3(SW_THREADS), 0, st, (const uint32_t *)pr.keys,
+                                                           (const uint32_t *)pr.vals, w.isa, count, (uint32_t)n, wlog));
+        else
+            PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_windows<15>), dim3(grid), dim3(SW_THREADS), 0, st, (const uint32_t *)pr.keys,
+                                                           (const uint32_t *)pr.vals, w.isa, count, (uint32_t)n, wlog));
+        return SA_AMD_OK;
+    }
+    const int shift = nb > RADIX_BITS ? nb - RADIX_BITS : 0;
     int rc = sort_pairs32(pk, pv, altk, altv, count, shift, shift + RADIX_BITS, w.spine, w.digit_tot, nullptr, st, &pr, tn, iota);
     if (rc) return rc;
     local->sort_passes += pr.passes; local->sorted_elements += (int64_t)pr.passes * count;
-    PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_pairs<uint32_t>), dim3((unsigned)(ceil_div(ceil_div(count, 1024), 8) * 8)), dim3(256), 0, st,
+    PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_pairs<uint32_t>), dim3((unsigned)ceil_div(count, 1024)), dim3(256), 0, st,
                                                    (const uint32_t *)pr.keys, (const uint32_t *)pr.vals, w.isa, count, (uint32_t)n));
     return SA_AMD_OK;
 }
@@ -751,7 +788,9 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                 // the top 8 bits of the suffix position, the scatter then works window by window (10.0 -> ~2.5 ms at 256 MiB)
                 hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);
                 LAUNCH_CHECK(st);
-                rc = scatter_binned(dSA, nullptr, (uint32_t *)rkB, (uint32_t *)rkA, n + 1, n, w, st, &local, tn, true);
+                const size_t H = ((size_t)n + 1 + 3) & ~(size_t)3;      // keys in the first half of an 8(n + 64)-byte buffer, values in the second
+                rc = scatter_binned(dSA, nullptr, (uint32_t *)rkB, (uint32_t *)rkB + H, n + 1, n, w, st, &local, tn, true,
+                                    (uint32_t *)rkA, (uint32_t *)rkA + H);
                 if (rc) return rc;
             } else
                 PROF(KC_SCATTER, n, st, hipLaunchKernelGGL((k_isa_from_sa), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)SA, w.isa, n));

@@ -53,6 +53,7 @@ struct Tuning {
     bool no_repeat_probe = false;    // SA_AMD_NO_REPEAT_PROBE: never start rank doubling right after the initial sort
     int64_t binned_min = (int64_t)1 << 26;   // SA_AMD_BINNED_MIN: fewest (suffix, rank) pairs a round bins before scattering
     int chase = 7;                   // SA_AMD_CHASE: rank look-ups per member and dense doubling round (1 = plain doubling), 1..15
+    int scatter_levels = 0;          // SA_AMD_SCATTER_LEVELS: radix passes before a binned ISA write (0 = by size, 1, 2)
     int max_text_rounds = 4;         // SA_AMD_MAX_TEXT_ROUNDS: text-keyed rounds before rank doubling with a full ISA, 0..8
 #ifdef SA_AMD_DIAG
     bool timing_only_initial_sort = false;     // SA_AMD_TIMING_ONLY_INITIAL_SORT (diag library only: the array is NOT finished)
@@ -84,6 +85,7 @@ struct Tuning {
         t.no_repeat_probe = env_flag("SA_AMD_NO_REPEAT_PROBE");
         t.max_text_rounds = (int)env_int("SA_AMD_MAX_TEXT_ROUNDS", 4, 0, 8);
         t.chase = (int)env_int("SA_AMD_CHASE", 7, 1, 15);
+        t.scatter_levels = (int)env_int("SA_AMD_SCATTER_LEVELS", 0, 0, 2);
         t.binned_min = env_int("SA_AMD_BINNED_MIN", (int64_t)1 << 26, 1, (int64_t)1 << 40);
 #ifdef SA_AMD_DIAG
         t.timing_only_initial_sort = env_flag("SA_AMD_TIMING_ONLY_INITIAL_SORT");

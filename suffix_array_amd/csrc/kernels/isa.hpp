@@ -44,6 +44,53 @@ __global__ __launch_bounds__(256) void k_scatter_pairs(const KeyT *__restrict__ 
     }
 }
 
+// The same after TWO radix passes (pairs sorted by the top 16 bits of the suffix position): a workgroup takes 8192 consecutive
+// pairs, which then lie in a few consecutive windows of 2^WLOG ISA entries; window by window it places the ranks in LDS and
+// stores the window's touched entries in address order -- whole 64-byte lines when every entry is written (the full build),
+// one partial write per line otherwise -- instead of one read-modify-write of a 64-byte HBM burst per pair.
+constexpr int SW_THREADS = 1024;
+constexpr int SW_ITEMS = 8;
+constexpr int SW_CHUNK = SW_THREADS * SW_ITEMS;
+
+template <int WLOG_MAX>
+__global__ __launch_bounds__(SW_THREADS) void k_scatter_windows(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pv,
+                                                                 uint32_t *__restrict__ ISA, int64_t count, uint32_t n_text, int wlog)
+{
+    __shared__ uint32_t s_rank[1 << WLOG_MAX];
+    __shared__ uint32_t s_bits[(1 << WLOG_MAX) / 32 + 1];
+    const int t = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * SW_CHUNK;
+    const int64_t c1 = c0 + SW_CHUNK < count ? c0 + SW_CHUNK : count;
+    if (c0 >= count) return;
+    uint32_t v[SW_ITEMS], r[SW_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SW_ITEMS; ++k) {
+        const int64_t i = c0 + k * SW_THREADS + t;
+        v[k] = i < c1 ? pk[i] : 0xffffffffu;
+        r[k] = i < c1 ? pv[i] : 0u;
+    }
+    const uint32_t W = 1u << wlog, wmask = W - 1u;
+    const uint32_t wfirst = pk[c0] >> wlog, wlast = pk[c1 - 1] >> wlog;       // (the pairs are sorted by this value)
+    for (uint32_t w = wfirst; w <= wlast; ++w) {
+        for (uint32_t i = t; i < (W + 31) / 32; i += SW_THREADS) s_bits[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SW_ITEMS; ++k) {
+            if (v[k] != 0xffffffffu && (v[k] >> wlog) == w && v[k] < n_text) {
+                const uint32_t p = v[k] & wmask;
+                s_rank[p] = r[k];
+                atomicOr(&s_bits[p >> 5], 1u << (p & 31u));
+            }
+        }
+        __syncthreads();
+        const uint64_t wbase = (uint64_t)w << wlog;
+        for (uint32_t p = t; p < W; p += SW_THREADS)
+            if ((s_bits[p >> 5] >> (p & 31u)) & 1u) ISA[wbase + p] = s_rank[p];
+        __syncthreads();
+        if (w == 0xffffffffu) break;                                           // (cannot wrap: wlast < 2^32 >> wlog)
+    }
+}
+
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 
 __global__ __launch_bounds__(256) void k_copy_u32(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int64_t n)

@@ -227,8 +227,16 @@ def test_binned_isa_update_path(oracle, monkeypatch, gen, n, seed):
     exp = oracle.sais(text)
     monkeypatch.setenv("SA_AMD_BINNED_ISA_ALWAYS", "1")
     monkeypatch.setenv("SA_AMD_FORCE_DENSE", "1")
-    assert np.array_equal(build(text), exp)
-    assert sa.last_stats()["rounds"] >= 1
+    for levels in ("1", "2"):                         # one radix pass + plain scatter / two passes + windows assembled in LDS
+        monkeypatch.setenv("SA_AMD_SCATTER_LEVELS", levels)
+        assert np.array_equal(build(text), exp), levels
+        assert sa.last_stats()["rounds"] >= 1
+        monkeypatch.setenv("SA_AMD_MAX_TEXT_ROUNDS", "1")      # the late ISA build (after a text-keyed round) too
+        monkeypatch.delenv("SA_AMD_FORCE_DENSE")
+        monkeypatch.setenv("SA_AMD_SPARSE_DIV", "1000000000")
+        assert np.array_equal(build(text), exp), levels
+        monkeypatch.delenv("SA_AMD_MAX_TEXT_ROUNDS"); monkeypatch.delenv("SA_AMD_SPARSE_DIV")
+        monkeypatch.setenv("SA_AMD_FORCE_DENSE", "1")
     monkeypatch.delenv("SA_AMD_BINNED_ISA_ALWAYS")
     monkeypatch.setenv("SA_AMD_NO_BINNED_ISA", "1")
     assert np.array_equal(build(text), exp)
@@ -415,7 +423,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_FORCE_DENSE", "SA_AMD_NO_TEXT_ROUNDS", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TOP32", "SA_AMD_FORCE_TOP32",
              "SA_AMD_NO_FUSED_FINISH", "SA_AMD_FUSED64", "SA_AMD_NO_PACKED_TEXT", "SA_AMD_NO_BINNED_ISA",
              "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_FUSED_HIST", "SA_AMD_NO_RUN_SKIP", "SA_AMD_TIMING_ONLY_INITIAL_SORT",
-             "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE",
+             "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
