@@ -92,7 +92,8 @@ static Workspace carve(void *base, int64_t n)
     return w;
 }
 
-struct SortResult { uint64_t *keys; uint32_t *vals; int passes; };
+struct SortResult { uint64_t *keys; uint32_t *vals; int passes; int skipped; };
+static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st);
 
 // stable LSD sort of `count` pairs on key bits [begin_bit, end_bit); ping-pongs between in/alt.
 // spine: RADIX * SORT_MAX_WG words, digit_tot: RADIX words.  final_vals (optional): the LAST pass
@@ -102,7 +103,7 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
                       int begin_bit, int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals,
                       hipStream_t st, SortResult *res, const Tuning &tn, bool iota = false)   // iota: value i = index i, vals_in is scratch only
 {
-    res->keys = keys_in; res->vals = vals_in; res->passes = 0;
+    res->keys = keys_in; res->vals = vals_in; res->passes = 0; res->skipped = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
     const SortVariant &sv = sort_variants[tn.sort_variant];
     const SortGrid g = sort_grid(count, sv);
@@ -126,6 +127,20 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
         }
         PROF(KC_SPINE, (int64_t)RADIX * g.G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st,
                                                                     spine, digit_tot, g.G));
+        // A digit that is the same for EVERY element makes the pass the identity (the sort is stable): skip the tile scatter.
+        // Worth a 1 KiB read-back for large sorts only; texts that are one run or one period keep hundreds of millions of
+        // suffixes in a single group round after round, and their (group, rank) keys are constant in most digits.
+        if (!tn.no_run_skip && count >= ((int64_t)1 << 22) && !(iota && res->passes == 0) && !(last && final_vals)) {
+            uint32_t tot[RADIX];
+            { const int rcw = read_words(tot, digit_tot, sizeof(tot), st); if (rcw) return rcw; }
+            bool constant = false;
+            for (int d = 0; d < RADIX; ++d) constant |= (int64_t)tot[d] == count;
+            if (constant) {
+                HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * g.G * 4, st));     // (the tile scatter would have zeroed what it consumed)
+                res->skipped++;
+                continue;
+            }
+        }
         PROF(KC_DOWNSWEEP, count, st, hipLaunchKernelGGL((sv.fn), dim3(g.G), dim3(sv.threads), 0, st,
                                                          (const uint64_t *)kin, (const uint32_t *)((iota && res->passes == 0) ? nullptr : vin), kout, vdst,
                                                          spine, (const uint32_t *)digit_tot, count, shift,
@@ -365,16 +380,16 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     (const uint8_t *)flags, Ucur, Gcur, m, w.tcnt, w.ft_cnt));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-        uint32_t big32 = 0;
-        { const int rcw = read_words(&big32, w.total, 4, st); if (rcw) return rcw; }
-        const int64_t m_big = big32;
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.thead, tiles, w.total + 8));
+        uint32_t tot9[9] = { 0 };                             // [0] flagged members, [8] flagged groups
+        { const int rcw = read_words(tot9, w.total, sizeof(tot9), st); if (rcw) return rcw; }
+        const int64_t m_big = tot9[0];
         const size_t half = (((size_t)n / 2 + 1) & ~(size_t)1);
         if ((size_t)m_big <= half) {
             if (m_big > 0) {
-                // groups no tile owns: global sort of (index of the group among them, key2), then back to their list positions.
-                // Every such group has more than `cap` members, so there are at most m_big / (cap + 1) of them.
-                PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.thead, tiles, w.total + 8));
-                const int idx_bits = bit_length((uint64_t)(m_big / (cap + 1) + 1));
+                // groups no tile owns: global sort of (index of the group among them, key2), then back to their list positions
+                // (a text that is one long run has ONE such group: no index bits at all, four passes instead of eight)
+                const int idx_bits = bit_length((uint64_t)(tot9[8] > 0 ? tot9[8] - 1 : 0));
                 PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_flag_gather), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                             (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, Ucur, Gcur, m,
                                                             (const uint32_t *)w.tcnt, (const uint32_t *)w.ft_cnt, kb, rkB, Valt, scratchU));

@@ -23,7 +23,7 @@ def check_sort():
             mask = np.uint64((1 << hi) - 1) if hi < 64 else np.uint64(2**64 - 1)
             order = np.argsort((keys & mask) >> np.uint64(lo), kind="stable")
             k2, v2 = keys.copy(), vals.copy()
-            rc = sa.lib().sa_amd_test_sort_pairs(k2.ctypes.data, v2.ctypes.data, count, lo, hi)
+            rc = sa.diag_lib().sa_amd_test_sort_pairs(k2.ctypes.data, v2.ctypes.data, count, lo, hi)
             fd = first_diff(v2, vals[order])
             if rc or fd:
                 ok = False

@@ -6,12 +6,13 @@ import suffix_array_amd as sa
 from suffix_array_amd import corpus
 t = corpus.workload("c3_english_256m")
 out = np.zeros(t.size + 1, dtype=np.uint32)
-L = sa.lib()
+L = sa.diag_lib()        # the stamps are compiled into the diagnostic library only
+saca = lambda text, arr: L.sa_amd_saca_u8(text.ctypes.data, arr.ctypes.data, text.size)
 buf = (ctypes.c_uint64 * 16)()
-sa.saca(t, out)
+assert saca(t, out) == 0
 L.sa_amd_debug_group_sort_stamps(1)
 L.sa_amd_debug_phase_cycles(buf, 16)          # zero
-sa.saca(t, out)
+assert saca(t, out) == 0
 L.sa_amd_debug_phase_cycles(buf, 16)
 L.sa_amd_debug_group_sort_stamps(0)
 names = ["list loads issued", "secondary keys gathered (+ wait for the list loads)", "keys + bitmap in LDS, next-start table (3 barriers)",

@@ -1,6 +1,8 @@
-"""Diagnostic: where a tile of the dominant kernel spends its cycles (in-kernel s_memtime stamps)."""
+"""Diagnostic: where a tile of the dominant kernel spends its cycles (in-kernel s_memtime stamps).
+Runs through libsuffix_array_amd_diag.so: the stamped kernel and SA_AMD_TIMING_ONLY_INITIAL_SORT exist only there
+(variant 9 of the diagnostic table = phase stamps; sa_amd_debug_sort_variant_name lists them)."""
 import sys, os, ctypes
-os.environ["SA_AMD_SORT_VARIANT"] = sys.argv[1] if len(sys.argv) > 1 else "7"
+os.environ["SA_AMD_SORT_VARIANT"] = sys.argv[1] if len(sys.argv) > 1 else "9"
 os.environ["SA_AMD_TIMING_ONLY_INITIAL_SORT"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,11 +10,12 @@ import suffix_array_amd as sa
 from suffix_array_amd import corpus
 t = corpus.uniform(256 << 20, 5)
 out = np.zeros(t.size + 1, dtype=np.uint32)
-L = sa.lib()
+L = sa.diag_lib()
+saca = lambda text, arr: L.sa_amd_saca_u8(text.ctypes.data, arr.ctypes.data, text.size)
 buf = (ctypes.c_uint64 * 16)()
-sa.saca(t, out)
+assert saca(t, out) == 0
 L.sa_amd_debug_phase_cycles(buf, 16)          # discard warm-up
-sa.saca(t, out)
+assert saca(t, out) == 0
 L.sa_amd_debug_phase_cycles(buf, 16)
 names = ["load issue + zero + barrier", "ranking (+ key wait)", "value loads + barrier", "digit prefix + bookkeeping",
          "keys -> LDS + carry out", "keys LDS -> global", "values -> LDS + carry out", "values LDS -> global"]

@@ -23,8 +23,11 @@ def load(counter_dir):
         for r in csv.DictReader(open(f)):
             full = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sa::", "")
             k = full.split("<")[0]
+            if k in ("k_scatter_windows",):
+                k = "k_scatter_pairs"                 # bench.py's kernel class of all binned ISA writes
             if k.startswith("k_radix_downsweep"):     # all tile-scatter variants are one kernel class per key width in bench.py
-                k = "k_radix_downsweep32" if "unsigned int>" in full else "k_radix_downsweep"
+                # template arguments: <threads, items, granule, min waves, stamps, KEY TYPE, prefetched items>
+                k = "k_radix_downsweep32" if "unsigned int" in full else "k_radix_downsweep"
             agg[k][0] += 1
             agg[k][1] += float(r["Counter_Value"])
     return agg

@@ -1,15 +1,29 @@
+# Round evidence, run on the GPU box from the repo root:  bash tools/profile_round.sh <tag>   (tag: r02, ...)
+# bench lines of every BASELINE config + the 256 MiB random text + the round-1 iid corpus, rocprofv3 kernel stats of the
+# headline command, PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) -> gpurun_out/<tag>/, to be copied into profiles/.
 set -e
-cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python bench.py --steps 5 --warmup 1 --verify > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err
-for w in c2_uniform_64m c4_dna_1g c5_uniform_512m; do timeout -k 10 300 python bench.py --steps 5 --warmup 1 --verify --workload $w > gpurun_out/bench_$w.json 2>gpurun_out/bench_$w.err; done
-export TMPDIR=/tmp
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
-cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_stats.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc/pmc_FETCH_SIZE -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc/pmc_WRITE_SIZE -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write.log 2>&1
+O=$R/gpurun_out/$TAG
+mkdir -p $O
 cd $R
-find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -2
-find gpurun_out/pmc -name "*counter_collection.csv" | xargs ls -la | head
-find gpurun_out/pmc -name "*.csv" -size +30M -delete
-tail -1 gpurun_out/bench_c3.json | cut -c1-300
+for w in c3_english_256m c3_iid_256m c2_uniform_256m c2_uniform_64m c4_dna_1g c5_uniform_512m; do
+  timeout -k 10 400 python bench.py --steps 5 --warmup 1 --workload $w > $O/bench_$w.json 2> $O/bench_$w.err
+done
+SA_BENCH_SHARE_GPU=1 timeout -k 10 400 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_2ranks_shared_gpu.json 2> $O/bench_2ranks_shared_gpu.err
+export TMPDIR=/tmp
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o c3 -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/prof_stats.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc/pmc_FETCH_SIZE -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc/pmc_WRITE_SIZE -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/pmc_write.log 2>&1
+cd $R
+python tools/pmc_traffic.py $O/pmc $O/traffic.json c3_english_256m 268435456
+find $O/pmc -name "*.csv" -delete
+find $O/prof_stats -name "*kernel_trace.csv" -delete
+for w in c3_english_256m c3_iid_256m c2_uniform_256m c2_uniform_64m c4_dna_1g c5_uniform_512m; do python - <<PY
+import json
+r = json.load(open("$O/bench_$w.json"))
+e = r["end_to_end"]
+print("$w", r["value"], "MB/s", r["ms_per_step"], "ms  verified", r["verified"], " e2e reused", e["reused_buffer"]["ms"], "fresh", e["fresh_buffer"]["ms"], " roofline", r["roofline"]["kernel"], r["roofline"]["frac"])
+PY
+done

@@ -8,7 +8,13 @@ import numpy as np
 import suffix_array_amd as sa
 from suffix_array_amd import corpus
 for name in sys.argv[1:] or ["c3_english_256m"]:
-    t = corpus.workload(name)
+    if name.startswith("adv:"):                 # adversarial families of tools/adversarial_timing.py: adv:<family>:<n>
+        _, fam, nn = name.split(":"); nn = int(nn)
+        t = {"one": lambda: np.full(nn, 97, dtype=np.uint8),
+             "ab": lambda: np.resize(np.frombuffer(b"ab", dtype=np.uint8), nn).copy(),
+             "twice": lambda: np.concatenate([corpus.english(nn // 2, 5)] * 2)}[fam]()
+    else:
+        t = corpus.workload(name)
     out = np.zeros(t.size + 1, dtype=np.uint32)
     os.environ["SA_AMD_VERBOSE"] = "0"
     sa.saca(t, out)

@@ -1,8 +1,8 @@
 #!/bin/bash
 # A/B of the downsweep configurations (SA_AMD_SORT_VARIANT) on one workload; prints kernel ms per build
 W=${1:-c2_uniform_64m}
-for v in ${VARIANTS:-0 1 2 8 9}; do      # 3-6 are timing-only ablations (wrong results: add SA_AMD_TIMING_ONLY_INITIAL_SORT=1), 7 = phase stamps
-  SA_AMD_SORT_VARIANT=$v timeout -k 10 200 python bench.py --steps 3 --warmup 1 --verify --no-cpu-baseline --workload $W 2>/dev/null > gpurun_out/sweep_$v.log
+for v in ${VARIANTS:-0 1 2 3}; do      # the product library has four tile-scatter shapes; ablations and stamps: diagnostic library only (tools/phase_stamps.py)
+  SA_AMD_SORT_VARIANT=$v timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-end-to-end --no-cpu-baseline --workload $W 2>/dev/null > gpurun_out/sweep_$v.log
   python - <<PY
 import json
 try:
