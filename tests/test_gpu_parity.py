@@ -1,5 +1,6 @@
 """GPU suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
 bytes.  Bit-exact everywhere (integer / index work)."""
+import ctypes
 import json
 import os
 
@@ -461,6 +462,47 @@ def test_any_environment_is_bit_exact(oracle, monkeypatch):
         i = it % len(texts)
         env = {k: os.environ[k] for k in ALL_KNOBS if k in os.environ}
         assert np.array_equal(build(texts[i]), expected[i]), (it, i, env)
+
+
+def test_device_ordinal_from_the_environment(oracle, monkeypatch):
+    """SA_AMD_DEVICE picks the GPU of the host-pointer entry points; an ordinal that does not exist is an error code
+    (SA_AMD_EINVAL), never another result; text that is not a number is ignored"""
+    s = corpus.english(30_000, 2)
+    exp = oracle.sais(s)
+    monkeypatch.setenv("SA_AMD_DEVICE", "0")
+    assert np.array_equal(build(s), exp)
+    monkeypatch.setenv("SA_AMD_DEVICE", "not a number")
+    assert np.array_equal(build(s), exp)
+    monkeypatch.setenv("SA_AMD_DEVICE", str(sa.lib().sa_amd_device_count() + 5))
+    with pytest.raises(sa.SuffixArrayError) as e:
+        build(s)
+    assert e.value.code == -1
+    out = np.zeros(s.size + 1, dtype=np.uint32)
+    st = (ctypes.c_int32 * 1)()
+    T = (ctypes.c_void_p * 1)(s.ctypes.data); S = (ctypes.c_void_p * 1)(out.ctypes.data)
+    N = (ctypes.c_int32 * 1)(s.size); D = (ctypes.c_int32 * 1)(77)
+    assert sa.lib().sa_amd_saca_batch(T, S, N, D, 1, st) == -1 and st[0] == -1          # bad ordinal in the batch call
+
+
+def test_unpack_rejects_truncated_data():
+    """a packed file whose data section is shorter than the full blocks it must contain is InvalidData, not an array with
+    zeros filled in; misaligned device scratch is rejected by sa_amd_saca_device"""
+    rng = np.random.default_rng(3)
+    arr = rng.permutation(1000).astype(np.uint32)
+    blob = sa.pack(arr)
+    cut = bytearray(blob[: 16 + 3 * 160])                     # three of eight 10-bit blocks
+    cut[8:16] = int(len(cut) - 16).to_bytes(8, "little")      # a consistent header: only the block count is wrong
+    with pytest.raises(ValueError):
+        sa.unpack(bytes(cut))
+    import torch
+    dev = torch.device("cuda", 0)
+    t = torch.zeros(4096, dtype=torch.uint8, device=dev); o = torch.zeros(4097, dtype=torch.int32, device=dev)
+    wb = sa.workspace_bytes(4096)
+    w = torch.zeros(wb + 512, dtype=torch.uint8, device=dev)
+    base = w.data_ptr()
+    aligned = (base + 255) & ~255
+    assert sa.lib().sa_amd_saca_device(t.data_ptr(), o.data_ptr(), 4096, aligned, wb, None, None) == 0
+    assert sa.lib().sa_amd_saca_device(t.data_ptr(), o.data_ptr(), 4096, aligned + 4, wb, None, None) == -1
 
 
 # ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------

@@ -20,6 +20,22 @@ cd $R
 python tools/pmc_traffic.py $O/pmc $O/traffic.json c3_english_256m 268435456
 find $O/pmc -name "*.csv" -delete
 find $O/prof_stats -name "*kernel_trace.csv" -delete
+# ---- timelines, adversarial families, host path, A/B runs ----
+for w in c3_english_256m c3_iid_256m adv:one:268435456 adv:twice:268435456; do
+  f=$(echo $w | tr ':' '_')
+  SA_AMD_VERBOSE=3 timeout -k 10 200 python tools/round_trace.py $w > $O/round_trace_$f.txt 2>&1
+done
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace -d $O/prof_seq -o d --output-format csv -- python3 $R/tools/ab_env.py c3_english_256m - > $O/prof_seq.log 2>&1
+cd $R
+python tools/trace_sequence.py $O/prof_seq/d_kernel_trace.csv -2 > $O/c3_dispatch_sequence.txt
+rm -rf $O/prof_seq
+timeout -k 10 900 python tools/adversarial_timing.py 268435456 > $O/adversarial_256m.txt 2>&1
+( [ -x tools/bin/pcie_probe ] && timeout -k 10 300 tools/bin/pcie_probe 1024; timeout -k 10 300 python tools/host_api_timing.py; timeout -k 10 100 python tools/small_latency.py ) > $O/host_path.txt 2>&1
+timeout -k 10 300 python tools/ab_env.py c3_english_256m - SA_AMD_NO_REPEAT_PROBE=1 SA_AMD_NO_REPEAT_PROBE=1,SA_AMD_MAX_TEXT_ROUNDS=1 SA_AMD_FORCE_DENSE=1 > $O/ab_text_rounds_vs_doubling.txt 2>&1
+timeout -k 10 300 python tools/ab_env.py c3_iid_256m - SA_AMD_FORCE_DENSE=1 SA_AMD_MAX_TEXT_ROUNDS=1 >> $O/ab_text_rounds_vs_doubling.txt 2>&1
+timeout -k 10 300 python tools/ab_env.py c3_english_256m - SA_AMD_CHASE=1 SA_AMD_CHASE=3 SA_AMD_CHASE=15 SA_AMD_SCATTER_LEVELS=1 SA_AMD_SCATTER_LEVELS=2 SA_AMD_BINNED_MIN=4194304 SA_AMD_BINNED_MIN=268435457 SA_AMD_NO_RUN_SKIP=1 SA_AMD_GROUP_CAP=256 SA_AMD_GROUP_CAP=512 > $O/ab_refinement_knobs.txt 2>&1
+tail -3 $O/adversarial_256m.txt; tail -4 $O/ab_refinement_knobs.txt
 for w in c3_english_256m c3_iid_256m c2_uniform_256m c2_uniform_64m c4_dna_1g c5_uniform_512m; do python - <<PY
 import json
 r = json.load(open("$O/bench_$w.json"))
