@@ -494,15 +494,24 @@ def test_unpack_rejects_truncated_data():
     cut[8:16] = int(len(cut) - 16).to_bytes(8, "little")      # a consistent header: only the block count is wrong
     with pytest.raises(ValueError):
         sa.unpack(bytes(cut))
-    import torch
-    dev = torch.device("cuda", 0)
-    t = torch.zeros(4096, dtype=torch.uint8, device=dev); o = torch.zeros(4097, dtype=torch.int32, device=dev)
+    hip = ctypes.CDLL("libamdhip64.so")                       # (already in the process: the product library links it)
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
     wb = sa.workspace_bytes(4096)
-    w = torch.zeros(wb + 512, dtype=torch.uint8, device=dev)
-    base = w.data_ptr()
-    aligned = (base + 255) & ~255
-    assert sa.lib().sa_amd_saca_device(t.data_ptr(), o.data_ptr(), 4096, aligned, wb, None, None) == 0
-    assert sa.lib().sa_amd_saca_device(t.data_ptr(), o.data_ptr(), 4096, aligned + 4, wb, None, None) == -1
+    ptrs = []
+    for size in (4096, 4097 * 4, wb + 512):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), size) == 0
+        assert hip.hipMemset(p, 0, size) == 0
+        ptrs.append(p.value)
+    t, o, w = ptrs
+    aligned = (w + 255) & ~255
+    L = sa.lib()
+    assert L.sa_amd_saca_device(t, o, 4096, aligned, wb, None, None) == 0
+    assert L.sa_amd_saca_device(t, o, 4096, aligned + 4, wb, None, None) == -1
+    for p in ptrs:
+        hip.hipFree(p)
 
 
 # ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------
