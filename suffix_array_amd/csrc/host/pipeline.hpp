@@ -21,6 +21,7 @@ static const SortVariant sort_variants[] = {
     { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8>, "carry-completed lines 1024x8" },
     { 512, 16, 1, k_radix_downsweep_wcl<512, 16>, "carry-completed lines 512x16" },
     { 1024, 8, 2, k_radix_downsweep_wcl<1024, 8, 8>, "carry 1024x8, granule 8" },
+    // (two workgroups per CU at 64 VGPRs -- 1024x4 or 512x8 with granule 8 -- measured slower: C3-iid 28.0 -> 29.8 .. 33.9 ms)
 #ifdef SA_AMD_DIAG
     { 1024, 8, 2, k_radix_downsweep<1024, 8, 4>, "plain tile scatter 1024x8 (first generation)" },
     { 1024, 8, 2, k_radix_downsweep<1024, 8, 4, 1>, "plain 1024x8 ABLATION sequential stores (wrong results)" },
@@ -167,6 +168,7 @@ static const Sort32Variant sort32_variants[] = {
     { 8, k_radix_downsweep_wcl<SORT32_THREADS, 8, 16, 1, false, uint32_t> },
     { 16, k_radix_downsweep_wcl<SORT32_THREADS, 16, 16, 1, false, uint32_t> },        // spills
     { 8, k_radix_downsweep_wcl<SORT32_THREADS, 8, 16, 1, false, uint32_t, 8> },
+    // (two workgroups per CU: 1024 x 4 or 1024 x 8 with granule 8 and 64 VGPRs measured slower, 8.6 -> 9.0 .. 10.2 ms at 256 MiB)
 };
 constexpr int N_SORT32_VARIANTS = (int)(sizeof(sort32_variants) / sizeof(sort32_variants[0]));
 
