@@ -407,6 +407,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
             if (m_big * 2 > m) *local_ok = false;           // mostly large groups: not worth another local pass
             return SA_AMD_OK;
         }
+        if (m_big * 10 >= m * 9) *local_ok = false;     // (nearly) the whole list sits in groups no tile can own (runs, periodic texts): the next rounds skip the local pass
     }
     else {
         int64_t gblocks = ceil_div(m, GK_THREADS);
@@ -424,9 +425,33 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_SPARSE>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
     }
-    rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, kb + g_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn);
+    // the whole list through the global sort.  Large lists are keyed by (index of the group in the list, key2) instead of
+    // (28-bit slot of the group head, key2) when that saves radix passes: count the group heads, re-key in place, sort,
+    // put the head slots back (two extra streaming passes against up to four tile scatters)
+    int sort_bits = kb + g_bits;
+    bool rekeyed = false;
+    if (m >= tn.dense_rekey_min) {
+        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    (const uint8_t *)nullptr, Ucur, Gcur, m, w.tcnt, w.ft_cnt));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.thead, tiles, w.total + 8));
+        uint32_t groups = 0;
+        { const int rcw = read_words(&groups, w.total + 8, 4, st); if (rcw) return rcw; }
+        const int idx_bits = bit_length((uint64_t)(groups > 0 ? groups - 1 : 0));
+        if (ceil_div(kb + idx_bits, RADIX_BITS) < ceil_div(kb + g_bits, RADIX_BITS)) {
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rekey_dense), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rkA, Ucur, Gcur, m,
+                                                        (const uint32_t *)w.ft_cnt, kb));
+            sort_bits = kb + idx_bits;
+            rekeyed = true;
+        }
+    }
+    rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn);
     if (rc) return rc;
     local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m;
+    if (rekeyed) {
+        int64_t blocks = ceil_div(m, 1024);
+        if (blocks > 16384) blocks = 16384;
+        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_restore_heads), dim3((unsigned)blocks), dim3(256), 0, st, sr.keys, Gcur, m, kb));
+    }
     out->keys = sr.keys; out->vals = sr.vals; out->m_global = m;
     out->vnext = (sr.vals == Vcur) ? Valt : Vcur;
     return SA_AMD_OK;
@@ -826,6 +851,8 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     const int64_t depth_text = depth;
     int64_t h = depth;
     bool chase_ok = false;
+    int64_t m_local_off = m;                          // size of the tied list when the local pass was last in use
+    int rounds_local_off = 0;
     while (m > 0) {
         if (local.rounds >= 48) return SA_AMD_EINTERNAL;
         uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
@@ -836,6 +863,10 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         K.mode = sparse ? KS_SPARSE : KS_RANK; K.h = h; K.kb = key2_bits; K.isa = w.isa;
         // dense rounds chase (up to `chase` rank look-ups per member inside one launch) once a round has had no group left
         // for the global sort: from then on every surviving group is known to share (iters + 1) * h symbols
+        // the local pass was given up because (nearly) every member sat in a group no tile can own: it is tried again when the
+        // list has halved, and every third round anyway (a Fibonacci word's groups shrink while the list does not)
+        if (!local_ok && !tn.no_local_sort && (m * 2 < m_local_off || ++rounds_local_off >= 3)) local_ok = true;
+        if (local_ok) { m_local_off = m; rounds_local_off = 0; }
         K.iters = (!sparse && local_ok && chase_ok) ? tn.chase : 1;
         if (K.iters > 1) K.mode = KS_CHASE;
         K.has_isa = w.has_isa; K.sorted_keys = sorted0; K.sorted_top32 = sorted32; K.sa = SA; K.depth = depth_text; K.top_shift = top_shift;

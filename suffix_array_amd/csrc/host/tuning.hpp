@@ -50,6 +50,7 @@ struct Tuning {
     bool binned_isa_always = false;  // SA_AMD_BINNED_ISA_ALWAYS
     bool no_fused_hist = false;      // SA_AMD_NO_FUSED_HIST: every radix pass runs its own histogram kernel
     bool no_run_skip = false;        // SA_AMD_NO_RUN_SKIP
+    int64_t dense_rekey_min = (int64_t)1 << 22;   // SA_AMD_DENSE_REKEY_MIN: smallest whole-list global sort that is re-keyed by group index
     bool no_repeat_probe = false;    // SA_AMD_NO_REPEAT_PROBE: never start rank doubling right after the initial sort
     int64_t binned_min = (int64_t)1 << 26;   // SA_AMD_BINNED_MIN: fewest (suffix, rank) pairs a round bins before scattering
     int chase = 7;                   // SA_AMD_CHASE: rank look-ups per member and dense doubling round (1 = plain doubling), 1..15
@@ -83,6 +84,7 @@ struct Tuning {
         t.no_fused_hist = env_flag("SA_AMD_NO_FUSED_HIST");
         t.no_run_skip = env_flag("SA_AMD_NO_RUN_SKIP");
         t.no_repeat_probe = env_flag("SA_AMD_NO_REPEAT_PROBE");
+        t.dense_rekey_min = env_int("SA_AMD_DENSE_REKEY_MIN", (int64_t)1 << 22, 1, (int64_t)1 << 40);
         t.max_text_rounds = (int)env_int("SA_AMD_MAX_TEXT_ROUNDS", 4, 0, 8);
         t.chase = (int)env_int("SA_AMD_CHASE", 7, 1, 15);
         t.scatter_levels = (int)env_int("SA_AMD_SCATTER_LEVELS", 0, 0, 2);

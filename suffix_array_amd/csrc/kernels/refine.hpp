@@ -890,7 +890,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_flag_count(const uint8_t *__rest
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
         const int64_t i = wbase + 64 * r + l;
-        const bool f = i < m && flag[i] != 0;
+        const bool f = i < m && (!flag || flag[i] != 0);       // flag == nullptr: every member (the whole list goes through the global sort)
         const bool hd = f && U[i] == G[i];
         c += (uint32_t)__popcll(__ballot(f));
         h += (uint32_t)__popcll(__ballot(hd));
@@ -943,6 +943,50 @@ __global__ __launch_bounds__(RR_THREADS) void k_flag_gather(const uint8_t *__res
         off += (uint32_t)__popcll(fm[r]);
         heads += (uint32_t)__popcll(hm[r]);
     }
+}
+
+// The whole list through the global sort (no tile could own most of it: runs, periodic texts): the keys are re-written in place
+// as (index of the group in the list << kb) | secondary key -- tile_heads holds the exclusive head counts of k_flag_count /
+// k_rr_scan with flag == nullptr -- and after the sort k_restore_heads puts the group-head slot back (a group keeps its list
+// positions).  A text of 1000 repeated blocks has 1000 groups: 10 + 30 key bits, five radix passes instead of eight.
+__global__ __launch_bounds__(RR_THREADS) void k_rekey_dense(uint64_t *__restrict__ keys, const uint32_t *__restrict__ U,
+                                                             const uint32_t *__restrict__ G, int64_t m,
+                                                             const uint32_t *__restrict__ tile_heads, int kb)
+{
+    constexpr int NW = RR_THREADS / WAVE;
+    __shared__ uint32_t wh[NW];
+    const int l = lane_id(), w = wave_id();
+    const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)w * RR_WAVE_ELEMS;
+    uint64_t hm[RR_ITEMS];
+    uint32_t h = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        hm[r] = __ballot(i < m && U[i] == G[i]);
+        h += (uint32_t)__popcll(hm[r]);
+    }
+    if (l == 0) wh[w] = h;
+    __syncthreads();
+    uint32_t heads = tile_heads[blockIdx.x];
+    for (int ww = 0; ww < w; ++ww) heads += wh[ww];
+    const uint64_t kmask = kb >= 64 ? ~0ull : ((1ull << kb) - 1ull);
+    const uint64_t le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        if (i < m) {
+            const uint32_t gi = heads + (uint32_t)__popcll(hm[r] & le_mask) - 1u;
+            keys[i] = ((uint64_t)gi << kb) | (keys[i] & kmask);
+        }
+        heads += (uint32_t)__popcll(hm[r]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_restore_heads(uint64_t *__restrict__ keys, const uint32_t *__restrict__ G, int64_t m, int kb)
+{
+    const uint64_t kmask = kb >= 64 ? ~0ull : ((1ull << kb) - 1ull);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += stride) keys[j] = ((uint64_t)G[j] << kb) | (keys[j] & kmask);
 }
 
 // sorted flagged elements back to their list positions (sorted by group first, and bidx is increasing,

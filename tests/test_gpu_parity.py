@@ -320,6 +320,10 @@ def test_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed):
     monkeypatch.setenv("SA_AMD_NO_LOCAL_SORT", "1")      # the probe path is off without the local sort
     assert np.array_equal(build(text), exp)
     assert sa.last_stats()["top32_first"] == 0
+    monkeypatch.setenv("SA_AMD_DENSE_REKEY_MIN", "1")    # every round: the whole list through the global sort, keyed by group index
+    assert np.array_equal(build(text), exp)
+    monkeypatch.setenv("SA_AMD_FORCE_DENSE", "1")
+    assert np.array_equal(build(text), exp)
 
 
 @pytest.mark.parametrize("gen,n,seed", [("english", 700_000, 11), ("dna", 1 << 20, 12), ("sigma3", 300_000, 13),
@@ -332,6 +336,7 @@ def test_group_sort_caps(oracle, monkeypatch, gen, n, seed, cap):
     text = corpus.sigma(n, seed, 3, 97) if gen == "sigma3" else getattr(corpus, gen)(n, seed)
     exp = oracle.sais(text)
     monkeypatch.setenv("SA_AMD_GROUP_CAP", cap)
+    monkeypatch.setenv("SA_AMD_DENSE_REKEY_MIN", "1")          # whole-list global sorts keyed by group index at any size
     for top32 in ("SA_AMD_FORCE_TOP32", "SA_AMD_NO_TOP32"):
         monkeypatch.delenv("SA_AMD_FORCE_TOP32", raising=False)
         monkeypatch.delenv("SA_AMD_NO_TOP32", raising=False)
@@ -424,7 +429,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_FORCE_DENSE", "SA_AMD_NO_TEXT_ROUNDS", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TOP32", "SA_AMD_FORCE_TOP32",
              "SA_AMD_NO_FUSED_FINISH", "SA_AMD_FUSED64", "SA_AMD_NO_PACKED_TEXT", "SA_AMD_NO_BINNED_ISA",
              "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_FUSED_HIST", "SA_AMD_NO_RUN_SKIP", "SA_AMD_TIMING_ONLY_INITIAL_SORT",
-             "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_SCATTER_LEVELS",
+             "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 

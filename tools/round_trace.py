@@ -12,7 +12,8 @@ for name in sys.argv[1:] or ["c3_english_256m"]:
         _, fam, nn = name.split(":"); nn = int(nn)
         t = {"one": lambda: np.full(nn, 97, dtype=np.uint8),
              "ab": lambda: np.resize(np.frombuffer(b"ab", dtype=np.uint8), nn).copy(),
-             "twice": lambda: np.concatenate([corpus.english(nn // 2, 5)] * 2)}[fam]()
+             "twice": lambda: np.concatenate([corpus.english(nn // 2, 5)] * 2),
+             "p1000": lambda: np.resize(np.random.default_rng(7).integers(0, 256, 1000, dtype=np.uint8), nn).copy()}[fam]()
     else:
         t = corpus.workload(name)
     out = np.zeros(t.size + 1, dtype=np.uint32)
