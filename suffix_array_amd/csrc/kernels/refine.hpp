@@ -202,7 +202,10 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         const bool head = (base + jl >= m) || u[r] == g[r];       // past the end counts as a group start
         const uint64_t hb = __ballot(head);
         if (lane_id() == 0) s_head[jl >> 6] = hb;
-        s_key[jl] = packed ? ((key[r] << 11) | (uint64_t)jl) : key[r];
+        // plain rank keys (n + rank or n - 1 - v, below 2^32): ranked as 32-bit words, ties by list position through the
+        // split of the counting loop at the member's own place -- one full-rate compare per step instead of a 64-bit one
+        if ((MODE == KS_RANK || MODE == KS_CHASE) && K.kb <= 32) ((uint32_t *)s_key)[jl] = (uint32_t)key[r];
+        else s_key[jl] = packed ? ((key[r] << 11) | (uint64_t)jl) : key[r];
     }
     if (t == 0) {
         // does a group start exactly at the first element after the tile?
@@ -254,7 +257,16 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         int rank = 0;
         start_[r] = start;
         uint32_t rng = ((uint32_t)jl << 16) | 1u;                // not owned: stays where it is, never tied
-        if (owned && CHASE) {
+        if (owned && CHASE && K.kb <= 32) {
+            const uint32_t *k32 = (const uint32_t *)s_key;
+            const uint32_t mine = (uint32_t)key[r];
+            int lt_a = 0, le_a = 0, lt_b = 0, le_b = 0;               // members before / behind me with a smaller, smaller-or-equal key
+            for (int i = start; i < jl; ++i) { const uint32_t k = k32[i]; lt_a += k < mine ? 1 : 0; le_a += k <= mine ? 1 : 0; }
+            for (int i = jl + 1; i < end; ++i) { const uint32_t k = k32[i]; lt_b += k < mine ? 1 : 0; le_b += k <= mine ? 1 : 0; }
+            rank = le_a + lt_b;                                        // an equal key before me orders before me
+            const int lt = lt_a + lt_b, le = le_a + le_b + 1;          // (+1: myself)
+            rng = ((uint32_t)(start + lt) << 16) | (uint32_t)(le - lt);
+        } else if (owned && CHASE) {
             const uint64_t mine = (key[r] << 11) | (uint64_t)jl;
             int lt = 0, le = 0;
             for (int i = start; i < end; ++i) {
@@ -264,6 +276,11 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
                 le += (k >> 11) <= key[r] ? 1 : 0;
             }
             rng = ((uint32_t)(start + lt) << 16) | (uint32_t)(le - lt);
+        } else if (owned && MODE == KS_RANK && K.kb <= 32) {
+            const uint32_t *k32 = (const uint32_t *)s_key;
+            const uint32_t mine = (uint32_t)key[r];
+            for (int i = start; i < jl; ++i) rank += k32[i] <= mine ? 1 : 0;        // an equal key before me orders before me
+            for (int i = jl + 1; i < end; ++i) rank += k32[i] < mine ? 1 : 0;
         } else if (owned && packed) {
             const uint64_t mine = (key[r] << 11) | (uint64_t)jl;
             for (int i = start; i < end; ++i) rank += s_key[i] < mine ? 1 : 0;
