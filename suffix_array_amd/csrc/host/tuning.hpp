@@ -48,8 +48,7 @@ struct Tuning {
     bool no_packed_text = false;     // SA_AMD_NO_PACKED_TEXT
     bool no_binned_isa = false;      // SA_AMD_NO_BINNED_ISA
     bool binned_isa_always = false;  // SA_AMD_BINNED_ISA_ALWAYS
-    bool no_fused_hist = false;      // SA_AMD_NO_FUSED_HIST: every radix pass runs its own histogram kernel
-    bool no_run_skip = false;        // SA_AMD_NO_RUN_SKIP
+    bool no_run_skip = false;        // SA_AMD_NO_RUN_SKIP: never skip a radix pass whose digit is the same for every element
     int64_t dense_rekey_min = (int64_t)1 << 22;   // SA_AMD_DENSE_REKEY_MIN: smallest whole-list global sort that is re-keyed by group index
     bool no_repeat_probe = false;    // SA_AMD_NO_REPEAT_PROBE: never start rank doubling right after the initial sort
     int64_t binned_min = (int64_t)1 << 26;   // SA_AMD_BINNED_MIN: fewest (suffix, rank) pairs a round bins before scattering
@@ -81,7 +80,6 @@ struct Tuning {
         t.no_packed_text = env_flag("SA_AMD_NO_PACKED_TEXT");
         t.no_binned_isa = env_flag("SA_AMD_NO_BINNED_ISA");
         t.binned_isa_always = env_flag("SA_AMD_BINNED_ISA_ALWAYS");
-        t.no_fused_hist = env_flag("SA_AMD_NO_FUSED_HIST");
         t.no_run_skip = env_flag("SA_AMD_NO_RUN_SKIP");
         t.no_repeat_probe = env_flag("SA_AMD_NO_REPEAT_PROBE");
         t.dense_rekey_min = env_int("SA_AMD_DENSE_REKEY_MIN", (int64_t)1 << 22, 1, (int64_t)1 << 40);

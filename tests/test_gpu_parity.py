@@ -428,7 +428,7 @@ def test_randomised_inputs_and_regimes(oracle, monkeypatch):
 ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", "SA_AMD_GROUP_CAP", "SA_AMD_SPARSE_DIV",
              "SA_AMD_FORCE_DENSE", "SA_AMD_NO_TEXT_ROUNDS", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TOP32", "SA_AMD_FORCE_TOP32",
              "SA_AMD_NO_FUSED_FINISH", "SA_AMD_FUSED64", "SA_AMD_NO_PACKED_TEXT", "SA_AMD_NO_BINNED_ISA",
-             "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_FUSED_HIST", "SA_AMD_NO_RUN_SKIP", "SA_AMD_TIMING_ONLY_INITIAL_SORT",
+             "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_RUN_SKIP", "SA_AMD_TIMING_ONLY_INITIAL_SORT",
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
