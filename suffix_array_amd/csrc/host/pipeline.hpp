@@ -294,13 +294,13 @@ static int scatter_binned(uint32_t *pk, uint32_t *pv, uint32_t *altk, uint32_t *
                           uint32_t *altk2 = nullptr, uint32_t *altv2 = nullptr)
 {
     const int nb = bit_length((uint64_t)(n > 1 ? n : 1));          // (the sentinel value n may be among the keys)
-    const bool two = tn.scatter_levels == 2 || (tn.scatter_levels == 0 && count >= ((int64_t)1 << 25));
+    int wlog = nb - 16;                                              // window = 2^wlog ISA entries, assembled in LDS
+    if (wlog < 10) wlog = 10;                                        // small texts: one pass covers the bits above the window
+    if (wlog > 15) wlog = 15;                                        // (n < 2^31, so nb <= 31)
+    // (a text of fewer than 2^10 bytes has no bits above the window: the one-pass form below does it)
+    const bool two = nb > wlog && (tn.scatter_levels == 2 || (tn.scatter_levels == 0 && count >= ((int64_t)1 << 25)));
     SortResult32 pr;
     if (two) {
-        int wlog = nb - 16;
-        const int small = nb < 10 ? nb : 10;
-        if (wlog < small) wlog = small;                              // small texts: one pass (or none) covers the bits above the window
-        if (wlog > 15) wlog = 15;                                    // (n < 2^31, so nb <= 31)
         int rc;
         if (iota) {
             const int mid = wlog + RADIX_BITS < nb ? wlog + RADIX_BITS : nb;

@@ -243,6 +243,28 @@ def test_binned_isa_update_path(oracle, monkeypatch, gen, n, seed):
     assert np.array_equal(build(text), exp)
 
 
+def test_binned_isa_paths_on_tiny_texts(oracle, monkeypatch):
+    """both binned ISA routes forced on texts far smaller than a window (found by tools/stress.py: with no key bits above
+    the window the two-pass route has nothing to sort and must hand over to the one-pass form)"""
+    rng = np.random.default_rng(5)
+    monkeypatch.setenv("SA_AMD_BINNED_ISA_ALWAYS", "1")
+    monkeypatch.setenv("SA_AMD_BINNED_MIN", "1")
+    for levels in ("1", "2"):
+        monkeypatch.setenv("SA_AMD_SCATTER_LEVELS", levels)
+        for dense in (True, False):
+            if dense:
+                monkeypatch.setenv("SA_AMD_FORCE_DENSE", "1")
+            else:
+                monkeypatch.delenv("SA_AMD_FORCE_DENSE", raising=False)
+                monkeypatch.setenv("SA_AMD_SPARSE_DIV", "1000000000")
+            for n in (2, 3, 21, 51, 222, 226, 1023, 1024, 1025, 2049, 5000):
+                for sig in (1, 3, 10):
+                    s = (rng.integers(0, sig, n) + 60).astype(np.uint8)
+                    s[n // 2:] = s[: n - n // 2]                       # a long repeat: several doubling rounds
+                    assert np.array_equal(build(s), oracle.sais(s)), (levels, dense, n, sig)
+        monkeypatch.delenv("SA_AMD_SPARSE_DIV", raising=False)
+
+
 def test_concurrent_callers(oracle):
     """SuffixArray is Send + Sync in the reference (src/sa.rs:15-19): arrays may be built from many
     threads at once; every thread owns its stream and device block here"""

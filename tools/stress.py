@@ -13,11 +13,15 @@ orc = Oracle()
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 BIG = int(sys.argv[3]) if len(sys.argv) > 3 else 400000
 ENV = ["SA_AMD_FORCE_TOP32", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TEXT_ROUNDS", "SA_AMD_FORCE_DENSE", "SA_AMD_BINNED_ISA_ALWAYS",
-       "SA_AMD_NO_TOP32", "SA_AMD_FUSED64", "SA_AMD_NO_FUSED_FINISH", "SA_AMD_NO_PACKED_TEXT"]
+       "SA_AMD_NO_TOP32", "SA_AMD_FUSED64", "SA_AMD_NO_FUSED_FINISH", "SA_AMD_NO_PACKED_TEXT", "SA_AMD_NO_REPEAT_PROBE",
+       "SA_AMD_NO_RUN_SKIP"]
+NUM = {"SA_AMD_SPARSE_DIV": [1, 4, 64, 10**9], "SA_AMD_GROUP_CAP": [2, 3, 7, 40, 300], "SA_AMD_CHASE": [1, 2, 3, 7, 15],
+       "SA_AMD_SCATTER_LEVELS": [1, 2], "SA_AMD_DENSE_REKEY_MIN": [1, 1000], "SA_AMD_MAX_TEXT_ROUNDS": [0, 1, 2, 6],
+       "SA_AMD_BINNED_MIN": [1, 5000], "SA_AMD_KEY_BITS": [16, 24, 40, 56]}
 t0 = time.time(); cases = 0; fails = 0
 while time.time() - t0 < budget:
     n = int(rng.choice([rng.integers(0, 300), rng.integers(300, 20000), rng.integers(20000, BIG)]))
-    kind = int(rng.integers(0, 7))
+    kind = int(rng.integers(0, 8))
     if kind == 0:
         s = rng.integers(0, 256, n, dtype=np.uint8)
     elif kind == 1:
@@ -33,18 +37,19 @@ while time.time() - t0 < budget:
                 ln = int(rng.integers(2, max(3, n // 3))); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln)); s[b:b + ln] = s[a:a + ln]
     elif kind == 5:
         s = np.concatenate([rng.integers(0, 3, n // 2, dtype=np.uint8), np.zeros(n - n // 2, dtype=np.uint8)])
-    else:
+    elif kind == 6:
         s = corpus.dna_repeats(n, int(rng.integers(0, 1 << 30)), 0.4) if n > 5000 else rng.integers(65, 69, n, dtype=np.uint8)
+    else:
+        s = corpus.english_corpus(n, int(rng.integers(0, 1 << 30)), 2000, 0.3) if n else np.zeros(0, np.uint8)
     s = np.ascontiguousarray(s, dtype=np.uint8)
-    for k in ENV + ["SA_AMD_SPARSE_DIV", "SA_AMD_GROUP_CAP"]:
+    for k in ENV + list(NUM):
         os.environ.pop(k, None)
     chosen = [k for k in ENV if rng.random() < 0.2]
     for k in chosen:
         os.environ[k] = "1"
-    if rng.random() < 0.3:
-        os.environ["SA_AMD_SPARSE_DIV"] = str(int(rng.choice([1, 4, 64, 10**9]))); chosen.append("DIV=" + os.environ["SA_AMD_SPARSE_DIV"])
-    if rng.random() < 0.3:
-        os.environ["SA_AMD_GROUP_CAP"] = str(int(rng.choice([2, 3, 7, 40, 300]))); chosen.append("CAP=" + os.environ["SA_AMD_GROUP_CAP"])
+    for k, vals in NUM.items():
+        if rng.random() < 0.25:
+            os.environ[k] = str(int(rng.choice(vals))); chosen.append(k[7:] + "=" + os.environ[k])
     try:
         got = sa.SuffixArray(s).into_parts()[1]
         ok = np.array_equal(got, orc.sais(s))
