@@ -102,7 +102,8 @@ static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)
 // straight into SA this way).
 static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, uint32_t *vals_alt, int64_t count,
                       int begin_bit, int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals,
-                      hipStream_t st, SortResult *res, const Tuning &tn, bool iota = false)   // iota: value i = index i, vals_in is scratch only
+                      hipStream_t st, SortResult *res, const Tuning &tn, bool iota = false,   // iota: value i = index i, vals_in is scratch only
+                      bool may_skip = false)                                                   // look for passes that are the identity (costs a read-back per pass)
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0; res->skipped = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
@@ -129,9 +130,10 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
         PROF(KC_SPINE, (int64_t)RADIX * g.G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st,
                                                                     spine, digit_tot, g.G));
         // A digit that is the same for EVERY element makes the pass the identity (the sort is stable): skip the tile scatter.
-        // Worth a 1 KiB read-back for large sorts only; texts that are one run or one period keep hundreds of millions of
-        // suffixes in a single group round after round, and their (group, rank) keys are constant in most digits.
-        if (!tn.no_run_skip && count >= ((int64_t)1 << 22) && !(iota && res->passes == 0) && !(last && final_vals)) {
+        // Worth a 1 KiB read-back (a host round trip of ~30 us) only for the large global sorts of the refinement rounds: texts
+        // that are one run or one period keep hundreds of millions of suffixes in a few groups round after round, and their
+        // (group, rank) keys are constant in most digits.  The initial sort and the ISA passes never look.
+        if (may_skip && !tn.no_run_skip && count >= tn.run_skip_min && !(iota && res->passes == 0) && !(last && final_vals)) {
             uint32_t tot[RADIX];
             { const int rcw = read_words(tot, digit_tot, sizeof(tot), st); if (rcw) return rcw; }
             bool constant = false;
@@ -395,7 +397,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
                 PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_flag_gather), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                             (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, Ucur, Gcur, m,
                                                             (const uint32_t *)w.tcnt, (const uint32_t *)w.ft_cnt, kb, rkB, Valt, scratchU));
-                rc = sort_pairs(rkB, Valt, rkB + half, Valt + half, m_big, 0, kb + idx_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn);
+                rc = sort_pairs(rkB, Valt, rkB + half, Valt + half, m_big, 0, kb + idx_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn, false, true);
                 if (rc) return rc;
                 local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m_big;
                 PROF(KC_SCATTER, m_big, st, hipLaunchKernelGGL((k_scatter_back), dim3((unsigned)ceil_div(m_big, 256)), dim3(256), 0, st,
@@ -444,7 +446,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
             rekeyed = true;
         }
     }
-    rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn);
+    rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn, false, true);
     if (rc) return rc;
     local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m;
     if (rekeyed) {

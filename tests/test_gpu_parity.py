@@ -181,10 +181,19 @@ def test_batch_entry_point(oracle):
         assert np.array_equal(o, oracle.sais(t))
 
 
-def test_degenerate_large_runs(oracle):
-    for s in (np.full(1 << 20, 0, dtype=np.uint8), np.tile(np.array([1, 2], dtype=np.uint8), 1 << 19),
-              np.full((1 << 20) + 3, 255, dtype=np.uint8)):
-        assert np.array_equal(build(s), oracle.sais(s))
+def test_degenerate_large_runs(oracle, monkeypatch):
+    """runs and periodic texts: one or a few huge groups in every round -- whole-list global sorts keyed by group index, radix
+    passes whose digit is constant skipped (both forced on at this size), the local pass given up and probed again"""
+    texts = (np.full(1 << 20, 0, dtype=np.uint8), np.tile(np.array([1, 2], dtype=np.uint8), 1 << 19),
+             np.full((1 << 20) + 3, 255, dtype=np.uint8), np.resize(np.arange(1, 98, dtype=np.uint8), 700_001).copy())
+    exp = [oracle.sais(s) for s in texts]
+    for env in ({}, {"SA_AMD_RUN_SKIP_MIN": "1", "SA_AMD_DENSE_REKEY_MIN": "1"}, {"SA_AMD_RUN_SKIP_MIN": "1", "SA_AMD_NO_LOCAL_SORT": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for s, e in zip(texts, exp):
+            assert np.array_equal(build(s), e), env
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def _planted(n, seed, copies):
@@ -450,7 +459,7 @@ def test_randomised_inputs_and_regimes(oracle, monkeypatch):
 ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", "SA_AMD_GROUP_CAP", "SA_AMD_SPARSE_DIV",
              "SA_AMD_FORCE_DENSE", "SA_AMD_NO_TEXT_ROUNDS", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TOP32", "SA_AMD_FORCE_TOP32",
              "SA_AMD_NO_FUSED_FINISH", "SA_AMD_FUSED64", "SA_AMD_NO_PACKED_TEXT", "SA_AMD_NO_BINNED_ISA",
-             "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_RUN_SKIP", "SA_AMD_TIMING_ONLY_INITIAL_SORT",
+             "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_RUN_SKIP", "SA_AMD_RUN_SKIP_MIN", "SA_AMD_TIMING_ONLY_INITIAL_SORT",
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
