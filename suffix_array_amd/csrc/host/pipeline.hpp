@@ -52,7 +52,7 @@ static SortGrid sort_grid(int64_t count, const SortVariant &sv)
 struct Workspace {
     uint64_t *keysA, *keysB, *keysC;
     uint32_t *valsA, *valsB, *isa, *U0, *U1, *G0, *G1;
-    uint32_t *spine, *digit_tot, *tcnt, *thead, *hist, *total, *has_isa;
+    uint32_t *spine, *digit_tot, *tcnt, *thead, *tnext, *hist, *total, *chg, *has_isa;
     uint8_t *packed;           // bit-packed text (alphabets of 2, 4 or 16 symbols): n / 2 + 64 bytes
     uint32_t *surv_bits, *surv_cnt, *todo_bits, *ft_cnt, *ft_head;   // first refinement round straight from the sorted keys (k_finish_sorted)
     size_t bytes;
@@ -79,8 +79,10 @@ static Workspace carve(void *base, int64_t n)
     const size_t rr_tiles = (size_t)ceil_div((int64_t)N, RR_TILE);
     w.tcnt = (uint32_t *)take(rr_tiles * 4);
     w.thead = (uint32_t *)take(rr_tiles * 4);
+    w.tnext = (uint32_t *)take(rr_tiles * 4);
     w.hist = (uint32_t *)take(256 * 4);
     w.total = (uint32_t *)take(256);
+    w.chg = (uint32_t *)take((size_t)RR_CHG_COUNTERS * 32 * 4);      // (directly behind w.total: read back together)
     w.has_isa = (uint32_t *)take((N + 31) / 32 * 4);
     w.packed = (uint8_t *)take(N / 2 + 64);
     w.surv_bits = (uint32_t *)take((N + 31) / 32 * 4);
@@ -261,9 +263,9 @@ struct PinnedWords {
     ~PinnedWords() { if (p) (void)hipHostFree(p); }
 };
 static thread_local PinnedWords g_pinned;
-static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)     // bytes <= 1024; synchronises the stream
+static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)     // bytes <= 2048; synchronises the stream
 {
-    if (!g_pinned.p && hipHostMalloc((void **)&g_pinned.p, 1024, hipHostMallocDefault) != hipSuccess) {
+    if (!g_pinned.p && hipHostMalloc((void **)&g_pinned.p, 2048, hipHostMallocDefault) != hipSuccess) {
         g_pinned.p = nullptr;
         (void)hipGetLastError();
         HIP_TRY(hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, st));
@@ -353,6 +355,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
     const int kb = K.kb;
     SortResult sr;
     int rc;
+    const bool had_local_pass = *local_ok;            // (then the keys are in rkA already when the whole list goes through the global sort after all)
     if (*local_ok) {
         uint8_t *flags = (uint8_t *)scratchG;
         const unsigned gs_blocks = (unsigned)ceil_div(m, GS_TILE);
@@ -411,25 +414,10 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         }
         if (m_big * 10 >= m * 9) *local_ok = false;     // (nearly) the whole list sits in groups no tile can own (runs, periodic texts): the next rounds skip the local pass
     }
-    else {
-        int64_t gblocks = ceil_div(m, GK_THREADS);
-        if (gblocks > 8192) gblocks = 8192;
-        if (K.mode == KS_TEXT)
-            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_TEXT>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
-                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
-        else if (K.mode == KS_LOWKEY)
-            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_LOWKEY>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
-                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
-        else if (K.mode == KS_RANK || K.mode == KS_CHASE)
-            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_RANK>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
-                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
-        else
-            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_SPARSE>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
-                                                      (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
-    }
     // the whole list through the global sort.  Large lists are keyed by (index of the group in the list, key2) instead of
-    // (28-bit slot of the group head, key2) when that saves radix passes: count the group heads, re-key in place, sort,
-    // put the head slots back (two extra streaming passes against up to four tile scatters)
+    // (28-bit slot of the group head, key2) when that saves radix passes: count the group heads first, then gather the keys in
+    // that form (k_gather_keyed) or re-key the ones the local pass left (k_rekey_dense).  The head slots are not put back
+    // after the sort: the re-rank kernels only compare neighbouring keys.
     int sort_bits = kb + g_bits;
     bool rekeyed = false;
     if (m >= tn.dense_rekey_min) {
@@ -440,20 +428,38 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         { const int rcw = read_words(&groups, w.total + 8, 4, st); if (rcw) return rcw; }
         const int idx_bits = bit_length((uint64_t)(groups > 0 ? groups - 1 : 0));
         if (ceil_div(kb + idx_bits, RADIX_BITS) < ceil_div(kb + g_bits, RADIX_BITS)) {
-            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rekey_dense), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rkA, Ucur, Gcur, m,
-                                                        (const uint32_t *)w.ft_cnt, kb));
             sort_bits = kb + idx_bits;
             rekeyed = true;
         }
     }
+    if (had_local_pass) {
+        if (rekeyed)
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rekey_dense), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rkA, Ucur, Gcur, m,
+                                                        (const uint32_t *)w.ft_cnt, kb));
+    } else if (K.mode == KS_SPARSE) {
+        // (a chain of ~60 dependent loads per suffix: one suffix per thread)
+        int64_t gblocks = ceil_div(m, GK_THREADS);
+        if (gblocks > 8192) gblocks = 8192;
+        PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_SPARSE>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
+                                                  (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
+        if (rekeyed)
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rekey_dense), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rkA, Ucur, Gcur, m,
+                                                        (const uint32_t *)w.ft_cnt, kb));
+    } else {
+        const uint32_t *th = rekeyed ? (const uint32_t *)w.ft_cnt : (const uint32_t *)nullptr;
+        if (K.mode == KS_TEXT)
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_keyed<KS_TEXT>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA));
+        else if (K.mode == KS_LOWKEY)
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_keyed<KS_LOWKEY>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA));
+        else
+            PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_keyed<KS_RANK>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                      (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA));
+    }
     rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn, false, true);
     if (rc) return rc;
     local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m;
-    if (rekeyed) {
-        int64_t blocks = ceil_div(m, 1024);
-        if (blocks > 16384) blocks = 16384;
-        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_restore_heads), dim3((unsigned)blocks), dim3(256), 0, st, sr.keys, Gcur, m, kb));
-    }
     out->keys = sr.keys; out->vals = sr.vals; out->m_global = m;
     out->vnext = (sr.vals == Vcur) ? Valt : Vcur;
     return SA_AMD_OK;
@@ -687,12 +693,12 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             if (rc) return rc;
             const int64_t tt = ceil_div(m_todo, RR_TILE);
             PROF(KC_RR_COUNT, m_todo, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st, rf.keys,
-                                                        (const uint32_t *)Ucur, m_todo, w.ft_cnt, w.ft_head, 0));
+                                                        (const uint32_t *)Ucur, m_todo, w.ft_cnt, w.ft_head, 0, (uint32_t *)nullptr, 0));
             PROF(KC_RR_SCAN, tt, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, tt, w.total + 4));
             PROF(KC_RR_APPLY, m_todo, st, hipLaunchKernelGGL((k_rr_apply<false, true, 4>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st,
                                                         rf.keys, rf.vals, (const uint32_t *)Ucur, m_todo, (const uint32_t *)w.ft_cnt,
                                                         (const uint32_t *)w.ft_head, SA, surv_head, Unext, Gnext, rf.vnext, (uint32_t)n,
-                                                        w.surv_bits, 0, (uint64_t *)nullptr, w.surv_cnt, (const uint32_t *)(w.total + 4), 0));
+                                                        w.surv_bits, 0, (uint64_t *)nullptr, w.surv_cnt, (const uint32_t *)(w.total + 4), 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
         }
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.surv_cnt, w.thead, tiles, w.total));
         { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
@@ -711,10 +717,10 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     if (!finished32 && !fused64) {
     if (top_shift)
         PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sorted32,
-                                                    (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0));
+                                                    (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
     else
         PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)sr.keys,
-                                                    (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0));
+                                                    (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
     PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
     { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
     m = m32;
@@ -728,7 +734,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     sorted32, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
                                                     (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
-                                                    w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+                                                    w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
         uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
         Refined rf;
         KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
@@ -736,13 +742,13 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         if (rc) return rc;
         tiles = ceil_div(m, RR_TILE);
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rf.keys,
-                                                    (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0));
+                                                    (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
         PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     rf.keys, rf.vals, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
                                                     (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, rf.vnext, (uint32_t)n,
                                                     (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
-                                                    (const uint32_t *)w.total, 0));
+                                                    (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
         { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
         m = m32;
         uint32_t *t;
@@ -768,14 +774,14 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             uint64_t *pk = (sr.keys == w.keysA) ? w.keysB : w.keysA;
             PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total, 0));
+                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
             rc = scatter_binned((uint32_t *)pk, w.U1, (uint32_t *)sr.keys, w.G1, n, n, w, st, &local, tn);
             if (rc) return rc;
         } else {
             PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
                                                         SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0,
-                                                        (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+                                                        (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
         }
     } else if (m > 0) {
         // compaction only; the sorted initial keys stay intact for the rank look-ups
@@ -786,7 +792,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         (const uint64_t *)sorted0, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
                                                         (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
-                                                        w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+                                                        w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
         }
         // ---- text-keyed rounds ----
         bool progressing = true;     // a text round that resolves little (runs, long repeats) is the last one
@@ -803,13 +809,13 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             uint32_t *Vnext = rf.vnext;
             tiles = ceil_div(m, RR_TILE);
             PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS,
-                                                        (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0));
+                                                        (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
             PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         keysS, valsS, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
                                                         (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, Vnext,
                                                         (uint32_t)n, (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
-                                                        (const uint32_t *)w.total, 0));
+                                                        (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
             { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
             m = m32;
             uint32_t *t;
@@ -853,6 +859,8 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     const int64_t depth_text = depth;
     int64_t h = depth;
     bool chase_ok = false;
+    bool parent_tail = false;                         // the ranks in the ISA are tail ranks (set by the first dense round)
+    int64_t changed_prev = 0;                         // ranks the last dense round wrote
     int64_t m_local_off = m;                          // size of the tied list when the local pass was last in use
     int rounds_local_off = 0;
     while (m > 0) {
@@ -877,29 +885,52 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         if (rc) return rc;
         const uint64_t *keysS = rf.keys; const uint32_t *valsS = rf.vals; uint32_t *Vnext = rf.vnext;
         tiles = ceil_div(m, RR_TILE);
-        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m, w.tcnt,
-                           w.thead, 0));
+        // dense rounds: a group's rank is its last slot + 1 and a parent's last subgroup keeps it (k_rr_apply, TAIL); the tiles
+        // then also need the first group start BEHIND them (k_rr_scan_next)
+        if (sparse)
+            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m, w.tcnt,
+                               w.thead, 0, (uint32_t *)nullptr, 0));
+        else
+            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false, uint64_t, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m,
+                               w.tcnt, w.thead, 0, w.tnext, key2_bits));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+        if (!sparse)
+            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan_next), dim3(1), dim3(SPINE_THREADS), 0, st, w.tnext, tiles, w.chg));
+        // binned or direct ISA stores: by the number of ranks this round is expected to write -- all of them when the parents'
+        // ranks are not tail ranks yet, otherwise about as many as the round before wrote
+        const int64_t expect = (!parent_tail || m < changed_prev) ? m : changed_prev;
         if (sparse) {
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
-        } else if (binned(n, m, tn)) {
+                                                        (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
+        } else if (binned(n, expect, tn)) {
             // Gcur has been consumed by the gather, the other key buffer by nothing: they take the pairs
             uint64_t *pk = (keysS == rkA) ? rkB : rkA;
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total, 0));
+                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total, 0,
+                                                        (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg));
             rc = scatter_binned((uint32_t *)pk, Gcur, (uint32_t *)keysS, (uint32_t *)valsS, m, n, w, st, &local, tn);
             if (rc) return rc;
         } else {
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
                                                         (uint32_t)n, (uint32_t *)nullptr, key2_bits, (uint64_t *)nullptr,
-                                                        (uint32_t *)nullptr, (const uint32_t *)w.total, 0));
+                                                        (uint32_t *)nullptr, (const uint32_t *)w.total, 0,
+                                                        (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg));
         }
-        { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
-        if (trace) fprintf(stderr, "suffix_array_amd: doubling round %d h %lld (%s, %d look-ups, %lld through the global sort): tied %lld -> %u\n", local.rounds + 1, (long long)h, sparse ? "sparse" : "dense", K.iters, (long long)rf.m_global, (long long)m, m32), fprintf(stderr, "    (%.2f ms)\n", lap());
+        {
+            // w.total (64 words) and the changed-rank counters behind it (w.chg) in one read-back
+            uint32_t words[64 + RR_CHG_COUNTERS * 32];
+            const int rcw = read_words(words, w.total, sparse ? 4 : sizeof(words), st); if (rcw) return rcw;
+            m32 = words[0];
+            if (!sparse) {
+                changed_prev = 0;
+                for (int c = 0; c < RR_CHG_COUNTERS; ++c) changed_prev += words[64 + c * 32];
+                parent_tail = true;
+            }
+        }
+        if (trace) fprintf(stderr, "suffix_array_amd: doubling round %d h %lld (%s, %d look-ups, %lld through the global sort): tied %lld -> %u, %lld ranks written\n", local.rounds + 1, (long long)h, sparse ? "sparse" : "dense", K.iters, (long long)rf.m_global, (long long)m, m32, sparse ? -1ll : (long long)changed_prev), fprintf(stderr, "    (%.2f ms)\n", lap());
         m = m32;
         uint32_t *t;
         t = Ucur; Ucur = Unext; Unext = t;

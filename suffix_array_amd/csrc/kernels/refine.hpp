@@ -119,7 +119,24 @@ __global__ __launch_bounds__(GK_THREADS) void k_gather_textkey(const uint32_t *_
     __syncthreads();
     const bool aligned8 = (((uintptr_t)T) & 7) == 0;
     const int64_t stride = (int64_t)gridDim.x * GK_THREADS;
-    for (int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x; j < m; j += stride)
+    int64_t j = (int64_t)blockIdx.x * GK_THREADS + threadIdx.x;
+    if (MODE != KS_SPARSE) {
+        // four members per thread and step: their look-ups (one random 64-byte sector each) are in flight together -- with
+        // one at a time the kernel ran at the latency of a memory access, not at the rate of the memory system
+        // (Fibonacci word, 268 M rank look-ups: 6.8 ms)
+        constexpr int B = 4;
+        for (; j + (B - 1) * stride < m; j += B * stride) {
+            uint32_t v[B], g[B];
+            uint64_t k2[B];
+#pragma unroll
+            for (int q = 0; q < B; ++q) { v[q] = V[j + q * stride]; g[q] = G[j + q * stride]; }
+#pragma unroll
+            for (int q = 0; q < B; ++q) k2[q] = text_key2<MODE>(T, lcode, P, n, K, v[q], aligned8);
+#pragma unroll
+            for (int q = 0; q < B; ++q) keys[j + q * stride] = ((uint64_t)g[q] << K.kb) | k2[q];
+        }
+    }
+    for (; j < m; j += stride)
         keys[j] = ((uint64_t)G[j] << K.kb) | text_key2<MODE>(T, lcode, P, n, K, V[j], aligned8);
 }
 
@@ -964,8 +981,8 @@ __global__ __launch_bounds__(RR_THREADS) void k_flag_gather(const uint8_t *__res
 
 // The whole list through the global sort (no tile could own most of it: runs, periodic texts): the keys are re-written in place
 // as (index of the group in the list << kb) | secondary key -- tile_heads holds the exclusive head counts of k_flag_count /
-// k_rr_scan with flag == nullptr -- and after the sort k_restore_heads puts the group-head slot back (a group keeps its list
-// positions).  A text of 1000 repeated blocks has 1000 groups: 10 + 30 key bits, five radix passes instead of eight.
+// k_rr_scan with flag == nullptr.  The group-head slots are not put back after the sort (the re-rank kernels only compare
+// neighbouring keys).  A text of 1000 repeated blocks has 1000 groups: 10 + 30 key bits, five radix passes instead of eight.
 __global__ __launch_bounds__(RR_THREADS) void k_rekey_dense(uint64_t *__restrict__ keys, const uint32_t *__restrict__ U,
                                                              const uint32_t *__restrict__ G, int64_t m,
                                                              const uint32_t *__restrict__ tile_heads, int kb)
@@ -999,11 +1016,55 @@ __global__ __launch_bounds__(RR_THREADS) void k_rekey_dense(uint64_t *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_restore_heads(uint64_t *__restrict__ keys, const uint32_t *__restrict__ G, int64_t m, int kb)
+// Gather of the secondary keys for a list that goes through the global sort as a whole, tile-structured (eight look-ups per
+// thread in flight) and keyed directly: tile_heads == nullptr: (group-head slot << kb) | key2, otherwise (index of the group
+// in the list << kb) | key2 as k_rekey_dense would make it.  Nothing restores the head slots after the sort: the re-rank
+// kernels only compare neighbouring keys.
+template <int MODE>
+__global__ __launch_bounds__(RR_THREADS) void k_gather_keyed(const uint32_t *__restrict__ V, const uint32_t *__restrict__ U,
+                                                              const uint32_t *__restrict__ G, const uint8_t *__restrict__ T, KeyParams P,
+                                                              int64_t m, int64_t n, KeySrc K, const uint32_t *__restrict__ tile_heads,
+                                                              uint64_t *__restrict__ keys)
 {
-    const uint64_t kmask = kb >= 64 ? ~0ull : ((1ull << kb) - 1ull);
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += stride) keys[j] = ((uint64_t)G[j] << kb) | (keys[j] & kmask);
+    constexpr int NW = RR_THREADS / WAVE;
+    __shared__ uint32_t wh[NW];
+    __shared__ uint8_t lcode[256];
+    if (threadIdx.x < 256) lcode[threadIdx.x] = P.code[threadIdx.x];
+    const bool aligned8 = (((uintptr_t)T) & 7) == 0;
+    const int l = lane_id(), w = wave_id();
+    const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)w * RR_WAVE_ELEMS;
+    uint32_t v[RR_ITEMS], g[RR_ITEMS];
+    uint64_t hm[RR_ITEMS];
+    uint32_t h = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        v[r] = i < m ? V[i] : 0u;
+        g[r] = i < m ? G[i] : 0u;
+        hm[r] = 0;
+        if (tile_heads) {                                       // (uniform)
+            hm[r] = __ballot(i < m && U[i] == g[r]);
+            h += (uint32_t)__popcll(hm[r]);
+        }
+    }
+    if (l == 0) wh[w] = h;
+    __syncthreads();
+    uint64_t k2[RR_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        k2[r] = i < m ? text_key2<MODE>(T, lcode, P, n, K, v[r], aligned8) : 0ull;
+    }
+    uint32_t heads = tile_heads ? tile_heads[blockIdx.x] : 0u;
+    if (tile_heads) for (int ww = 0; ww < w; ++ww) heads += wh[ww];
+    const uint64_t le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        const uint32_t hi = tile_heads ? heads + (uint32_t)__popcll(hm[r] & le_mask) - 1u : g[r];
+        if (i < m) keys[i] = ((uint64_t)hi << K.kb) | k2[r];
+        heads += (uint32_t)__popcll(hm[r]);
+    }
 }
 
 // sorted flagged elements back to their list positions (sorted by group first, and bidx is increasing,

@@ -26,15 +26,19 @@ constexpr int RR_WAVE_ELEMS = WAVE * RR_ITEMS;   // 512 consecutive elements per
 // instruction); the neighbour keys come from shuffles, so the whole classification is 8 ballots
 // and scalar bit arithmetic: head[r] bit l = element (r, l) starts a group, tied[r] bit l = it is
 // in a group of more than one element, valid[r] = it exists.
-struct WaveGroups { uint64_t head[RR_ITEMS], tied[RR_ITEMS], valid[RR_ITEMS]; };
+// PARENTS: phead[r] bit l = element (r, l) is the first one of its PARENT group (the group the round started from: a run
+// of equal key >> g_shift) -- the dense doubling rounds label a group by its LAST slot and leave the ranks of a parent's
+// last subgroup alone (see k_rr_apply)
+struct WaveGroups { uint64_t head[RR_ITEMS], tied[RR_ITEMS], valid[RR_ITEMS], phead[RR_ITEMS]; };
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 {
     return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, WAVE);
 }
 
-template <typename KeyT>
-__device__ __forceinline__ WaveGroups rr_wave_classify(const KeyT *__restrict__ keys, int64_t m, int64_t wbase, int key_shift)
+template <typename KeyT, bool PARENTS = false>
+__device__ __forceinline__ WaveGroups rr_wave_classify(const KeyT *__restrict__ keys, int64_t m, int64_t wbase, int key_shift, int g_shift = 0,
+                                                       uint64_t *kout = nullptr)      // kout: the wave's keys, [RR_ITEMS] = the key before the wave
 {
     const int l = lane_id();
     uint64_t k[RR_ITEMS];
@@ -54,6 +58,12 @@ __device__ __forceinline__ WaveGroups rr_wave_classify(const KeyT *__restrict__ 
         if (l == 0) up = prev_last;
         const int64_t i = wbase + 64 * r + l;
         g.head[r] = __ballot(i < m && (i == 0 || k[r] != up));
+        g.phead[r] = PARENTS ? __ballot(i < m && (i == 0 || ((k[r] ^ up) >> g_shift) != 0ull)) : 0ull;
+    }
+    if (kout) {
+#pragma unroll
+        for (int r = 0; r < RR_ITEMS; ++r) kout[r] = k[r];
+        kout[RR_ITEMS] = before;
     }
     const uint64_t last_key = shfl64(k[RR_ITEMS - 1], 63);
     const bool boundary_after = (wbase + RR_WAVE_ELEMS >= m) || after != last_key;
@@ -69,15 +79,36 @@ __device__ __forceinline__ WaveGroups rr_wave_classify(const KeyT *__restrict__ 
     return g;
 }
 
-template <bool FIRST, typename KeyT = uint64_t>
+// "head code" of the dense doubling rounds: (list index of a group start << 1) | (it also starts a parent group);
+// RR_NO_HEAD: there is none (list indices are below 2^31, so the code of index m with the parent bit set is the same word)
+constexpr uint32_t RR_NO_HEAD = 0xffffffffu;
+constexpr int RR_CHG_COUNTERS = 8;              // changed-rank counters of a dense round, 32 words apart (1 KiB: one read-back)
+__device__ __forceinline__ uint32_t rr_first_head_code(const WaveGroups &g, int64_t wbase, int r_from)
+{
+    uint32_t code = RR_NO_HEAD;
+#pragma unroll
+    for (int r = RR_ITEMS - 1; r >= 0; --r) {
+        if (r >= r_from && g.head[r]) {
+            const int b = __builtin_ctzll(g.head[r]);
+            code = ((uint32_t)(wbase + 64 * r + b) << 1) | (uint32_t)((g.phead[r] >> b) & 1ull);
+        }
+    }
+    return code;
+}
+
+// PARENTS (dense doubling rounds): also tile_first, the head code of the tile's first group start (g_shift: the parent
+// group is the key above that bit)
+template <bool FIRST, typename KeyT = uint64_t, bool PARENTS = false>
 __global__ __launch_bounds__(RR_THREADS) void k_rr_count(const KeyT *__restrict__ keys,
                                                           const uint32_t *__restrict__ U, int64_t m,
                                                           uint32_t *__restrict__ tile_cnt,
-                                                          uint32_t *__restrict__ tile_head, int key_shift)
+                                                          uint32_t *__restrict__ tile_head, int key_shift,
+                                                          uint32_t *__restrict__ tile_first, int g_shift)
 {
-    __shared__ uint32_t wcnt[RR_THREADS / WAVE], whead[RR_THREADS / WAVE];
+    __shared__ uint32_t wcnt[RR_THREADS / WAVE], whead[RR_THREADS / WAVE], wfirst[RR_THREADS / WAVE];
     const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)wave_id() * RR_WAVE_ELEMS;
-    const WaveGroups g = rr_wave_classify(keys, m, wbase, key_shift);
+    uint64_t kk[RR_ITEMS + 1];
+    const WaveGroups g = rr_wave_classify<KeyT, false>(keys, m, wbase, key_shift, 0, PARENTS ? kk : nullptr);
     uint32_t cnt = 0, lasthead = 0;
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
@@ -87,14 +118,62 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_count(const KeyT *__restrict_
             lasthead = (FIRST ? (uint32_t)i : U[i]) + 1u;       // slots grow with the index: the last head wins
         }
     }
-    if (lane_id() == 0) { wcnt[wave_id()] = cnt; whead[wave_id()] = lasthead; }
+    // the wave's first group start, and whether its parent group starts there too: only that one element's key and its left
+    // neighbour's are compared (wave-uniform item and lane: two shuffles, not a ballot per item)
+    uint32_t first_code = RR_NO_HEAD;
+    if (PARENTS) {
+        bool found = false;
+#pragma unroll
+        for (int r = 0; r < RR_ITEMS; ++r) {
+            if (!found && g.head[r]) {                          // (uniform)
+                found = true;
+                const int b = __builtin_ctzll(g.head[r]);
+                const uint64_t mine = shfl64(kk[r], b);
+                const uint64_t left = b ? shfl64(kk[r], b - 1) : (r ? shfl64(kk[r ? r - 1 : 0], 63) : kk[RR_ITEMS]);
+                const int64_t i = wbase + 64 * r + b;
+                const uint32_t ph = (i == 0 || ((mine ^ left) >> g_shift) != 0ull) ? 1u : 0u;
+                first_code = ((uint32_t)i << 1) | ph;
+            }
+        }
+    }
+    if (lane_id() == 0) { wcnt[wave_id()] = cnt; whead[wave_id()] = lasthead; wfirst[wave_id()] = first_code; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tot = 0, mx = 0;
-        for (int w = 0; w < RR_THREADS / WAVE; ++w) { tot += wcnt[w]; mx = mx > whead[w] ? mx : whead[w]; }
+        uint32_t tot = 0, mx = 0, fc = RR_NO_HEAD;
+        for (int w = 0; w < RR_THREADS / WAVE; ++w) { tot += wcnt[w]; mx = mx > whead[w] ? mx : whead[w]; fc = fc < wfirst[w] ? fc : wfirst[w]; }
         tile_cnt[blockIdx.x] = tot;
         tile_head[blockIdx.x] = mx;
+        if (PARENTS) tile_first[blockIdx.x] = fc;
     }
+}
+
+// one workgroup: tile_first (head code of every tile's first group start) -> for every tile the smallest code of the tiles
+// BEHIND it (RR_NO_HEAD: no group starts behind this tile); also clears the round's changed-rank counter
+__global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan_next(uint32_t *__restrict__ tile_first, int64_t tiles, uint32_t *__restrict__ changed_cnt)
+{
+    __shared__ uint32_t s_min[SPINE_THREADS];
+    const int t = threadIdx.x;
+    const int64_t per = (tiles + SPINE_THREADS - 1) / SPINE_THREADS;
+    int64_t b = (int64_t)t * per, e = b + per;
+    if (b > tiles) b = tiles;
+    if (e > tiles) e = tiles;
+    uint32_t mn = RR_NO_HEAD;
+    for (int64_t i = b; i < e; ++i) { const uint32_t c = tile_first[i]; mn = mn < c ? mn : c; }
+    s_min[t] = mn;
+    __syncthreads();
+    for (int o = 1; o < SPINE_THREADS; o <<= 1) {            // inclusive suffix minimum over the threads
+        const uint32_t other = t + o < SPINE_THREADS ? s_min[t + o] : RR_NO_HEAD;
+        __syncthreads();
+        if (other < s_min[t]) s_min[t] = other;
+        __syncthreads();
+    }
+    uint32_t run = t + 1 < SPINE_THREADS ? s_min[t + 1] : RR_NO_HEAD;     // everything behind this thread's tiles
+    for (int64_t i = e - 1; i >= b; --i) {
+        const uint32_t c = tile_first[i];
+        tile_first[i] = run;
+        run = run < c ? run : c;
+    }
+    if (t < RR_CHG_COUNTERS && changed_cnt) changed_cnt[t * 32] = 0u;
 }
 
 // one workgroup: tile_cnt -> exclusive sums (+ total), tile_head -> exclusive running max.
@@ -154,11 +233,23 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_head, uint32_t *__restrict__ SA,
     uint32_t *__restrict__ ISA, uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo,
     uint32_t n_text, uint32_t *__restrict__ has_isa, int g_shift, uint64_t *__restrict__ pair_k,
-    uint32_t *__restrict__ pair_v, const uint32_t *__restrict__ tile_total, int key_shift)
+    uint32_t *__restrict__ pair_v, const uint32_t *__restrict__ tile_total, int key_shift,
+    const uint32_t *__restrict__ tile_next, int parent_tail, uint32_t *__restrict__ changed_cnt)
 {
     constexpr bool SPARSE = ISA_MODE == 1;
+    // Dense doubling rounds (TAIL): the rank of a group is its LAST slot + 1 (Larsson-Sadakane's group number).  When a
+    // parent group splits, its last subgroup ends where the parent ended, so its members' ranks in the ISA are already
+    // right and are not rewritten.  A run, a periodic text or a long repeat that runs into the end of the text sheds its
+    // shortest -- smallest -- suffixes at the FRONT of every group round after round: with ranks counted from the first
+    // slot every one of the hundreds of millions of remaining members changed rank every round, with ranks counted from
+    // the last slot only the members that leave do.  parent_tail = 0: the parents' ranks are not of this form (first
+    // doubling round: ranks from the initial order), everything is written.  changed_cnt: ranks written (steers the
+    // host's choice between binned and direct ISA stores in the next round).
+    constexpr bool TAIL = !FIRST && (ISA_MODE == 0 || ISA_MODE == 2);
     constexpr int NW = RR_THREADS / WAVE;
-    __shared__ uint32_t wcnt[NW], whead[NW];
+    __shared__ uint32_t wcnt[NW], whead[NW], wfirst[NW];
+    __shared__ uint32_t s_chg;
+    if (TAIL && threadIdx.x == 0) s_chg = 0;          // (the barrier behind the wave totals orders it before the adds)
     if (FIRST && !WRITE_SA && SPARSE) {
         // compaction-only pass (no SA, no ISA write): a tile without tied suffixes has nothing to do
         const uint32_t here = tile_cnt[blockIdx.x];
@@ -167,7 +258,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     }
     const int l = lane_id(), w = wave_id();
     const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)w * RR_WAVE_ELEMS;
-    const WaveGroups g = rr_wave_classify(keys, m, wbase, key_shift);
+    const WaveGroups g = rr_wave_classify<KeyT, TAIL>(keys, m, wbase, key_shift, g_shift);
     uint32_t slot[RR_ITEMS], v[RR_ITEMS];
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
@@ -184,11 +275,28 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
             cnt += (uint32_t)__popcll(g.tied[r]);
             if (g.head[r]) lasthead = (uint32_t)__shfl((int)slot[r], 63 - __builtin_clzll(g.head[r]), WAVE) + 1u;
         }
-        if (l == 0) { wcnt[w] = cnt; whead[w] = lasthead; }
+        if (l == 0) { wcnt[w] = cnt; whead[w] = lasthead; wfirst[w] = TAIL ? rr_first_head_code(g, wbase, 0) : RR_NO_HEAD; }
     }
     __syncthreads();
     uint32_t run_cnt = tile_cnt[blockIdx.x], run_head = tile_head[blockIdx.x];     // carried in from the tiles before
     for (int ww = 0; ww < w; ++ww) { run_cnt += wcnt[ww]; run_head = run_head > whead[ww] ? run_head : whead[ww]; }
+    // TAIL: next_code[r] = head code of the first group start behind item r of this wave (later items, later waves, later tiles;
+    // none: the list ends there, which also ends the parent)
+    uint32_t next_code[RR_ITEMS];
+    uint32_t n_changed = 0;
+    if (TAIL) {
+        uint32_t behind = tile_next[blockIdx.x];
+        for (int ww = NW - 1; ww > w; --ww) behind = wfirst[ww] != RR_NO_HEAD ? wfirst[ww] : behind;
+        if (behind == RR_NO_HEAD) behind = ((uint32_t)m << 1) | 1u;
+#pragma unroll
+        for (int r = RR_ITEMS - 1; r >= 0; --r) {
+            next_code[r] = behind;
+            if (g.head[r]) {
+                const int b = __builtin_ctzll(g.head[r]);
+                behind = ((uint32_t)(wbase + 64 * r + b) << 1) | (uint32_t)((g.phead[r] >> b) & 1ull);
+            }
+        }
+    }
     const uint64_t le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);              // lanes <= l
     const uint64_t lt_mask = le_mask >> 1;                                          // lanes <  l
 #pragma unroll
@@ -200,17 +308,28 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         const uint32_t hslot = (uint32_t)__shfl((int)slot[r], src, WAVE);
         const uint32_t run = hle ? hslot + 1u : run_head;
         const uint32_t off = run_cnt + (uint32_t)__popcll(g.tied[r] & lt_mask);
+        uint32_t rank = run;                      // the value that goes into the ISA
+        bool changed = true;
+        if (TAIL) {
+            const uint64_t hgt = (l == 63) ? 0ull : (g.head[r] & (~0ull << (l + 1)));   // group starts behind this lane in the item
+            uint32_t code = next_code[r];
+            if (hgt) {
+                const int b = __builtin_ctzll(hgt);
+                code = ((uint32_t)(wbase + 64 * r + b) << 1) | (uint32_t)((g.phead[r] >> b) & 1ull);
+            }
+            // the group's slots are consecutive: its last one = my slot + (members behind me)
+            rank = slot[r] + ((code >> 1) - 1u - (uint32_t)i) + 1u;
+            changed = !(parent_tail && (code & 1u));
+            n_changed += (uint32_t)__popcll(__ballot(i < m && changed));
+        }
         if (i < m) {
             if (WRITE_SA && slot[r] < n_text) SA[slot[r]] = v[r];
             if (ISA_MODE == 2) {
                 ((uint32_t *)pair_k)[i] = v[r];          // (suffix, rank) as 32-bit pairs: binned by one 32-bit radix pass
-                pair_v[i] = run;
+                pair_v[i] = rank;
             } else if (ISA_MODE != 3 && ISA_MODE != 4 && v[r] < n_text) {
-                // refinement rounds: the key's high part is the old group head, i.e. the rank already in ISA;
-                // the first subgroup of a split group keeps its rank and is not rewritten
-                const uint32_t oldrank = (FIRST || ISA_MODE != 0) ? 0u : (uint32_t)((uint64_t)keys[i] >> g_shift) + 1u;
-                if (run != oldrank) {
-                    ISA[v[r]] = run;
+                if (changed) {
+                    ISA[v[r]] = rank;
                     if (SPARSE) atomicOr(&has_isa[v[r] >> 5], 1u << (v[r] & 31u));   // this rank overrides the initial one
                 }
             }
@@ -227,6 +346,13 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         }
         run_cnt += (uint32_t)__popcll(g.tied[r]);
         if (g.head[r]) run_head = (uint32_t)__shfl((int)slot[r], 63 - __builtin_clzll(g.head[r]), WAVE) + 1u;
+    }
+    if (TAIL) {
+        // one global atomic per workgroup, spread over RR_CHG_COUNTERS words in different 128-byte lines (a single
+        // counter bumped by every wave serialises in one L2 channel: 465 K atomics cost 4 ms at 256 MiB)
+        if (l == 0 && n_changed) atomicAdd(&s_chg, n_changed);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_chg) atomicAdd(&changed_cnt[(blockIdx.x % RR_CHG_COUNTERS) * 32], s_chg);
     }
 }
 

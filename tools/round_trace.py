@@ -12,6 +12,7 @@ for name in sys.argv[1:] or ["c3_english_256m"]:
         _, fam, nn = name.split(":"); nn = int(nn)
         t = {"one": lambda: np.full(nn, 97, dtype=np.uint8),
              "ab": lambda: np.resize(np.frombuffer(b"ab", dtype=np.uint8), nn).copy(),
+             "fib": lambda: (lambda f: np.frombuffer(f(nn)[:nn], dtype=np.uint8).copy())(lambda k: (lambda ab: ab)(__import__("functools").reduce(lambda p, _: (p[1], p[1] + p[0]) if len(p[1]) < k else p, range(64), (b"a", b"ab"))[1])),
              "twice": lambda: np.concatenate([corpus.english(nn // 2, 5)] * 2),
              "p1000": lambda: np.resize(np.random.default_rng(7).integers(0, 256, 1000, dtype=np.uint8), nn).copy()}[fam]()
     else:
