@@ -349,12 +349,26 @@ struct Refined { const uint64_t *keys; const uint32_t *vals; uint32_t *vnext; in
 static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *Valt, const uint32_t *Ucur, const uint32_t *Gcur,
                        uint32_t *scratchU, uint32_t *scratchG, int64_t m, int64_t n, const uint8_t *dT, const KeyParams &P,
                        const KeySrc &K, int g_bits, bool *local_ok, const Workspace &w, hipStream_t st, sa_amd_stats *local,
-                       Refined *out, const Tuning &tn)
+                       Refined *out, const Tuning &tn, bool retry_local = false)
 {
     const int64_t tiles = ceil_div(m, RR_TILE);
     const int kb = K.kb;
     SortResult sr;
     int rc;
+    // The local pass was given up because (nearly) every member sat in a group no tile can own.  Lists large enough for the
+    // dense group index count their groups anyway: when the average group has come down to about what a tile can own
+    // (a Fibonacci word's groups shrink while the list does not), the local pass is tried again -- in this round
+    bool counted = false;
+    uint32_t groups = 0;
+    if (!*local_ok && retry_local && !tn.no_local_sort && m < tn.dense_rekey_min) *local_ok = true;     // (small lists do not count their groups)
+    if (!*local_ok && retry_local && !tn.no_local_sort && m >= tn.dense_rekey_min) {
+        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                    (const uint8_t *)nullptr, Ucur, Gcur, m, w.tcnt, w.ft_cnt));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.thead, tiles, w.total + 8));
+        { const int rcw = read_words(&groups, w.total + 8, 4, st); if (rcw) return rcw; }
+        counted = true;
+        if ((int64_t)groups * 2 * tn.group_cap >= m) *local_ok = true;
+    }
     const bool had_local_pass = *local_ok;            // (then the keys are in rkA already when the whole list goes through the global sort after all)
     if (*local_ok) {
         uint8_t *flags = (uint8_t *)scratchG;
@@ -421,11 +435,12 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
     int sort_bits = kb + g_bits;
     bool rekeyed = false;
     if (m >= tn.dense_rekey_min) {
-        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                    (const uint8_t *)nullptr, Ucur, Gcur, m, w.tcnt, w.ft_cnt));
-        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.thead, tiles, w.total + 8));
-        uint32_t groups = 0;
-        { const int rcw = read_words(&groups, w.total + 8, 4, st); if (rcw) return rcw; }
+        if (!counted || had_local_pass) {              // (the local pass has used the count arrays for its own compaction)
+            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        (const uint8_t *)nullptr, Ucur, Gcur, m, w.tcnt, w.ft_cnt));
+            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.thead, tiles, w.total + 8));
+            { const int rcw = read_words(&groups, w.total + 8, 4, st); if (rcw) return rcw; }
+        }
         const int idx_bits = bit_length((uint64_t)(groups > 0 ? groups - 1 : 0));
         if (ceil_div(kb + idx_bits, RADIX_BITS) < ceil_div(kb + g_bits, RADIX_BITS)) {
             sort_bits = kb + idx_bits;
@@ -874,15 +889,18 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         // dense rounds chase (up to `chase` rank look-ups per member inside one launch) once a round has had no group left
         // for the global sort: from then on every surviving group is known to share (iters + 1) * h symbols
         // the local pass was given up because (nearly) every member sat in a group no tile can own: it is tried again when the
-        // list has halved, and every third round anyway (a Fibonacci word's groups shrink while the list does not)
-        if (!local_ok && !tn.no_local_sort && (m * 2 < m_local_off || ++rounds_local_off >= 3)) local_ok = true;
-        if (local_ok) { m_local_off = m; rounds_local_off = 0; }
+        // list has halved, and every third round -- if refine_list then finds the average group small enough for a tile (large
+        // lists count their groups anyway; a Fibonacci word's groups shrink while the list does not, a periodic text's never do)
+        if (!local_ok && !tn.no_local_sort && m * 2 < m_local_off) local_ok = true;
+        const bool retry_local = !local_ok && ++rounds_local_off >= 3;
         K.iters = (!sparse && local_ok && chase_ok) ? tn.chase : 1;
         if (K.iters > 1) K.mode = KS_CHASE;
         K.has_isa = w.has_isa; K.sorted_keys = sorted0; K.sorted_top32 = sorted32; K.sa = SA; K.depth = depth_text; K.top_shift = top_shift;
         Refined rf;
-        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn);
+        if (local_ok) { m_local_off = m; rounds_local_off = 0; }
+        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn, retry_local);
         if (rc) return rc;
+        if (retry_local && rf.m_global < m) { m_local_off = m; rounds_local_off = 0; }      // (the local pass ran again)
         const uint64_t *keysS = rf.keys; const uint32_t *valsS = rf.vals; uint32_t *Vnext = rf.vnext;
         tiles = ceil_div(m, RR_TILE);
         // dense rounds: a group's rank is its last slot + 1 and a parent's last subgroup keeps it (k_rr_apply, TAIL); the tiles
