@@ -263,9 +263,9 @@ struct PinnedWords {
     ~PinnedWords() { if (p) (void)hipHostFree(p); }
 };
 static thread_local PinnedWords g_pinned;
-static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)     // bytes <= 2048; synchronises the stream
+static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)     // bytes <= 4096; synchronises the stream
 {
-    if (!g_pinned.p && hipHostMalloc((void **)&g_pinned.p, 2048, hipHostMallocDefault) != hipSuccess) {
+    if (!g_pinned.p && hipHostMalloc((void **)&g_pinned.p, 4096, hipHostMallocDefault) != hipSuccess) {
         g_pinned.p = nullptr;
         (void)hipGetLastError();
         HIP_TRY(hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, st));
@@ -644,13 +644,19 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         HIP_TRY(hipMemsetAsync(w.tcnt, 0, (size_t)tiles * 4, st));
         HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
         HIP_TRY(hipMemsetAsync(w.total, 0, 16, st));
+        HIP_TRY(hipMemsetAsync(w.chg, 0, (size_t)RR_CHG_COUNTERS * 32 * 4, st));
         KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
         PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint32_t, KS_LOWKEY, false>), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS),
                                                  0, st, sorted32, SA, dT, P, n, K, cap, surv_bits, surv_head, w.tcnt, w.total, (uint32_t *)nullptr,
                                                  (uint32_t *)nullptr, (uint32_t *)nullptr));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
         uint32_t cnt3[3] = { 0, 0, 0 };                       // still tied on 64 bits, members of groups nobody owned, tied on 32 bits
-        { const int rcw = read_words(cnt3, w.total, 12, st); if (rcw) return rcw; }
+        {
+            uint32_t words[64 + RR_CHG_COUNTERS * 32];         // (the tied-slot counts are spread over w.chg, directly behind w.total)
+            const int rcw = read_words(words, w.total, sizeof(words), st); if (rcw) return rcw;
+            cnt3[0] = words[0]; cnt3[1] = words[1];
+            for (int c = 0; c < RR_CHG_COUNTERS; ++c) cnt3[2] += words[64 + c * 32];
+        }
         if (cnt3[1] == 0) {
             finished32 = true;
             m = cnt3[0];
@@ -684,13 +690,19 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         HIP_TRY(hipMemsetAsync(w.surv_cnt, 0, (size_t)tiles * 4, st));
         HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
         HIP_TRY(hipMemsetAsync(w.total, 0, 32, st));
+        HIP_TRY(hipMemsetAsync(w.chg, 0, (size_t)RR_CHG_COUNTERS * 32 * 4, st));
         KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
         PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint64_t, KS_TEXT, true>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
                                                  (const uint64_t *)sorted0, SA, dT, Ptext, n, K, cap, w.surv_bits, surv_head, w.surv_cnt, w.total,
                                                  w.todo_bits, w.ft_cnt, w.ft_head));
         PROF(KC_RR_SCAN, ft_tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, ft_tiles, w.total + 3));
         uint32_t cnt4[4] = { 0, 0, 0, 0 };                    // [2] tied after the initial sort, [3] members left to the general route
-        { const int rcw = read_words(cnt4, w.total, 16, st); if (rcw) return rcw; }
+        {
+            uint32_t words[64 + RR_CHG_COUNTERS * 32];
+            const int rcw = read_words(words, w.total, sizeof(words), st); if (rcw) return rcw;
+            cnt4[0] = words[0]; cnt4[1] = words[1]; cnt4[3] = words[3];
+            for (int c = 0; c < RR_CHG_COUNTERS; ++c) cnt4[2] += words[64 + c * 32];
+        }
         local.unresolved_after_initial = cnt4[2];
         const int64_t m_todo = cnt4[3];
         local.locally_sorted += (int64_t)cnt4[2] - m_todo;

@@ -564,6 +564,8 @@ __global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__
 // Algorithmic traffic per slot: 4 B key + (tied: 4 B SA read, text gather, 4 B SA write).
 // ------------------------------------------------------------------------------------------
 constexpr int FT_THREADS = 256;
+constexpr int FT_MINW = 5;                                  // waves per SIMD the register allocation leaves room for (96 VGPRs, no spills; 6 spills:
+                                                            // 256 MiB random bytes 7.96 -> 7.73 ms with 5, 7.89 with 6; 1 GiB DNA 32.0 -> 33.4 ms with 6)
 constexpr int FT_TILE = 2048;
 constexpr int FT_XITEMS = FT_TILE / FT_THREADS + 1;         // 8 items + 1 of overhang
 constexpr int FT_SPAN = FT_THREADS * FT_XITEMS;             // 2304
@@ -575,7 +577,7 @@ constexpr int FT_WORDS = FT_SPAN / 64;                      // 36
 // todo_bits (todo_cnt per 2048-slot tile, ft_head = last run start + 1 of every tile for the group-head carry);
 // k_todo_compact turns them into a tied list for the general path, whose survivors join surv_bits.
 template <typename KeyT, int MODE, bool TODO>
-__global__ __launch_bounds__(FT_THREADS) void k_finish_sorted(const KeyT *__restrict__ skeys, uint32_t *SA, const uint8_t *__restrict__ T,
+__global__ __launch_bounds__(FT_THREADS, FT_MINW) void k_finish_sorted(const KeyT *__restrict__ skeys, uint32_t *SA, const uint8_t *__restrict__ T,
                                                                KeyParams P, int64_t n, KeySrc K, int cap, uint32_t *__restrict__ surv_bits,
                                                                uint32_t *__restrict__ surv_head, uint32_t *__restrict__ tile_cnt,
                                                                uint32_t *__restrict__ counters, uint32_t *__restrict__ todo_bits,
@@ -801,7 +803,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_finish_sorted(const KeyT *__rest
     __syncthreads();
     if (t == 0) {
         if (s_cnt[0]) atomicAdd(&counters[1], s_cnt[0]);
-        if (s_cnt[1]) atomicAdd(&counters[2], s_cnt[1]);
+        // (statistics, bumped by nearly every workgroup: spread over the words behind the 64 control words -- one word took
+        // 8 ns per workgroup, 1.05 of the kernel's 1.7 ms at 256 MiB; the host adds them to counters[2])
+        if (s_cnt[1]) atomicAdd(&counters[64 + (blockIdx.x % RR_CHG_COUNTERS) * 32], s_cnt[1]);
     }
     if (t < FT_SPAN / 32) {
         // one atomic per non-empty 32-slot word (base is a multiple of 2048, so words are aligned in the global bitmaps)

@@ -82,7 +82,8 @@ __device__ __forceinline__ WaveGroups rr_wave_classify(const KeyT *__restrict__ 
 // "head code" of the dense doubling rounds: (list index of a group start << 1) | (it also starts a parent group);
 // RR_NO_HEAD: there is none (list indices are below 2^31, so the code of index m with the parent bit set is the same word)
 constexpr uint32_t RR_NO_HEAD = 0xffffffffu;
-constexpr int RR_CHG_COUNTERS = 8;              // changed-rank counters of a dense round, 32 words apart (1 KiB: one read-back)
+constexpr int RR_CHG_COUNTERS = 16;             // counters every workgroup of a large launch bumps (changed ranks of a dense round, tied slots of
+                                                // k_finish_sorted) are spread over this many words, 32 words apart: a single word serialises in one L2 channel
 __device__ __forceinline__ uint32_t rr_first_head_code(const WaveGroups &g, int64_t wbase, int r_from)
 {
     uint32_t code = RR_NO_HEAD;

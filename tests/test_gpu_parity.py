@@ -196,6 +196,31 @@ def test_degenerate_large_runs(oracle, monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_dense_rounds_keep_the_ranks_of_the_last_subgroup(oracle, monkeypatch):
+    """dense doubling rounds label a group by its last slot and do not rewrite the ranks of a parent's last subgroup
+    (k_rr_apply, TAIL): groups that shed members at the front (run to the end of the text), at the back (run before a larger
+    symbol), on both sides, groups longer than a re-rank tile and a wave; direct and binned rank stores, local pass on / off"""
+    rng = np.random.default_rng(5)
+    a = np.full(300_000, 7, dtype=np.uint8)
+    texts = [
+        np.concatenate([a, [9]]).astype(np.uint8),                              # a^k b: the longest run is the smallest suffix
+        np.concatenate([a, [3]]).astype(np.uint8),                              # a^k followed by a smaller symbol
+        np.concatenate([a[:100_000], [9], a[:150_000], [3], a[:70_000]]).astype(np.uint8),
+        np.concatenate([np.tile(np.array([5, 6, 7], dtype=np.uint8), 90_000), [8], np.tile(np.array([5, 6, 7], dtype=np.uint8), 60_000), [1]]).astype(np.uint8),
+        np.concatenate([rng.integers(0, 3, 5000, dtype=np.uint8)] * 40 + [rng.integers(0, 3, 777, dtype=np.uint8)]),   # one block 40 times
+    ]
+    exp = [oracle.sais(s) for s in texts]
+    for env in ({"SA_AMD_FORCE_DENSE": "1"}, {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_BINNED_ISA_ALWAYS": "1"},
+                {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_BINNED_ISA_ALWAYS": "1", "SA_AMD_NO_LOCAL_SORT": "1", "SA_AMD_DENSE_REKEY_MIN": "1"},
+                {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_DENSE_REKEY_MIN": "1", "SA_AMD_GROUP_CAP": "16"}, {}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for s, e in zip(texts, exp):
+            assert np.array_equal(build(s), e), env
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def _planted(n, seed, copies):
     rng = np.random.default_rng(seed)
     s = corpus.uniform(n, seed).copy()
