@@ -577,7 +577,7 @@ constexpr int FT_WORDS = FT_SPAN / 64;                      // 36
 // todo_bits (todo_cnt per 2048-slot tile, ft_head = last run start + 1 of every tile for the group-head carry);
 // k_todo_compact turns them into a tied list for the general path, whose survivors join surv_bits.
 template <typename KeyT, int MODE, bool TODO>
-__global__ __launch_bounds__(FT_THREADS, FT_MINW) void k_finish_sorted(const KeyT *__restrict__ skeys, uint32_t *SA, const uint8_t *__restrict__ T,
+__global__ __launch_bounds__(FT_THREADS, sizeof(KeyT) == 4 ? FT_MINW : 1) void k_finish_sorted(const KeyT *__restrict__ skeys, uint32_t *SA, const uint8_t *__restrict__ T,
                                                                KeyParams P, int64_t n, KeySrc K, int cap, uint32_t *__restrict__ surv_bits,
                                                                uint32_t *__restrict__ surv_head, uint32_t *__restrict__ tile_cnt,
                                                                uint32_t *__restrict__ counters, uint32_t *__restrict__ todo_bits,
