@@ -105,7 +105,8 @@ static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)
 static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, uint32_t *vals_alt, int64_t count,
                       int begin_bit, int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals,
                       hipStream_t st, SortResult *res, const Tuning &tn, bool iota = false,   // iota: value i = index i, vals_in is scratch only
-                      bool may_skip = false)                                                   // look for passes that are the identity (costs a read-back per pass)
+                      bool may_skip = false,                                                   // look for passes that are the identity (costs a read-back per pass)
+                      bool first_counted = false)                                              // the producer of keys_in has histogrammed the first digit into the (zeroed) spine
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0; res->skipped = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
@@ -125,9 +126,13 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
             while (split > 1 && chunk / split < 4096) split /= 2;
             const int64_t sub = (ceil_div(chunk, split) + 1) & ~(int64_t)1;
             // (atomic accumulation needs a zeroed spine: once here, afterwards every downsweep zeroes what it consumed)
+            if (first_counted && shift == begin_bit) {
+                // (nothing to do: k_build_keys has added this pass's digit counts to the spine)
+            } else {
             if (split > 1 && res->passes == 0) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * g.G * 4, st));
             PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.G * split), dim3(SORT_THREADS), 0, st, kin, spine,
                                                            count, shift, dmask, chunk, g.G, split, sub));
+            }
         }
         PROF(KC_SPINE, (int64_t)RADIX * g.G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st,
                                                                     spine, digit_tot, g.G));
@@ -176,18 +181,28 @@ static const Sort32Variant sort32_variants[] = {
 };
 constexpr int N_SORT32_VARIANTS = (int)(sizeof(sort32_variants) / sizeof(sort32_variants[0]));
 
+struct SortGrid32 { int G; int64_t tiles_per_wg, tile; };
+static SortGrid32 sort_grid32(int64_t count, const Sort32Variant &sv)
+{
+    SortGrid32 g;
+    g.tile = (int64_t)SORT32_THREADS * sv.items;
+    const int64_t tiles = ceil_div(count, g.tile);
+    g.tiles_per_wg = ceil_div(tiles, 512);
+    if (g.tiles_per_wg < 1) g.tiles_per_wg = 1;
+    g.G = (int)ceil_div(tiles, g.tiles_per_wg);
+    return g;
+}
+
 static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit,
                         int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals, hipStream_t st, SortResult32 *res,
-                        const Tuning &tn, bool iota = false)
+                        const Tuning &tn, bool iota = false, bool first_counted = false)
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
     const Sort32Variant &sv = sort32_variants[tn.sort32_variant];
-    const int64_t SORT32_TILE = (int64_t)SORT32_THREADS * sv.items;
-    const int64_t tiles = ceil_div(count, SORT32_TILE);
-    int64_t tiles_per_wg = ceil_div(tiles, 512);
-    if (tiles_per_wg < 1) tiles_per_wg = 1;
-    const int G = (int)ceil_div(tiles, tiles_per_wg);
+    const SortGrid32 g32 = sort_grid32(count, sv);
+    const int64_t SORT32_TILE = g32.tile, tiles_per_wg = g32.tiles_per_wg;
+    const int G = g32.G;
     uint32_t *kin = keys_in, *kout = keys_alt, *vin = vals_in, *vout = vals_alt;
     for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
         const int nb = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
@@ -200,9 +215,13 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
             if (split < 1) split = 1;
             while (split > 1 && chunk / split < 8192) split /= 2;
             const int64_t sub = (ceil_div(chunk, split) + 3) & ~(int64_t)3;
+            if (first_counted && shift == begin_bit) {
+                // (k_build_keys has added this pass's digit counts to the spine)
+            } else {
             if (split > 1 && res->passes == 0) HIP_TRY(hipMemsetAsync(spine, 0, (size_t)RADIX * G * 4, st));
             PROF(KC_UPSWEEP32, count, st, hipLaunchKernelGGL((k_radix_upsweep32), dim3(G * split), dim3(SORT_THREADS), 0, st,
                                                            (const uint32_t *)kin, spine, count, shift, dmask, chunk, G, split, sub));
+            }
         }
         PROF(KC_SPINE, (int64_t)RADIX * G, st, hipLaunchKernelGGL((k_spine_rows), dim3(RADIX), dim3(SPINE_THREADS), 0, st, spine, digit_tot, G));
         PROF(KC_DOWNSWEEP32, count, st, hipLaunchKernelGGL((sv.fn),
@@ -585,19 +604,29 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     }
     if (top_shift) {
         uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
-        PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P,
-                                                      (uint64_t *)nullptr, vals0, k32a, top_shift, packed_out));
+        // the first radix pass's digit histogram comes out of k_build_keys (keys in registers there): one read of every key less
+        const SortGrid32 g32 = sort_grid32(n, sort32_variants[tn.sort32_variant]);
+        const bool counted = n > 1;
+        if (counted) HIP_TRY(hipMemsetAsync(w.spine, 0, (size_t)RADIX * g32.G * 4, st));
+        PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                      (uint64_t *)nullptr, vals0, k32a, top_shift, packed_out,
+                                                      counted ? w.spine : (uint32_t *)nullptr, g32.tiles_per_wg * g32.tile, g32.G, 0xffu));
         SortResult32 s32;
-        rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.spine, w.digit_tot, SA, st, &s32, tn, iota);
+        rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.spine, w.digit_tot, SA, st, &s32, tn, iota, counted);
         if (rc) return rc;
         local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
         sorted32 = s32.keys;
         sr.vals = s32.vals; sr.passes = s32.passes;
         sr.keys = (s32.keys == k32a) ? w.keysA : w.keysB;      // the 8n-byte buffer that now holds the sorted 32-bit keys
     } else {
-        PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(n, KB_TILE)), dim3(KB_THREADS), 0, st, dT, n, P,
-                                                      w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out));
-        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr, tn, iota);
+        const SortGrid g64 = sort_grid(n, sort_variants[tn.sort_variant]);
+        const bool counted = n > 1 && key_bits > 0;
+        const int nb0 = key_bits < RADIX_BITS ? key_bits : RADIX_BITS;
+        if (counted) HIP_TRY(hipMemsetAsync(w.spine, 0, (size_t)RADIX * g64.G * 4, st));
+        PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                      w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
+                                                      counted ? w.spine : (uint32_t *)nullptr, g64.tiles_per_wg * g64.tile, g64.G, (1u << nb0) - 1u));
+        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr, tn, iota, false, counted);
         if (rc) return rc;
         local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
     }

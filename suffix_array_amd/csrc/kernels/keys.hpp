@@ -70,18 +70,29 @@ struct KeyParams {
 };
 
 // TOP32: only the top 32 bits of every key are stored (keys32), for the two-stage initial sort
+// A workgroup takes KB_TPW consecutive tiles.  counts != nullptr: it also histograms the lowest digit (key & dmask) of the
+// keys it writes -- the digit of the first radix pass -- and adds it to that pass's spine (counts[d * G + chunk], zeroed by
+// the host; chunk_elems is a multiple of KB_TILE), so the first k_radix_upsweep[32] launch and its read of every key go away.
+constexpr int KB_TPW = 8;
 template <bool TOP32>
 __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__restrict__ T, int64_t n,
                                                             KeyParams P, uint64_t *__restrict__ keys,
                                                             uint32_t *__restrict__ vals, uint32_t *__restrict__ keys32,
-                                                            int top_shift, uint8_t *__restrict__ packed_out)
+                                                            int top_shift, uint8_t *__restrict__ packed_out,
+                                                            uint32_t *__restrict__ counts, int64_t chunk_elems, int G, uint32_t dmask)
 {
     __shared__ uint8_t lcode[256];
     __shared__ __attribute__((aligned(16))) uint8_t c[KB_TILE + KB_HALO];
+    __shared__ uint32_t dhist[256];
     const int tid = threadIdx.x;
     lcode[tid] = P.code[tid];
+    dhist[tid] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * KB_TILE;
+    const int64_t tiles = (n + KB_TILE - 1) / KB_TILE;
+    const int64_t tile0 = (int64_t)blockIdx.x * KB_TPW;
+    const int64_t tile1 = tile0 + KB_TPW < tiles ? tile0 + KB_TPW : tiles;
+  for (int64_t tile = tile0; tile < tile1; ++tile) {
+    const int64_t base = tile * KB_TILE;
     // stage KB_TILE + KB_HALO codes, 8 bytes per thread per step
     for (int o = tid * 8; o < KB_TILE + KB_HALO; o += KB_THREADS * 8) {
         const int64_t p = base + o;
@@ -160,6 +171,30 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
                 if (vals) vals[g0 + r] = (uint32_t)(g0 + r);
             }
     }
+    if (counts) {
+#pragma unroll
+        for (int r = 0; r < KB_ITEMS; ++r) {
+            const bool in = g0 + r < n;
+            const uint32_t d = (uint32_t)(TOP32 ? (kk[r] >> top_shift) : kk[r]) & dmask;
+            const uint64_t act = __ballot(in);
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+            if (__all(!in || d == f)) {                       // one digit for the whole wave (runs, tiny alphabets): one add, not 64 on one address
+                if (act && lane_id() == __ffsll((unsigned long long)act) - 1) atomicAdd(&dhist[d], (uint32_t)__popcll(act));
+            } else if (in) atomicAdd(&dhist[d], 1u);
+        }
+    }
+    __syncthreads();                                          // the staged codes are free; this tile's digits are counted
+    if (counts) {
+        const int64_t chunk = base / chunk_elems;
+        const bool flush = tile + 1 == tile1 || (base + KB_TILE) / chunk_elems != chunk;     // (uniform)
+        if (flush) {
+            const uint32_t cnt = dhist[tid];
+            if (cnt) atomicAdd(&counts[(int64_t)tid * G + chunk], cnt);
+            dhist[tid] = 0;
+            __syncthreads();
+        }
+    }
+  }
 }
 
 constexpr int GK_THREADS = 256;
