@@ -21,7 +21,7 @@ python tools/pmc_traffic.py $O/pmc $O/traffic.json c3_english_256m 268435456
 find $O/pmc -name "*.csv" -delete
 find $O/prof_stats -name "*kernel_trace.csv" -delete
 # ---- timelines, adversarial families, host path, A/B runs ----
-for w in c3_english_256m c3_iid_256m adv:one:268435456 adv:twice:268435456; do
+for w in c3_english_256m c3_iid_256m adv:one:268435456 adv:twice:268435456 adv:p1000:268435456 adv:fib:268435456; do
   f=$(echo $w | tr ':' '_')
   SA_AMD_VERBOSE=3 timeout -k 10 200 python tools/round_trace.py $w > $O/round_trace_$f.txt 2>&1
 done
