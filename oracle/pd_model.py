@@ -6,7 +6,8 @@ prefix-doubling refinement of the unresolved groups with the end-of-text rule --
 algorithm (not the HIP code) can be checked on the CPU against oracle_naive_sa / oracle_sais.
 Device-side staging that does not change the result is not modelled: the 32-bit first stage of the
 initial sort and its one-pass finish, the in-LDS group sort versus the global sort, the bit-field
-packing of the text-round keys, the sparse rank look-up versus a full ISA.
+packing of the text-round keys, the sparse rank look-up versus a full ISA, the choice of a group's rank
+(first slot here; the device's dense rounds use the last slot: any slot of the group orders the same).
 
 The output contract is the reference's: sa[0] = n, sa[1..] sorted suffix offsets
 (reference src/saca.rs:9-15), order as in reference src/sa.rs:72-84.

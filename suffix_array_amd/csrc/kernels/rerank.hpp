@@ -7,10 +7,12 @@ namespace sa {
 
 // ------------------------------------------------------------------------------------------
 // Re-rank: m sorted (key, suffix) pairs sitting in slots U[0..m) of SA (FIRST: U[j] = j).
-// A group = maximal run of equal keys; its rank is (slot of its first element) + 1.
+// A group = maximal run of equal keys; its rank is (slot of its first element) + 1 -- in the dense
+// doubling rounds (slot of its LAST element) + 1, see TAIL in k_rr_apply.
 //   k_rr_count : per tile, how many elements stay tied with a neighbour, and the last group
-//                head slot (+1) inside the tile
+//                head slot (+1) inside the tile; dense rounds: also the tile's first group start
 //   k_rr_scan  : exclusive sum / exclusive max over the tiles (one workgroup)
+//   k_rr_scan_next : dense rounds: for every tile the first group start behind it (one workgroup)
 //   k_rr_apply : SA[U[j]] = V[j]; ISA[V[j]] = rank; compact (slot, group head, suffix) of the
 //                elements that are still tied
 // Algorithmic traffic per element: 12 B read twice (keys + vals [+ 4 B slot]), 4 B SA write,
