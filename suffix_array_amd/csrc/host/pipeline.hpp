@@ -8,6 +8,7 @@
 namespace sa {
 
 constexpr int SORT_MAX_WG = 1024;   // spine rows are scanned by one 1024-thread block
+constexpr size_t GRAM_MAX_ENTRIES = (size_t)1 << 24;   // gram keys: the rank table has sigma^g <= min(n, 2^24) entries
 static_assert(GROUP_CAP_MAX == GS_CAP, "Tuning clamps SA_AMD_GROUP_CAP to the kernel's cap");
 
 // Tile-scatter kernel shapes (threads, items per thread, workgroups per CU).  SA_AMD_SORT_VARIANT selects one at run
@@ -54,6 +55,8 @@ struct Workspace {
     uint32_t *valsA, *valsB, *isa, *U0, *U1, *G0, *G1;
     uint32_t *spine, *digit_tot, *tcnt, *thead, *tnext, *hist, *total, *chg, *has_isa;
     uint8_t *packed;           // bit-packed text (alphabets of 2, 4 or 16 symbols): n / 2 + 64 bytes
+    uint8_t *gram_flags;       // gram keys: which g-grams occur (sigma^g <= min(n, 2^24) flags) and
+    uint4 *gram_table;         //   the rank directory over them (16 bytes per 64 indices)
     uint32_t *surv_bits, *surv_cnt, *todo_bits, *ft_cnt, *ft_head;   // first refinement round straight from the sorted keys (k_finish_sorted)
     size_t bytes;
 };
@@ -85,6 +88,9 @@ static Workspace carve(void *base, int64_t n)
     w.chg = (uint32_t *)take((size_t)RR_CHG_COUNTERS * 32 * 4);      // (directly behind w.total: read back together)
     w.has_isa = (uint32_t *)take((N + 31) / 32 * 4);
     w.packed = (uint8_t *)take(N / 2 + 64);
+    const size_t gram_entries = N < GRAM_MAX_ENTRIES ? N : GRAM_MAX_ENTRIES;
+    w.gram_flags = (uint8_t *)take(gram_entries + 64);
+    w.gram_table = (uint4 *)take((gram_entries / 64 + 1) * 16);
     w.surv_bits = (uint32_t *)take((N + 31) / 32 * 4);
     w.surv_cnt = (uint32_t *)take(rr_tiles * 4);          // (not tcnt: refine_list uses that one for its own compaction)
     w.todo_bits = (uint32_t *)take((N + 31) / 32 * 4);
@@ -249,6 +255,7 @@ static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out, i
     }
     *sigma_out = sigma;
     P->packed = nullptr;
+    P->gram = 0; P->gram_m = 0; P->gram_top = 0; P->gram_D = 0; P->gram_table = nullptr;
     const uint64_t se = sigma > 2 ? (uint64_t)sigma : 2u;      // effective radix (a unary text still needs one bit)
     P->sigma = se;
     // kb_max < 64 (A/B): fewer key bits = fewer radix passes, more left to the rounds
@@ -531,7 +538,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     { const int rcw = read_words(hist, w.hist, sizeof(hist), st); if (rcw) return rcw; }
     KeyParams P;
     int sigma;
-    const int key_bits = make_key_params(hist, &P, &sigma, tn.key_bits_max);
+    int key_bits = make_key_params(hist, &P, &sigma, tn.key_bits_max);      // (gram keys, step 2c, may shorten it)
     local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
 
     const int g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
@@ -586,6 +593,51 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                            dups, (long long)S, frac, probe_dense ? "rank doubling from the start" : "text-keyed rounds");
     }
 
+    // 2c. gram keys (texts that did not take the 32-bit route): how many of the sigma^g possible g-grams occur?  A
+    //     word-structured text uses a small part of them, so a key of dense gram ranks holds more symbols than the
+    //     base-sigma form, often in fewer digits (C3, sigma = 57: 12 symbols in 7 passes instead of 10 in 8).  Measured
+    //     (flags, count, scan), then decided; the probes above keep using the plain key.
+    if (!top_shift && !tn.no_gram_keys && n >= tn.gram_min_n && n >= 2 && sigma >= 2 && tn.key_bits_max == 64) {
+        const uint64_t se = P.sigma;
+        const uint64_t cap = (uint64_t)((size_t)n < GRAM_MAX_ENTRIES ? (size_t)n : GRAM_MAX_ENTRIES);
+        int g = 0;
+        uint64_t S = 1;
+        for (int t = 1; t <= 8; ++t) {
+            if (S * se > cap) break;
+            S *= se; g = t;
+            if (tn.gram_g >= 2 && g == tn.gram_g) break;
+        }
+        if (g >= 2) {
+            uint64_t top = 1;
+            for (int t = 0; t + 1 < g; ++t) top *= se;
+            const int64_t gtiles = ceil_div((int64_t)S, GT_TILE);
+            HIP_TRY(hipMemsetAsync(w.gram_flags, 0, (size_t)S, st));
+            PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_gram_mark), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P, g,
+                                                    (uint32_t)top, w.gram_flags));
+            PROF(KC_MISC, (int64_t)S, st, hipLaunchKernelGGL((k_gram_count), dim3((unsigned)gtiles), dim3(GT_THREADS), 0, st,
+                                                    (const uint8_t *)w.gram_flags, (int64_t)S, w.tcnt));
+            PROF(KC_RR_SCAN, gtiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, gtiles, w.total));
+            uint32_t D = 0;
+            { const int rcw = read_words(&D, w.total, 4, st); if (rcw) return rcw; }
+            int m = 0;
+            unsigned __int128 pw = 1;
+            while (D >= 2 && (m + 1) * g <= 64 && pw * D <= ((unsigned __int128)1 << 64)) { pw *= D; ++m; }
+            const int gram_bits = m > 0 ? bit_length((uint64_t)(pw - 1)) : 0;
+            const int plain_passes = (int)ceil_div(key_bits, RADIX_BITS), gram_passes = (int)ceil_div(gram_bits, RADIX_BITS);
+            const bool better = m > 0 && (m * g > P.k || (m * g == P.k && gram_passes < plain_passes));
+            if (trace) fprintf(stderr, "suffix_array_amd: gram keys: %u of %llu %d-grams occur -> %d symbols in %d bits (plain: %d in %d) -> %s\n",
+                               D, (unsigned long long)S, g, m * g, gram_bits, P.k, key_bits, better ? "gram keys" : "plain keys");
+            if (better) {
+                PROF(KC_MISC, (int64_t)S, st, hipLaunchKernelGGL((k_gram_table), dim3((unsigned)gtiles), dim3(GT_THREADS), 0, st,
+                                                        (const uint8_t *)w.gram_flags, (int64_t)S, (const uint32_t *)w.tcnt, w.gram_table));
+                P.gram = g; P.gram_m = m; P.gram_top = (uint32_t)top; P.gram_D = D; P.gram_table = w.gram_table;
+                P.bits = 0; P.k = m * g; P.mask = ~0ull;
+                key_bits = gram_bits;
+                local.bits_per_symbol = 0; local.symbols_per_key = P.k;
+            }
+        }
+    }
+
     // 3. packed keys, 4. initial sort: all key bits as (u64 key, u32 suffix) pairs, or only the top 32 bits as
     //    (u32, u32) pairs in 12 Ki-element tiles -- two thirds of the bytes per pass and half the passes
     SortResult sr;
@@ -623,9 +675,14 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         const bool counted = n > 1 && key_bits > 0;
         const int nb0 = key_bits < RADIX_BITS ? key_bits : RADIX_BITS;
         if (counted) HIP_TRY(hipMemsetAsync(w.spine, 0, (size_t)RADIX * g64.G * 4, st));
-        PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
-                                                      w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
-                                                      counted ? w.spine : (uint32_t *)nullptr, g64.tiles_per_wg * g64.tile, g64.G, (1u << nb0) - 1u));
+        if (P.gram > 0)
+            PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false, true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                          w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
+                                                          counted ? w.spine : (uint32_t *)nullptr, g64.tiles_per_wg * g64.tile, g64.G, (1u << nb0) - 1u));
+        else
+            PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                          w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
+                                                          counted ? w.spine : (uint32_t *)nullptr, g64.tiles_per_wg * g64.tile, g64.G, (1u << nb0) - 1u));
         rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr, tn, iota, false, counted);
         if (rc) return rc;
         local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
@@ -651,6 +708,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     // symbols in 36 bits either way.
     KeyParams Ptext = P;
     if (P.bits == 0) Ptext.bits = bit_length(P.sigma - 1);
+    Ptext.gram = 0;                                    // (gram ranks are the initial keys' business only)
     int s_sym = 0, tkb = 0;                            // symbols per round, bits of their packed key
     {
         const int room = 64 - g_bits;                   // bits left below the group head

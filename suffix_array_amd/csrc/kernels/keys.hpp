@@ -67,14 +67,38 @@ struct KeyParams {
     const uint8_t *packed;   // bits in {1, 2, 4}: the text as bit-packed codes, first symbol in the top bits of byte 0
                              // (written by k_build_keys; 4x smaller than DNA bytes, so the rounds' random reads stay in
                              // the 256 MB Infinity Cache), zero-padded by >= 24 bytes; nullptr: read the text itself
+    // Gram keys (gram > 0; then bits == 0 and k = gram * gram_m): the key is a base-D number whose digits are the dense
+    // ranks of the text's g-grams among the g-grams that OCCUR in the text (gram_table[index of the gram as a base-sigma
+    // number]; D = how many occur).  Order-preserving like the base-sigma form, but a word-structured text uses a small
+    // part of sigma^g: English-like sigma = 57 has 2.5e5 of 1.06e7 four-grams, so three of them (12 symbols) fit in 54
+    // bits -- two symbols more than 57^10 < 2^64 allows, in one radix pass less.
+    int32_t gram, gram_m;
+    uint32_t gram_top;       // sigma^(gram - 1)
+    uint64_t gram_D;
+    const uint4 *gram_table; // one 16-byte record per 64 gram indices: {bitmap of the grams that occur (2 words), how many occur below, 0}
 };
+
+// dense rank of gram `idx` among the grams that occur: a rank directory (2.6 MB for 57^4 indices: cache-resident, where a table
+// of one word per index would spread the 2.8e5 grams in use over 36 MB of cache lines)
+__device__ __forceinline__ uint32_t gram_rank(const uint4 *__restrict__ table, uint32_t idx)
+{
+    const uint4 rec = table[idx >> 6];
+    const uint64_t bits = ((uint64_t)rec.y << 32) | rec.x;
+    return rec.z + (uint32_t)__popcll(bits & ((1ull << (idx & 63u)) - 1ull));
+}
+
+// the staged text tile of k_build_keys / k_gram_mark: KB_TILE + KB_HALO symbol codes from text position `base` on, zero past the end
+__device__ __forceinline__ void kb_stage_codes(const uint8_t *__restrict__ T, int64_t n, int64_t base, const uint8_t *lcode, uint8_t *c, int tid);
 
 // TOP32: only the top 32 bits of every key are stored (keys32), for the two-stage initial sort
 // A workgroup takes KB_TPW consecutive tiles.  counts != nullptr: it also histograms the lowest digit (key & dmask) of the
 // keys it writes -- the digit of the first radix pass -- and adds it to that pass's spine (counts[d * G + chunk], zeroed by
 // the host; chunk_elems is a multiple of KB_TILE), so the first k_radix_upsweep[32] launch and its read of every key go away.
 constexpr int KB_TPW = 8;
-template <bool TOP32>
+constexpr int GRAM_CACHE = 4096;            // direct-mapped per-workgroup cache of gram indices already handled (mark) / of their ranks (keys)
+__device__ __forceinline__ uint32_t gram_slot(uint32_t idx) { return (idx * 2654435761u) >> 20; }     // 12 bits
+
+template <bool TOP32, bool GRAM = false>
 __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__restrict__ T, int64_t n,
                                                             KeyParams P, uint64_t *__restrict__ keys,
                                                             uint32_t *__restrict__ vals, uint32_t *__restrict__ keys32,
@@ -84,38 +108,40 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
     __shared__ uint8_t lcode[256];
     __shared__ __attribute__((aligned(16))) uint8_t c[KB_TILE + KB_HALO];
     __shared__ uint32_t dhist[256];
+    __shared__ uint32_t gc[GRAM ? KB_TILE + KB_HALO : 1];
     const int tid = threadIdx.x;
     lcode[tid] = P.code[tid];
     dhist[tid] = 0;
+
     __syncthreads();
     const int64_t tiles = (n + KB_TILE - 1) / KB_TILE;
     const int64_t tile0 = (int64_t)blockIdx.x * KB_TPW;
     const int64_t tile1 = tile0 + KB_TPW < tiles ? tile0 + KB_TPW : tiles;
   for (int64_t tile = tile0; tile < tile1; ++tile) {
     const int64_t base = tile * KB_TILE;
-    // stage KB_TILE + KB_HALO codes, 8 bytes per thread per step
-    for (int o = tid * 8; o < KB_TILE + KB_HALO; o += KB_THREADS * 8) {
-        const int64_t p = base + o;
-        uint8_t b[8];
-        if (p + 8 <= n && (((uintptr_t)(T + p)) & 7) == 0) {
-            uint2 q = *(const uint2 *)(T + p);
-            uint32_t w2[2] = { q.x, q.y };
-#pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = lcode[(w2[j >> 2] >> (8 * (j & 3))) & 255u];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = (p + j < n) ? lcode[T[p + j]] : (uint8_t)0;
-        }
-        uint2 o2;
-        o2.x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
-        o2.y = (uint32_t)b[4] | ((uint32_t)b[5] << 8) | ((uint32_t)b[6] << 16) | ((uint32_t)b[7] << 24);
-        *(uint2 *)(c + o) = o2;
-    }
+    kb_stage_codes(T, n, base, lcode, c, tid);
     __syncthreads();
     const int p0 = tid * KB_ITEMS;
     const int k = P.k, bits = P.bits;
     uint64_t kk[KB_ITEMS];
-    if (bits > 0) {
+    if (GRAM) {
+        // dense rank of the gram at every staged position (one table look-up each), then key(i) = sum rank(i + g j) D^(m-1-j)
+        const int g = P.gram, m = P.gram_m;
+        const uint32_t sg = (uint32_t)P.sigma;
+        for (int o = tid; o + g <= KB_TILE + KB_HALO; o += KB_THREADS) {
+            uint32_t idx = 0;
+            for (int t = 0; t < g; ++t) idx = idx * sg + (uint32_t)c[o + t];
+            gc[o] = gram_rank(P.gram_table, idx);
+        }
+        __syncthreads();
+        const uint64_t D = P.gram_D;
+#pragma unroll
+        for (int r = 0; r < KB_ITEMS; ++r) {
+            uint64_t key = 0;
+            for (int j = 0; j < m; ++j) key = key * D + (uint64_t)gc[p0 + r + g * j];
+            kk[r] = key;
+        }
+    } else if (bits > 0) {
         const uint64_t mask = P.mask;
         uint64_t key = 0;
         for (int j = 0; j < k; ++j) key = (key << bits) | (uint64_t)c[p0 + j];
@@ -197,6 +223,118 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
   }
 }
 
+__device__ __forceinline__ void kb_stage_codes(const uint8_t *__restrict__ T, int64_t n, int64_t base, const uint8_t *lcode, uint8_t *c, int tid)
+{
+    // 8 bytes per thread per step
+    for (int o = tid * 8; o < KB_TILE + KB_HALO; o += KB_THREADS * 8) {
+        const int64_t p = base + o;
+        uint8_t b[8];
+        if (p + 8 <= n && (((uintptr_t)(T + p)) & 7) == 0) {
+            uint2 q = *(const uint2 *)(T + p);
+            uint32_t w2[2] = { q.x, q.y };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = lcode[(w2[j >> 2] >> (8 * (j & 3))) & 255u];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = (p + j < n) ? lcode[T[p + j]] : (uint8_t)0;
+        }
+        uint2 o2;
+        o2.x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        o2.y = (uint32_t)b[4] | ((uint32_t)b[5] << 8) | ((uint32_t)b[6] << 16) | ((uint32_t)b[7] << 24);
+        *(uint2 *)(c + o) = o2;
+    }
+}
+
+// ---- gram keys: which g-grams occur, their dense ranks ----------------------------------------
+// k_gram_mark : F[index of the g-gram at p] = 1 for every text position p (zero codes past the end, as the keys pad;
+//               the all-zero gram is marked too: key positions behind the text read it).  A workgroup remembers the grams it
+//               has handled in a small direct-mapped LDS cache, so most positions of a word-structured text cost no access.
+// k_gram_count: flags per 8192-entry tile;  k_rr_scan turns them into exclusive sums and the total D;
+// k_gram_table: table[index] = number of marked grams below it = the gram's dense rank.
+__global__ __launch_bounds__(KB_THREADS) void k_gram_mark(const uint8_t *__restrict__ T, int64_t n, KeyParams P, int g, uint32_t top,
+                                                           uint8_t *__restrict__ F)
+{
+    __shared__ uint8_t lcode[256];
+    __shared__ __attribute__((aligned(16))) uint8_t c[KB_TILE + KB_HALO];
+    __shared__ uint32_t s_tag[GRAM_CACHE];     // a word-structured text repeats a few thousand grams over and over: most positions stop here
+    const int tid = threadIdx.x;
+    lcode[tid] = P.code[tid];
+    for (int i = tid; i < GRAM_CACHE; i += KB_THREADS) s_tag[i] = 0xffffffffu;
+    __syncthreads();
+    const int64_t tiles = (n + KB_TILE - 1) / KB_TILE;
+    const int64_t tile0 = (int64_t)blockIdx.x * KB_TPW;
+    const int64_t tile1 = tile0 + KB_TPW < tiles ? tile0 + KB_TPW : tiles;
+    const uint32_t sg = (uint32_t)P.sigma;
+    for (int64_t tile = tile0; tile < tile1; ++tile) {
+        const int64_t base = tile * KB_TILE;
+        kb_stage_codes(T, n, base, lcode, c, tid);
+        __syncthreads();
+        const int p0 = tid * KB_ITEMS;
+        uint32_t idx = 0;
+        for (int t = 0; t < g; ++t) idx = idx * sg + (uint32_t)c[p0 + t];
+        uint32_t ix[KB_ITEMS];
+        bool miss[KB_ITEMS];
+#pragma unroll
+        for (int r = 0; r < KB_ITEMS; ++r) {
+            ix[r] = idx;
+            const uint32_t sl = gram_slot(idx);
+            miss[r] = base + p0 + r < n && s_tag[sl] != idx;
+            if (miss[r]) s_tag[sl] = idx;
+            idx = (idx - (uint32_t)c[p0 + r] * top) * sg + (uint32_t)c[p0 + r + g];
+        }
+        // the flags of the misses are read together (one memory latency per tile, not one per position) and written only where
+        // still clear: after the first tiles nearly every gram is marked already
+        uint8_t f[KB_ITEMS];
+#pragma unroll
+        for (int r = 0; r < KB_ITEMS; ++r) f[r] = miss[r] ? F[ix[r]] : (uint8_t)1;
+#pragma unroll
+        for (int r = 0; r < KB_ITEMS; ++r) if (miss[r] && f[r] == 0) F[ix[r]] = 1;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && tid == 0) F[0] = 1;
+}
+
+constexpr int GT_THREADS = 1024;
+constexpr int GT_TILE = GT_THREADS * 64;         // 65536 flags per workgroup, 64 consecutive ones (one bitmap word) per thread
+__device__ __forceinline__ uint64_t gram_word(const uint8_t *__restrict__ F, int64_t S, int64_t i0)
+{
+    uint64_t w = 0;
+    if (i0 + 64 <= S) {                           // (F is 64-byte aligned: the flag array starts on a 256-byte boundary)
+        const uint4 *q = (const uint4 *)(F + i0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const uint4 v = q[a];
+            const uint32_t ww[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int b = 0; b < 16; ++b) w |= (uint64_t)((ww[b >> 2] >> (8 * (b & 3))) & 1u) << (16 * a + b);
+        }
+    } else {
+        for (int j = 0; j < 64; ++j) if (i0 + j < S && F[i0 + j]) w |= 1ull << j;
+    }
+    return w;
+}
+
+__global__ __launch_bounds__(GT_THREADS) void k_gram_count(const uint8_t *__restrict__ F, int64_t S, uint32_t *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t lds[GT_THREADS / WAVE];
+    const int64_t i0 = (int64_t)blockIdx.x * GT_TILE + (int64_t)threadIdx.x * 64;
+    const uint32_t c = i0 < S ? (uint32_t)__popcll(gram_word(F, S, i0)) : 0u;
+    uint32_t tot;
+    (void)block_excl_sum<GT_THREADS>(c, lds, &tot);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(GT_THREADS) void k_gram_table(const uint8_t *__restrict__ F, int64_t S, const uint32_t *__restrict__ tile_off,
+                                                            uint4 *__restrict__ table)
+{
+    __shared__ uint32_t lds[GT_THREADS / WAVE];
+    const int64_t i0 = (int64_t)blockIdx.x * GT_TILE + (int64_t)threadIdx.x * 64;
+    const uint64_t w = i0 < S ? gram_word(F, S, i0) : 0ull;
+    uint32_t tot;
+    const uint32_t off = tile_off[blockIdx.x] + block_excl_sum<GT_THREADS>((uint32_t)__popcll(w), lds, &tot);
+    if (i0 < S) table[i0 >> 6] = make_uint4((uint32_t)w, (uint32_t)(w >> 32), off, 0u);
+}
+
 constexpr int GK_THREADS = 256;
 
 // symbol code of text position pos (0 past the end: the same padding the initial keys use)
@@ -211,6 +349,16 @@ __device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ T, cons
                                              int64_t p, int nsym, bool aligned8)
 {
     uint64_t tk = 0;
+    if (P.gram > 0 && nsym == P.k) {
+        // gram keys: the same base-D number k_build_keys builds (rank look-ups; only the rare re-computations take this path)
+        const uint32_t sg = (uint32_t)P.sigma;
+        for (int j = 0; j < P.gram_m; ++j) {
+            uint32_t idx = 0;
+            for (int t = 0; t < P.gram; ++t) idx = idx * sg + (uint32_t)code_at(T, lcode, n, p + (int64_t)P.gram * j + t);
+            tk = tk * P.gram_D + (uint64_t)gram_rank(P.gram_table, idx);
+        }
+        return tk;
+    }
     if (P.packed) {
         // bit-packed codes: the key is a bit field of the packed text (two aligned big-endian 64-bit words)
         const int64_t bo = p * P.bits;

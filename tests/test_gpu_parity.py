@@ -221,6 +221,34 @@ def test_dense_rounds_keep_the_ranks_of_the_last_subgroup(oracle, monkeypatch):
             monkeypatch.delenv(k)
 
 
+@pytest.mark.parametrize("g", ["0", "2", "3", "5"])
+def test_gram_keys(oracle, monkeypatch, g):
+    """initial keys made of dense ranks of the g-grams that occur in the text (step 2c; by default only for texts of at
+    least 16 MiB -- the threshold is lowered here): word-structured texts, small alphabets where the gram form wins or
+    loses, texts shorter than a key, grams that run past the end of the text; then every refinement regime on top of them"""
+    monkeypatch.setenv("SA_AMD_GRAM_MIN_N", "1")
+    monkeypatch.setenv("SA_AMD_GRAM_G", g)
+    texts = [corpus.english(300_001, 3), corpus.english_corpus(1 << 20, 4, 2000, 0.3), corpus.sigma(200_000, 7, 5, 97),
+             corpus.dna_repeats(150_000, 5), np.resize(np.frombuffer(b"abcab", dtype=np.uint8), 50_001).copy(),
+             np.frombuffer(b"to be or not to be that is the question", dtype=np.uint8).copy(), corpus.english(37, 1),
+             _planted(400_000, 11, 3), np.full(5000, 9, dtype=np.uint8)]
+    exp = [oracle.sais(t) for t in texts]
+    for env in ({}, {"SA_AMD_NO_TOP32": "1"}, {"SA_AMD_NO_TOP32": "1", "SA_AMD_FORCE_DENSE": "1"},
+                {"SA_AMD_NO_TOP32": "1", "SA_AMD_NO_REPEAT_PROBE": "1", "SA_AMD_SPARSE_DIV": "4"},
+                {"SA_AMD_NO_TOP32": "1", "SA_AMD_FUSED64": "1"}, {"SA_AMD_NO_TOP32": "1", "SA_AMD_NO_LOCAL_SORT": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for t, e in zip(texts, exp):
+            assert np.array_equal(build(t), e), (env, t.size)
+        for k in env:
+            monkeypatch.delenv(k)
+    st = None
+    monkeypatch.setenv("SA_AMD_NO_TOP32", "1")
+    build(texts[0]); st = sa.last_stats()
+    if g in ("0", "3"):
+        assert st["symbols_per_key"] > 10, st          # english-like sigma ~ 56: 10 or 11 symbols in the plain form
+
+
 def _planted(n, seed, copies):
     rng = np.random.default_rng(seed)
     s = corpus.uniform(n, seed).copy()
@@ -487,6 +515,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_RUN_SKIP", "SA_AMD_RUN_SKIP_MIN", "SA_AMD_TIMING_ONLY_INITIAL_SORT",
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
+             "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
