@@ -992,7 +992,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         // lists count their groups anyway; a Fibonacci word's groups shrink while the list does not, a periodic text's never do)
         if (!local_ok && !tn.no_local_sort && m * 2 < m_local_off) local_ok = true;
         const bool retry_local = !local_ok && ++rounds_local_off >= 3;
-        K.iters = (!sparse && local_ok && chase_ok) ? tn.chase : 1;
+        K.iters = (!sparse && local_ok && chase_ok) ? (m >= tn.chase_big_min ? tn.chase_big : tn.chase) : 1;
         if (K.iters > 1) K.mode = KS_CHASE;
         K.has_isa = w.has_isa; K.sorted_keys = sorted0; K.sorted_top32 = sorted32; K.sa = SA; K.depth = depth_text; K.top_shift = top_shift;
         Refined rf;

@@ -54,6 +54,8 @@ struct Tuning {
     bool no_repeat_probe = false;    // SA_AMD_NO_REPEAT_PROBE: never start rank doubling right after the initial sort
     int64_t binned_min = (int64_t)1 << 26;   // SA_AMD_BINNED_MIN: fewest (suffix, rank) pairs a round bins before scattering
     int chase = 7;                   // SA_AMD_CHASE: rank look-ups per member and dense doubling round (1 = plain doubling), 1..15
+    int chase_big = 3;               // SA_AMD_CHASE_BIG: the same for lists of at least chase_big_min members (look-ups are what a long
+    int64_t chase_big_min = (int64_t)1 << 23;   // SA_AMD_CHASE_BIG_MIN  list pays for; a short one pays for launches and read-backs)
     int scatter_levels = 0;          // SA_AMD_SCATTER_LEVELS: radix passes before a binned ISA write (0 = by size, 1, 2)
     int max_text_rounds = 4;         // SA_AMD_MAX_TEXT_ROUNDS: text-keyed rounds before rank doubling with a full ISA, 0..8
     bool no_gram_keys = false;       // SA_AMD_NO_GRAM_KEYS: never key the initial sort by ranks of g-grams
@@ -90,6 +92,8 @@ struct Tuning {
         t.dense_rekey_min = env_int("SA_AMD_DENSE_REKEY_MIN", (int64_t)1 << 22, 1, (int64_t)1 << 40);
         t.max_text_rounds = (int)env_int("SA_AMD_MAX_TEXT_ROUNDS", 4, 0, 8);
         t.chase = (int)env_int("SA_AMD_CHASE", 7, 1, 15);
+        t.chase_big = (int)env_int("SA_AMD_CHASE_BIG", 3, 1, 15);
+        t.chase_big_min = env_int("SA_AMD_CHASE_BIG_MIN", (int64_t)1 << 23, 1, (int64_t)1 << 40);
         t.scatter_levels = (int)env_int("SA_AMD_SCATTER_LEVELS", 0, 0, 2);
         t.binned_min = env_int("SA_AMD_BINNED_MIN", (int64_t)1 << 26, 1, (int64_t)1 << 40);
         t.no_gram_keys = env_flag("SA_AMD_NO_GRAM_KEYS");
