@@ -1027,8 +1027,15 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                                                         keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
                                                         (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total, 0,
                                                         (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg));
-            rc = scatter_binned((uint32_t *)pk, Gcur, (uint32_t *)keysS, (uint32_t *)valsS, m, n, w, st, &local, tn);
-            if (rc) return rc;
+            // (only the ranks that change became pairs; their number is in the counters)
+            uint32_t chg[RR_CHG_COUNTERS * 32];
+            { const int rcw = read_words(chg, w.chg, sizeof(chg), st); if (rcw) return rcw; }
+            int64_t pairs = 0;
+            for (int c = 0; c < RR_CHG_COUNTERS; ++c) pairs += chg[c * 32];
+            if (pairs > 0) {
+                rc = scatter_binned((uint32_t *)pk, Gcur, (uint32_t *)keysS, (uint32_t *)valsS, pairs, n, w, st, &local, tn);
+                if (rc) return rc;
+            }
         } else {
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                         keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,

@@ -302,6 +302,40 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     }
     const uint64_t le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);              // lanes <= l
     const uint64_t lt_mask = le_mask >> 1;                                          // lanes <  l
+    // head code of the first group start behind element (r, l)
+    auto code_behind = [&](int r) -> uint32_t {
+        const uint64_t hgt = (l == 63) ? 0ull : (g.head[r] & (~0ull << (l + 1)));   // group starts behind this lane in the item
+        if (!hgt) return next_code[r];
+        const int b = __builtin_ctzll(hgt);
+        return ((uint32_t)(wbase + 64 * r + b) << 1) | (uint32_t)((g.phead[r] >> b) & 1ull);
+    };
+    // PAIRS (dense rounds that bin their ISA writes): only the ranks that change become (suffix, rank) pairs, packed: the
+    // workgroup counts them, takes a block of the pair arrays with ONE atomic on changed_cnt[0] (which so also ends up
+    // as the number of pairs) and its waves fill it in order
+    constexpr bool PAIRS = TAIL && ISA_MODE == 2;
+    uint64_t cmask[PAIRS ? RR_ITEMS : 1];
+    uint32_t pair_off = 0;
+    if (PAIRS) {
+        __shared__ uint32_t wpairs[NW];
+        __shared__ uint32_t s_base;
+        uint32_t mine = 0;
+#pragma unroll
+        for (int r = 0; r < RR_ITEMS; ++r) {
+            const int64_t i = wbase + 64 * r + l;
+            cmask[r] = __ballot(i < m && !(parent_tail && (code_behind(r) & 1u)));
+            mine += (uint32_t)__popcll(cmask[r]);
+        }
+        if (l == 0) wpairs[w] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int ww = 0; ww < NW; ++ww) tot += wpairs[ww];
+            s_base = tot ? atomicAdd(&changed_cnt[0], tot) : 0u;
+        }
+        __syncthreads();
+        pair_off = s_base;
+        for (int ww = 0; ww < w; ++ww) pair_off += wpairs[ww];
+    }
 #pragma unroll
     for (int r = 0; r < RR_ITEMS; ++r) {
         const int64_t i = wbase + 64 * r + l;
@@ -314,21 +348,22 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         uint32_t rank = run;                      // the value that goes into the ISA
         bool changed = true;
         if (TAIL) {
-            const uint64_t hgt = (l == 63) ? 0ull : (g.head[r] & (~0ull << (l + 1)));   // group starts behind this lane in the item
-            uint32_t code = next_code[r];
-            if (hgt) {
-                const int b = __builtin_ctzll(hgt);
-                code = ((uint32_t)(wbase + 64 * r + b) << 1) | (uint32_t)((g.phead[r] >> b) & 1ull);
-            }
+            const uint32_t code = code_behind(r);
             // the group's slots are consecutive: its last one = my slot + (members behind me)
             rank = slot[r] + ((code >> 1) - 1u - (uint32_t)i) + 1u;
             changed = !(parent_tail && (code & 1u));
-            n_changed += (uint32_t)__popcll(__ballot(i < m && changed));
+            if (!PAIRS) n_changed += (uint32_t)__popcll(__ballot(i < m && changed));
         }
         if (i < m) {
             if (WRITE_SA && slot[r] < n_text) SA[slot[r]] = v[r];
-            if (ISA_MODE == 2) {
-                ((uint32_t *)pair_k)[i] = v[r];          // (suffix, rank) as 32-bit pairs: binned by one 32-bit radix pass
+            if (PAIRS) {
+                if (changed) {
+                    const uint32_t o = pair_off + (uint32_t)__popcll(cmask[r] & lt_mask);
+                    ((uint32_t *)pair_k)[o] = v[r];      // (suffix, rank) as 32-bit pairs: binned by 32-bit radix passes
+                    pair_v[o] = rank;
+                }
+            } else if (ISA_MODE == 2) {
+                ((uint32_t *)pair_k)[i] = v[r];
                 pair_v[i] = rank;
             } else if (ISA_MODE != 3 && ISA_MODE != 4 && v[r] < n_text) {
                 if (changed) {
@@ -349,8 +384,9 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         }
         run_cnt += (uint32_t)__popcll(g.tied[r]);
         if (g.head[r]) run_head = (uint32_t)__shfl((int)slot[r], 63 - __builtin_clzll(g.head[r]), WAVE) + 1u;
+        if (PAIRS) pair_off += (uint32_t)__popcll(cmask[r]);
     }
-    if (TAIL) {
+    if (TAIL && !PAIRS) {
         // one global atomic per workgroup, spread over RR_CHG_COUNTERS words in different 128-byte lines (a single
         // counter bumped by every wave serialises in one L2 channel: 465 K atomics cost 4 ms at 256 MiB)
         if (l == 0 && n_changed) atomicAdd(&s_chg, n_changed);
