@@ -224,7 +224,7 @@ def test_dense_rounds_keep_the_ranks_of_the_last_subgroup(oracle, monkeypatch):
 @pytest.mark.parametrize("g", ["0", "2", "3", "5"])
 def test_gram_keys(oracle, monkeypatch, g):
     """initial keys made of dense ranks of the g-grams that occur in the text (step 2c; by default only for texts of at
-    least 16 MiB -- the threshold is lowered here): word-structured texts, small alphabets where the gram form wins or
+    least 4 MiB -- the threshold is lowered here): word-structured texts, small alphabets where the gram form wins or
     loses, texts shorter than a key, grams that run past the end of the text; then every refinement regime on top of them"""
     monkeypatch.setenv("SA_AMD_GRAM_MIN_N", "1")
     monkeypatch.setenv("SA_AMD_GRAM_G", g)
