@@ -498,6 +498,59 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_keyed<KS_RANK>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA));
     }
+    // Giant groups (runs, periodic texts, long repeats): all but a few members of a group carry the same key, so the few
+    // are pulled out and sorted on their own and the rest only shifts (three-way split around the group's majority key,
+    // kernels/refine.hpp) -- if the count pass finds that they are few indeed; otherwise the radix sort below.
+    if (rekeyed && !tn.no_split && m >= tn.split_min && groups > 0 && (int64_t)groups * tn.split_group_min <= m) {
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        char *sg = (char *)scratchG;
+        uint32_t *starts = (uint32_t *)sg;            sg += up(((size_t)groups + 1) * 4);
+        uint32_t *mps = (uint32_t *)sg;               sg += up(((size_t)groups + 1) * 4);
+        uint32_t *Lless = (uint32_t *)sg;             sg += up((size_t)groups * 4);
+        uint64_t *pivot = (uint64_t *)sg;             sg += up((size_t)groups * 8);
+        const size_t cap = (size_t)m / 8 + 1;                                   // (minority members when the split is taken)
+        uint32_t *mv = (uint32_t *)sg, *mv_alt = mv + ((cap + 63) & ~(size_t)63);
+        uint64_t *mk = (uint64_t *)scratchU, *mk_alt = mk + ((cap + 31) & ~(size_t)31);
+        const size_t need_g = (size_t)(sg - (char *)scratchG) + 2 * ((cap + 63) & ~(size_t)63) * 4;
+        const size_t need_u = 2 * ((cap + 31) & ~(size_t)31) * 8;
+        if (need_g <= (size_t)n * 4 && need_u <= (size_t)n * 4) {
+            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_group_starts), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, Ucur, Gcur, m,
+                                                        (const uint32_t *)w.ft_cnt, groups, starts));
+            PROF(KC_MISC, groups, st, hipLaunchKernelGGL((k_split_pivots), dim3((unsigned)ceil_div((int64_t)groups, 256)), dim3(256), 0, st,
+                                                     (const uint64_t *)rkA, (const uint32_t *)starts, groups, kb, pivot));
+            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_split_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)rkA, m, kb,
+                                                        (const uint64_t *)pivot, w.tcnt));
+            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+            uint32_t minor = 0;
+            { const int rcw = read_words(&minor, w.total, 4, st); if (rcw) return rcw; }
+            if ((int64_t)minor * 8 <= m) {
+                out->m_global = m;
+                if (minor == 0) {                                  // every member carries its group's pivot key: the order stands
+                    out->keys = rkA; out->vals = Vcur; out->vnext = Valt;
+                    return SA_AMD_OK;
+                }
+                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_split_pass<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            (const uint64_t *)rkA, (const uint32_t *)Vcur, m, kb, (const uint64_t *)pivot,
+                                                            (const uint32_t *)w.tcnt, (const uint32_t *)starts, groups, mps, (const uint32_t *)w.total,
+                                                            mk, mv, (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr));
+                SortResult s2;
+                rc = sort_pairs(mk, mv, mk_alt, mv_alt, minor, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &s2, tn);
+                if (rc) return rc;
+                local->sort_passes += s2.passes; local->sorted_elements += (int64_t)s2.passes * minor;
+                PROF(KC_MISC, groups, st, hipLaunchKernelGGL((k_split_less), dim3((unsigned)ceil_div((int64_t)groups, 256)), dim3(256), 0, st,
+                                                         (const uint64_t *)s2.keys, (const uint32_t *)mps, (const uint64_t *)pivot, groups, kb, Lless));
+                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_split_pass<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            (const uint64_t *)rkA, (const uint32_t *)Vcur, m, kb, (const uint64_t *)pivot,
+                                                            (const uint32_t *)w.tcnt, (const uint32_t *)starts, groups, mps, (const uint32_t *)w.total,
+                                                            (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)Lless, rkB, Valt));
+                PROF(KC_SCATTER, minor, st, hipLaunchKernelGGL((k_split_place_minor), dim3((unsigned)ceil_div((int64_t)minor, 256)), dim3(256), 0, st,
+                                                               (const uint64_t *)s2.keys, (const uint32_t *)s2.vals, (int64_t)minor, kb,
+                                                               (const uint32_t *)starts, (const uint32_t *)mps, (const uint32_t *)Lless, rkB, Valt));
+                out->keys = rkB; out->vals = Valt; out->vnext = Vcur;
+                return SA_AMD_OK;
+            }
+        }
+    }
     rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn, false, true);
     if (rc) return rc;
     local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m;

@@ -58,6 +58,9 @@ struct Tuning {
     int64_t chase_big_min = (int64_t)1 << 23;   // SA_AMD_CHASE_BIG_MIN  list pays for; a short one pays for launches and read-backs)
     int scatter_levels = 0;          // SA_AMD_SCATTER_LEVELS: radix passes before a binned ISA write (0 = by size, 1, 2)
     int max_text_rounds = 4;         // SA_AMD_MAX_TEXT_ROUNDS: text-keyed rounds before rank doubling with a full ISA, 0..8
+    bool no_split = false;           // SA_AMD_NO_SPLIT: never split giant groups around their majority key (always the whole-list radix sort)
+    int64_t split_min = (int64_t)1 << 22;        // SA_AMD_SPLIT_MIN: smallest list that is split
+    int64_t split_group_min = (int64_t)1 << 15;  // SA_AMD_SPLIT_GROUP_MIN: smallest average group of such a list
     bool no_gram_keys = false;       // SA_AMD_NO_GRAM_KEYS: never key the initial sort by ranks of g-grams
     int64_t gram_min_n = (int64_t)1 << 22;   // SA_AMD_GRAM_MIN_N: smallest text whose g-grams are looked at (measured: -4 % at 4 MiB, +5 % at 1 MiB)
     int gram_g = 0;                  // SA_AMD_GRAM_G: gram length (0 = the longest whose table fits, else 2..8, still subject to the fit)
@@ -96,6 +99,9 @@ struct Tuning {
         t.chase_big_min = env_int("SA_AMD_CHASE_BIG_MIN", (int64_t)1 << 23, 1, (int64_t)1 << 40);
         t.scatter_levels = (int)env_int("SA_AMD_SCATTER_LEVELS", 0, 0, 2);
         t.binned_min = env_int("SA_AMD_BINNED_MIN", (int64_t)1 << 26, 1, (int64_t)1 << 40);
+        t.no_split = env_flag("SA_AMD_NO_SPLIT");
+        t.split_min = env_int("SA_AMD_SPLIT_MIN", (int64_t)1 << 22, 1, (int64_t)1 << 40);
+        t.split_group_min = env_int("SA_AMD_SPLIT_GROUP_MIN", (int64_t)1 << 15, 1, (int64_t)1 << 40);
         t.no_gram_keys = env_flag("SA_AMD_NO_GRAM_KEYS");
         t.gram_min_n = env_int("SA_AMD_GRAM_MIN_N", (int64_t)1 << 22, 1, (int64_t)1 << 40);
         t.gram_g = (int)env_int("SA_AMD_GRAM_G", 0, 0, 8);

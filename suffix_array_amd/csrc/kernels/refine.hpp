@@ -1071,6 +1071,158 @@ __global__ __launch_bounds__(RR_THREADS) void k_gather_keyed(const uint32_t *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Three-way split of giant groups around their majority key.  A run, a periodic text or a long repeat keeps hundreds of
+// millions of suffixes in a handful of groups round after round, and in every round all but a few members of a group carry
+// the SAME secondary key (the rank of the one group their look-ups land in): a radix sort of the whole list moves 268 M pairs
+// five times to pull out the few thousand that differ.  Instead: pivot(g) = key of the group's middle member; the members
+// whose key differs (the minority) are extracted and sorted on their own; the others keep their relative order and only
+// shift by the number of minority members that sort below the pivot:
+//      [ minority < pivot, sorted | members with the pivot key, in list order | minority > pivot, sorted ]
+// The keys carry the dense group index above bit kb (k_gather_keyed / k_rekey_dense).  Streaming passes over the list:
+// count, extract, place -- against one histogram and one tile scatter per radix digit.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RR_THREADS) void k_group_starts(const uint32_t *__restrict__ U, const uint32_t *__restrict__ G, int64_t m,
+                                                              const uint32_t *__restrict__ tile_heads, uint32_t groups,
+                                                              uint32_t *__restrict__ starts)
+{
+    constexpr int NW = RR_THREADS / WAVE;
+    __shared__ uint32_t wh[NW];
+    const int l = lane_id(), w = wave_id();
+    const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)w * RR_WAVE_ELEMS;
+    uint64_t hm[RR_ITEMS];
+    uint32_t h = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        hm[r] = __ballot(i < m && U[i] == G[i]);
+        h += (uint32_t)__popcll(hm[r]);
+    }
+    if (l == 0) wh[w] = h;
+    __syncthreads();
+    uint32_t heads = tile_heads[blockIdx.x];
+    for (int ww = 0; ww < w; ++ww) heads += wh[ww];
+    const uint64_t lt_mask = (1ull << l) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        if ((hm[r] >> l) & 1ull) starts[heads + (uint32_t)__popcll(hm[r] & lt_mask)] = (uint32_t)(wbase + 64 * r + l);
+        heads += (uint32_t)__popcll(hm[r]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) starts[groups] = (uint32_t)m;
+}
+
+__global__ __launch_bounds__(256) void k_split_pivots(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ starts, uint32_t groups,
+                                                       int kb, uint64_t *__restrict__ pivot)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint64_t kmask = kb >= 64 ? ~0ull : ((1ull << kb) - 1ull);
+    if (g < groups) pivot[g] = keys[((uint64_t)starts[g] + starts[g + 1]) >> 1] & kmask;
+}
+
+// minority masks of one wave's 512 elements (wave-striped like the re-rank kernels)
+__device__ __forceinline__ void split_wave_masks(const uint64_t *__restrict__ keys, int64_t m, int64_t wbase, int kb,
+                                                 const uint64_t *__restrict__ pivot, uint64_t *k, uint64_t *mn)
+{
+    const int l = lane_id();
+    const uint64_t kmask = kb >= 64 ? ~0ull : ((1ull << kb) - 1ull);
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        k[r] = i < m ? keys[i] : 0ull;
+        mn[r] = __ballot(i < m && (k[r] & kmask) != pivot[k[r] >> kb]);
+    }
+}
+
+__global__ __launch_bounds__(RR_THREADS) void k_split_count(const uint64_t *__restrict__ keys, int64_t m, int kb,
+                                                             const uint64_t *__restrict__ pivot, uint32_t *__restrict__ tile_cnt)
+{
+    constexpr int NW = RR_THREADS / WAVE;
+    __shared__ uint32_t wc[NW];
+    const int w = wave_id();
+    const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)w * RR_WAVE_ELEMS;
+    uint64_t k[RR_ITEMS], mn[RR_ITEMS];
+    split_wave_masks(keys, m, wbase, kb, pivot, k, mn);
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) c += (uint32_t)__popcll(mn[r]);
+    if (lane_id() == 0) wc[w] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int i = 0; i < NW; ++i) t += wc[i];
+        tile_cnt[blockIdx.x] = t;
+    }
+}
+
+// PLACE = false: the minority members -> (mk, mv) in list order; mps[g] = minority members in front of group g's first member
+// (mps[groups] = their total).  PLACE = true: the members with the pivot key -> their final places in (outk, outv).
+template <bool PLACE>
+__global__ __launch_bounds__(RR_THREADS) void k_split_pass(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ V, int64_t m, int kb,
+                                                            const uint64_t *__restrict__ pivot, const uint32_t *__restrict__ tile_cnt,
+                                                            const uint32_t *__restrict__ starts, uint32_t groups, uint32_t *__restrict__ mps,
+                                                            const uint32_t *__restrict__ total, uint64_t *__restrict__ mk, uint32_t *__restrict__ mv,
+                                                            const uint32_t *__restrict__ L, uint64_t *__restrict__ outk, uint32_t *__restrict__ outv)
+{
+    constexpr int NW = RR_THREADS / WAVE;
+    __shared__ uint32_t wc[NW];
+    const int l = lane_id(), w = wave_id();
+    const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)w * RR_WAVE_ELEMS;
+    uint64_t k[RR_ITEMS], mn[RR_ITEMS];
+    split_wave_masks(keys, m, wbase, kb, pivot, k, mn);
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) c += (uint32_t)__popcll(mn[r]);
+    if (l == 0) wc[w] = c;
+    __syncthreads();
+    uint32_t off = tile_cnt[blockIdx.x];                     // minority members in front of this wave's first element
+    for (int ww = 0; ww < w; ++ww) off += wc[ww];
+    const uint64_t lt_mask = (1ull << l) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RR_ITEMS; ++r) {
+        const int64_t i = wbase + 64 * r + l;
+        if (i < m) {
+            const uint32_t before = off + (uint32_t)__popcll(mn[r] & lt_mask);
+            const uint32_t g = (uint32_t)(k[r] >> kb);
+            const bool minor = (mn[r] >> l) & 1ull;
+            if (!PLACE) {
+                if (minor) { mk[before] = k[r]; mv[before] = V[i]; }
+                if ((uint32_t)i == starts[g]) mps[g] = before;
+            } else if (!minor) {
+                // members with the pivot key in front of me in my group = (i - start) - (minority members between); L[g] go below
+                const uint32_t pos = (uint32_t)i + L[g] - (before - mps[g]);
+                outk[pos] = k[r]; outv[pos] = V[i];
+            }
+        }
+        off += (uint32_t)__popcll(mn[r]);
+    }
+    if (!PLACE && blockIdx.x == 0 && threadIdx.x == 0) mps[groups] = *total;
+}
+
+// L[g] = minority members of group g below its pivot: a binary search in the group's range of the SORTED minority keys
+__global__ __launch_bounds__(256) void k_split_less(const uint64_t *__restrict__ mk, const uint32_t *__restrict__ mps,
+                                                     const uint64_t *__restrict__ pivot, uint32_t groups, int kb, uint32_t *__restrict__ L)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= groups) return;
+    const uint64_t want = ((uint64_t)g << kb) | pivot[g];
+    uint32_t lo = mps[g], hi = mps[g + 1];
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (mk[mid] < want) lo = mid + 1; else hi = mid; }
+    L[g] = lo - mps[g];
+}
+
+__global__ __launch_bounds__(256) void k_split_place_minor(const uint64_t *__restrict__ mk, const uint32_t *__restrict__ mv, int64_t count, int kb,
+                                                            const uint32_t *__restrict__ starts, const uint32_t *__restrict__ mps,
+                                                            const uint32_t *__restrict__ L, uint64_t *__restrict__ outk, uint32_t *__restrict__ outv)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= count) return;
+    const uint64_t key = mk[q];
+    const uint32_t g = (uint32_t)(key >> kb);
+    const uint32_t t = (uint32_t)q - mps[g], cnt = mps[g + 1] - mps[g];
+    const uint32_t pos = t < L[g] ? starts[g] + t : starts[g + 1] - (cnt - t);
+    outk[pos] = key; outv[pos] = mv[q];
+}
+
 // sorted flagged elements back to their list positions (sorted by group first, and bidx is increasing,
 // so the o-th sorted element belongs at the o-th flagged position); the key gets its group-head slot back
 // (a group keeps its list positions, so position j still belongs to the group of G[j])

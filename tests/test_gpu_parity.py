@@ -9,7 +9,7 @@ import pytest
 
 import suffix_array_amd as sa
 from suffix_array_amd import corpus
-from conftest import KNOWN_ANSWERS, adversarial_cases
+from conftest import KNOWN_ANSWERS, adversarial_cases, fibonacci_word
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -247,6 +247,32 @@ def test_gram_keys(oracle, monkeypatch, g):
     build(texts[0]); st = sa.last_stats()
     if g in ("0", "3"):
         assert st["symbols_per_key"] > 10, st          # english-like sigma ~ 56: 10 or 11 symbols in the plain form
+
+
+def test_giant_groups_are_split_around_their_majority_key(oracle, monkeypatch):
+    """whole-list rounds over a few giant groups (runs, periodic texts, a block repeated): the members whose key differs from
+    their group's majority are extracted, sorted on their own and merged back (k_split_*), the rest only shifts -- thresholds
+    lowered so that the path runs at this size, with many and few groups, minorities on one side, on both sides, none at
+    all, and the fallback to the radix sort when the minority is not small"""
+    rng = np.random.default_rng(9)
+    a = np.full(400_000, 7, dtype=np.uint8)
+    blk = rng.integers(0, 256, 1000, dtype=np.uint8)
+    texts = [a, np.tile(np.array([1, 2], dtype=np.uint8), 250_000), np.resize(blk, 700_001).copy(),
+             np.concatenate([a[:100_000], [9], a[:150_000], [3], a[:70_000]]).astype(np.uint8),
+             np.concatenate([np.resize(blk[:37], 300_000), rng.integers(0, 4, 50_000, dtype=np.uint8), np.resize(blk[:37], 200_000)]).astype(np.uint8),
+             np.frombuffer(bytes(fibonacci_word(27)[:600_000]), dtype=np.uint8).copy()]
+    exp = [oracle.sais(s) for s in texts]
+    base = {"SA_AMD_SPLIT_MIN": "1", "SA_AMD_DENSE_REKEY_MIN": "1", "SA_AMD_FORCE_DENSE": "1"}
+    for extra in ({"SA_AMD_SPLIT_GROUP_MIN": "1000"}, {"SA_AMD_SPLIT_GROUP_MIN": "1", "SA_AMD_NO_LOCAL_SORT": "1"},
+                  {"SA_AMD_SPLIT_GROUP_MIN": "64", "SA_AMD_NO_LOCAL_SORT": "1", "SA_AMD_BINNED_ISA_ALWAYS": "1"},
+                  {"SA_AMD_SPLIT_GROUP_MIN": "1", "SA_AMD_GROUP_CAP": "8"}, {"SA_AMD_NO_SPLIT": "1", "SA_AMD_NO_LOCAL_SORT": "1"}):
+        env = dict(base); env.update(extra)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for s, e in zip(texts, exp):
+            assert np.array_equal(build(s), e), (env, s.size)
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def _planted(n, seed, copies):
@@ -515,7 +541,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_RUN_SKIP", "SA_AMD_RUN_SKIP_MIN", "SA_AMD_TIMING_ONLY_INITIAL_SORT",
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
-             "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN",
+             "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
