@@ -145,7 +145,7 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
         // A digit that is the same for EVERY element makes the pass the identity (the sort is stable): skip the tile scatter.
         // Worth a 1 KiB read-back (a host round trip of ~30 us) only for the large global sorts of the refinement rounds: texts
         // that are one run or one period keep hundreds of millions of suffixes in a few groups round after round, and their
-        // (group, rank) keys are constant in most digits.  The initial sort and the ISA passes never look.
+        // (group, rank) keys are constant in most digits.  The ISA passes never look, the initial sort only for a text of one byte value.
         if (may_skip && !tn.no_run_skip && count >= tn.run_skip_min && !(iota && res->passes == 0) && !(last && final_vals)) {
             uint32_t tot[RADIX];
             { const int rcw = read_words(tot, digit_tot, sizeof(tot), st); if (rcw) return rcw; }
@@ -736,7 +736,9 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
             PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
                                                           w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
                                                           counted ? w.spine : (uint32_t *)nullptr, g64.tiles_per_wg * g64.tile, g64.G, (1u << nb0) - 1u));
-        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr, tn, iota, false, counted);
+        // (a text of ONE byte value -- a zero-filled file -- has the same key everywhere but at its end: its passes are the identity
+        // and are looked for; any other text does not pay the read-backs)
+        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr, tn, iota, sigma == 1, counted);
         if (rc) return rc;
         local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
     }
