@@ -451,7 +451,10 @@ __global__ __launch_bounds__(256) void k_count_sample_dups(const uint64_t *__res
         uint32_t h = (k * 2654435761u) >> 7;
         for (;;) {
             h &= table_mask;
-            const unsigned long long old = atomicCAS(&table[h], ~0ull, e);
+            // (a look first: a text that is one run or one period hashes every sample to the same few entries, and a million
+            // compare-and-swaps on one address take 8 ms; a stale "empty" only means the swap is tried after all)
+            unsigned long long old = __atomic_load_n(&table[h], __ATOMIC_RELAXED);
+            if (old == ~0ull) old = atomicCAS(&table[h], ~0ull, e);
             if (old == ~0ull) break;                                           // inserted
             if ((uint32_t)(old >> 32) == k) { c += old != e ? 1u : 0u; break; }
             ++h;
