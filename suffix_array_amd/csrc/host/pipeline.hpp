@@ -375,7 +375,7 @@ struct Refined { const uint64_t *keys; const uint32_t *vals; uint32_t *vnext; in
 static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *Valt, const uint32_t *Ucur, const uint32_t *Gcur,
                        uint32_t *scratchU, uint32_t *scratchG, int64_t m, int64_t n, const uint8_t *dT, const KeyParams &P,
                        const KeySrc &K, int g_bits, bool *local_ok, const Workspace &w, hipStream_t st, sa_amd_stats *local,
-                       Refined *out, const Tuning &tn, bool retry_local = false)
+                       Refined *out, const Tuning &tn, bool retry_local = false, int *split_rest = nullptr)   // split_rest: rounds the three-way split sits out after its count pass found no majority
 {
     const int64_t tiles = ceil_div(m, RR_TILE);
     const int kb = K.kb;
@@ -501,7 +501,8 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
     // Giant groups (runs, periodic texts, long repeats): all but a few members of a group carry the same key, so the few
     // are pulled out and sorted on their own and the rest only shifts (three-way split around the group's majority key,
     // kernels/refine.hpp) -- if the count pass finds that they are few indeed; otherwise the radix sort below.
-    if (rekeyed && !tn.no_split && m >= tn.split_min && groups > 0 && (int64_t)groups * tn.split_group_min <= m) {
+    if (split_rest && *split_rest > 0) --*split_rest;
+    else if (rekeyed && !tn.no_split && m >= tn.split_min && groups > 0 && (int64_t)groups * tn.split_group_min <= m) {
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
         char *sg = (char *)scratchG;
         uint32_t *starts = (uint32_t *)sg;            sg += up(((size_t)groups + 1) * 4);
@@ -549,6 +550,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
                 out->keys = rkB; out->vals = Valt; out->vnext = Vcur;
                 return SA_AMD_OK;
             }
+            if (split_rest) *split_rest = 3;          // (a Fibonacci word's groups fall into parts of similar size round after round)
         }
     }
     rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn, false, true);
@@ -1028,6 +1030,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     const int64_t depth_text = depth;
     int64_t h = depth;
     bool chase_ok = false;
+    int split_rest = 0;                               // rounds the three-way split sits out (refine_list)
     bool parent_tail = false;                         // the ranks in the ISA are tail ranks (set by the first dense round)
     int64_t changed_prev = 0;                         // ranks the last dense round wrote
     int64_t m_local_off = m;                          // size of the tied list when the local pass was last in use
@@ -1052,7 +1055,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         K.has_isa = w.has_isa; K.sorted_keys = sorted0; K.sorted_top32 = sorted32; K.sa = SA; K.depth = depth_text; K.top_shift = top_shift;
         Refined rf;
         if (local_ok) { m_local_off = m; rounds_local_off = 0; }
-        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn, retry_local);
+        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn, retry_local, &split_rest);
         if (rc) return rc;
         if (retry_local && rf.m_global < m) { m_local_off = m; rounds_local_off = 0; }      // (the local pass ran again)
         const uint64_t *keysS = rf.keys; const uint32_t *valsS = rf.vals; uint32_t *Vnext = rf.vnext;
