@@ -368,6 +368,65 @@ static int scatter_binned(uint32_t *pk, uint32_t *pv, uint32_t *altk, uint32_t *
 
 struct Refined { const uint64_t *keys; const uint32_t *vals; uint32_t *vnext; int64_t m_global; };   // m_global: members ordered by the global sort
 
+// Three-way split of giant groups around their majority key (kernels/refine.hpp, k_split_*): the keys in rkA carry the dense
+// group index above bit kb, w.ft_cnt the exclusive group-start counts per tile.  *taken = false: the count pass found more
+// than an eighth of the members off their group's pivot key (or the scratch buffers too small) -- nothing has been changed,
+// the caller sorts the list with the radix sort.  scratchU / scratchG: two free 4n-byte buffers.
+static int split_giant_groups(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *Valt, const uint32_t *Ucur, const uint32_t *Gcur,
+                              uint32_t *scratchU, uint32_t *scratchG, int64_t m, int64_t n, uint32_t groups, int kb, int sort_bits,
+                              const Workspace &w, hipStream_t st, sa_amd_stats *local, Refined *out, const Tuning &tn, bool *taken)
+{
+    *taken = false;
+    const int64_t tiles = ceil_div(m, RR_TILE);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    char *sg = (char *)scratchG;
+    uint32_t *starts = (uint32_t *)sg;            sg += up(((size_t)groups + 1) * 4);     // list index of every group's first member (+ m)
+    uint32_t *mps = (uint32_t *)sg;               sg += up(((size_t)groups + 1) * 4);     // minority members in front of it (+ their total)
+    uint32_t *Lless = (uint32_t *)sg;             sg += up((size_t)groups * 4);           // minority members of the group below its pivot
+    uint64_t *pivot = (uint64_t *)sg;             sg += up((size_t)groups * 8);
+    const size_t cap = (size_t)m / 8 + 1;                                                  // (minority members when the split is taken)
+    uint32_t *mv = (uint32_t *)sg, *mv_alt = mv + ((cap + 63) & ~(size_t)63);
+    uint64_t *mk = (uint64_t *)scratchU, *mk_alt = mk + ((cap + 31) & ~(size_t)31);
+    const size_t need_g = (size_t)(sg - (char *)scratchG) + 2 * ((cap + 63) & ~(size_t)63) * 4;
+    const size_t need_u = 2 * ((cap + 31) & ~(size_t)31) * 8;
+    if (need_g > (size_t)n * 4 || need_u > (size_t)n * 4) return SA_AMD_OK;
+    PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_group_starts), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, Ucur, Gcur, m,
+                                                (const uint32_t *)w.ft_cnt, groups, starts));
+    PROF(KC_MISC, groups, st, hipLaunchKernelGGL((k_split_pivots), dim3((unsigned)ceil_div((int64_t)groups, 256)), dim3(256), 0, st,
+                                             (const uint64_t *)rkA, (const uint32_t *)starts, groups, kb, pivot));
+    PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_split_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)rkA, m, kb,
+                                                (const uint64_t *)pivot, w.tcnt));
+    PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+    uint32_t minor = 0;
+    { const int rcw = read_words(&minor, w.total, 4, st); if (rcw) return rcw; }
+    if ((int64_t)minor * 8 > m) return SA_AMD_OK;
+    *taken = true;
+    out->m_global = m;
+    if (minor == 0) {                                  // every member carries its group's pivot key: the order stands
+        out->keys = rkA; out->vals = Vcur; out->vnext = Valt;
+        return SA_AMD_OK;
+    }
+    PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_split_pass<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                (const uint64_t *)rkA, (const uint32_t *)Vcur, m, kb, (const uint64_t *)pivot,
+                                                (const uint32_t *)w.tcnt, (const uint32_t *)starts, groups, mps, (const uint32_t *)w.total,
+                                                mk, mv, (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr));
+    SortResult s2;
+    const int rc = sort_pairs(mk, mv, mk_alt, mv_alt, minor, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &s2, tn);
+    if (rc) return rc;
+    local->sort_passes += s2.passes; local->sorted_elements += (int64_t)s2.passes * minor;
+    PROF(KC_MISC, groups, st, hipLaunchKernelGGL((k_split_less), dim3((unsigned)ceil_div((int64_t)groups, 256)), dim3(256), 0, st,
+                                             (const uint64_t *)s2.keys, (const uint32_t *)mps, (const uint64_t *)pivot, groups, kb, Lless));
+    PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_split_pass<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                (const uint64_t *)rkA, (const uint32_t *)Vcur, m, kb, (const uint64_t *)pivot,
+                                                (const uint32_t *)w.tcnt, (const uint32_t *)starts, groups, mps, (const uint32_t *)w.total,
+                                                (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)Lless, rkB, Valt));
+    PROF(KC_SCATTER, minor, st, hipLaunchKernelGGL((k_split_place_minor), dim3((unsigned)ceil_div((int64_t)minor, 256)), dim3(256), 0, st,
+                                                   (const uint64_t *)s2.keys, (const uint32_t *)s2.vals, (int64_t)minor, kb,
+                                                   (const uint32_t *)starts, (const uint32_t *)mps, (const uint32_t *)Lless, rkB, Valt));
+    out->keys = rkB; out->vals = Valt; out->vnext = Vcur;
+    return SA_AMD_OK;
+}
+
 // One refinement round of the tied list with a secondary key taken from the text (KeySrc): afterwards every
 // group is ordered by (group head << kb) | key2.  Small groups: gather fused with the in-LDS group sort
 // (k_group_sort); groups no tile owns, or everything when *local_ok is off: plain gather + global radix sort.
@@ -499,65 +558,66 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
                                                       (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA));
     }
     // Giant groups (runs, periodic texts, long repeats): all but a few members of a group carry the same key, so the few
-    // are pulled out and sorted on their own and the rest only shifts (three-way split around the group's majority key,
-    // kernels/refine.hpp) -- if the count pass finds that they are few indeed; otherwise the radix sort below.
+    // are pulled out and sorted on their own and the rest only shifts (split_giant_groups) -- if its count pass finds that
+    // they are few indeed; otherwise the radix sort below.
     if (split_rest && *split_rest > 0) --*split_rest;
     else if (rekeyed && !tn.no_split && m >= tn.split_min && groups > 0 && (int64_t)groups * tn.split_group_min <= m) {
-        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        char *sg = (char *)scratchG;
-        uint32_t *starts = (uint32_t *)sg;            sg += up(((size_t)groups + 1) * 4);
-        uint32_t *mps = (uint32_t *)sg;               sg += up(((size_t)groups + 1) * 4);
-        uint32_t *Lless = (uint32_t *)sg;             sg += up((size_t)groups * 4);
-        uint64_t *pivot = (uint64_t *)sg;             sg += up((size_t)groups * 8);
-        const size_t cap = (size_t)m / 8 + 1;                                   // (minority members when the split is taken)
-        uint32_t *mv = (uint32_t *)sg, *mv_alt = mv + ((cap + 63) & ~(size_t)63);
-        uint64_t *mk = (uint64_t *)scratchU, *mk_alt = mk + ((cap + 31) & ~(size_t)31);
-        const size_t need_g = (size_t)(sg - (char *)scratchG) + 2 * ((cap + 63) & ~(size_t)63) * 4;
-        const size_t need_u = 2 * ((cap + 31) & ~(size_t)31) * 8;
-        if (need_g <= (size_t)n * 4 && need_u <= (size_t)n * 4) {
-            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_group_starts), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, Ucur, Gcur, m,
-                                                        (const uint32_t *)w.ft_cnt, groups, starts));
-            PROF(KC_MISC, groups, st, hipLaunchKernelGGL((k_split_pivots), dim3((unsigned)ceil_div((int64_t)groups, 256)), dim3(256), 0, st,
-                                                     (const uint64_t *)rkA, (const uint32_t *)starts, groups, kb, pivot));
-            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_split_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)rkA, m, kb,
-                                                        (const uint64_t *)pivot, w.tcnt));
-            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-            uint32_t minor = 0;
-            { const int rcw = read_words(&minor, w.total, 4, st); if (rcw) return rcw; }
-            if ((int64_t)minor * 8 <= m) {
-                out->m_global = m;
-                if (minor == 0) {                                  // every member carries its group's pivot key: the order stands
-                    out->keys = rkA; out->vals = Vcur; out->vnext = Valt;
-                    return SA_AMD_OK;
-                }
-                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_split_pass<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                            (const uint64_t *)rkA, (const uint32_t *)Vcur, m, kb, (const uint64_t *)pivot,
-                                                            (const uint32_t *)w.tcnt, (const uint32_t *)starts, groups, mps, (const uint32_t *)w.total,
-                                                            mk, mv, (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr));
-                SortResult s2;
-                rc = sort_pairs(mk, mv, mk_alt, mv_alt, minor, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &s2, tn);
-                if (rc) return rc;
-                local->sort_passes += s2.passes; local->sorted_elements += (int64_t)s2.passes * minor;
-                PROF(KC_MISC, groups, st, hipLaunchKernelGGL((k_split_less), dim3((unsigned)ceil_div((int64_t)groups, 256)), dim3(256), 0, st,
-                                                         (const uint64_t *)s2.keys, (const uint32_t *)mps, (const uint64_t *)pivot, groups, kb, Lless));
-                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_split_pass<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                            (const uint64_t *)rkA, (const uint32_t *)Vcur, m, kb, (const uint64_t *)pivot,
-                                                            (const uint32_t *)w.tcnt, (const uint32_t *)starts, groups, mps, (const uint32_t *)w.total,
-                                                            (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)Lless, rkB, Valt));
-                PROF(KC_SCATTER, minor, st, hipLaunchKernelGGL((k_split_place_minor), dim3((unsigned)ceil_div((int64_t)minor, 256)), dim3(256), 0, st,
-                                                               (const uint64_t *)s2.keys, (const uint32_t *)s2.vals, (int64_t)minor, kb,
-                                                               (const uint32_t *)starts, (const uint32_t *)mps, (const uint32_t *)Lless, rkB, Valt));
-                out->keys = rkB; out->vals = Valt; out->vnext = Vcur;
-                return SA_AMD_OK;
-            }
-            if (split_rest) *split_rest = 3;          // (a Fibonacci word's groups fall into parts of similar size round after round)
-        }
+        bool taken = false;
+        rc = split_giant_groups(rkA, rkB, Vcur, Valt, Ucur, Gcur, scratchU, scratchG, m, n, groups, kb, sort_bits, w, st, local, out, tn, &taken);
+        if (rc || taken) return rc;
+        if (split_rest) *split_rest = 3;              // (a Fibonacci word's groups fall into parts of similar size round after round)
     }
     rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn, false, true);
     if (rc) return rc;
     local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m;
     out->keys = sr.keys; out->vals = sr.vals; out->m_global = m;
     out->vnext = (sr.vals == Vcur) ? Valt : Vcur;
+    return SA_AMD_OK;
+}
+
+// Gram keys: how many of the sigma^g possible g-grams occur?  A word-structured text uses a small part of them, so a key of
+// dense gram ranks holds more symbols than the base-sigma form, often in fewer digits (C3, sigma = 57: 12 symbols in 7
+// passes instead of 10 in 8).  Measured (flags, count, scan), then decided: *P and *key_bits change only when the gram form
+// holds more symbols, or as many in fewer radix passes.
+static int choose_gram_keys(const uint8_t *dT, int64_t n, KeyParams *Pp, int *key_bits, const Workspace &w, hipStream_t st,
+                            const Tuning &tn, bool trace)
+{
+    KeyParams &P = *Pp;
+    const uint64_t se = P.sigma;
+    const uint64_t cap = (uint64_t)((size_t)n < GRAM_MAX_ENTRIES ? (size_t)n : GRAM_MAX_ENTRIES);
+    int g = 0;
+    uint64_t S = 1;
+    for (int t = 1; t <= 8; ++t) {
+        if (S * se > cap) break;
+        S *= se; g = t;
+        if (tn.gram_g >= 2 && g == tn.gram_g) break;
+    }
+    if (g < 2) return SA_AMD_OK;
+    uint64_t top = 1;
+    for (int t = 0; t + 1 < g; ++t) top *= se;
+    const int64_t gtiles = ceil_div((int64_t)S, GT_TILE);
+    HIP_TRY(hipMemsetAsync(w.gram_flags, 0, (size_t)S, st));
+    PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_gram_mark), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P, g,
+                                            (uint32_t)top, w.gram_flags));
+    PROF(KC_MISC, (int64_t)S, st, hipLaunchKernelGGL((k_gram_count), dim3((unsigned)gtiles), dim3(GT_THREADS), 0, st,
+                                            (const uint8_t *)w.gram_flags, (int64_t)S, w.tcnt));
+    PROF(KC_RR_SCAN, gtiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, gtiles, w.total));
+    uint32_t D = 0;
+    { const int rcw = read_words(&D, w.total, 4, st); if (rcw) return rcw; }
+    int m = 0;
+    unsigned __int128 pw = 1;
+    while (D >= 2 && (m + 1) * g <= 64 && pw * D <= ((unsigned __int128)1 << 64)) { pw *= D; ++m; }
+    const int gram_bits = m > 0 ? bit_length((uint64_t)(pw - 1)) : 0;
+    const int plain_passes = (int)ceil_div(*key_bits, RADIX_BITS), gram_passes = (int)ceil_div(gram_bits, RADIX_BITS);
+    const bool better = m > 0 && (m * g > P.k || (m * g == P.k && gram_passes < plain_passes));
+    if (trace) fprintf(stderr, "suffix_array_amd: gram keys: %u of %llu %d-grams occur -> %d symbols in %d bits (plain: %d in %d) -> %s\n",
+                       D, (unsigned long long)S, g, m * g, gram_bits, P.k, *key_bits, better ? "gram keys" : "plain keys");
+    if (!better) return SA_AMD_OK;
+    PROF(KC_MISC, (int64_t)S, st, hipLaunchKernelGGL((k_gram_table), dim3((unsigned)gtiles), dim3(GT_THREADS), 0, st,
+                                            (const uint8_t *)w.gram_flags, (int64_t)S, (const uint32_t *)w.tcnt, w.gram_table));
+    P.gram = g; P.gram_m = m; P.gram_top = (uint32_t)top; P.gram_D = D; P.gram_table = w.gram_table;
+    P.bits = 0; P.k = m * g; P.mask = ~0ull;
+    *key_bits = gram_bits;
     return SA_AMD_OK;
 }
 
@@ -648,49 +708,12 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                            dups, (long long)S, frac, probe_dense ? "rank doubling from the start" : "text-keyed rounds");
     }
 
-    // 2c. gram keys (texts that did not take the 32-bit route): how many of the sigma^g possible g-grams occur?  A
-    //     word-structured text uses a small part of them, so a key of dense gram ranks holds more symbols than the
-    //     base-sigma form, often in fewer digits (C3, sigma = 57: 12 symbols in 7 passes instead of 10 in 8).  Measured
-    //     (flags, count, scan), then decided; the probes above keep using the plain key.
+    // 2c. gram keys (texts that did not take the 32-bit route): choose_gram_keys measures and decides; the probes above keep
+    //     using the plain key
     if (!top_shift && !tn.no_gram_keys && n >= tn.gram_min_n && n >= 2 && sigma >= 2 && tn.key_bits_max == 64) {
-        const uint64_t se = P.sigma;
-        const uint64_t cap = (uint64_t)((size_t)n < GRAM_MAX_ENTRIES ? (size_t)n : GRAM_MAX_ENTRIES);
-        int g = 0;
-        uint64_t S = 1;
-        for (int t = 1; t <= 8; ++t) {
-            if (S * se > cap) break;
-            S *= se; g = t;
-            if (tn.gram_g >= 2 && g == tn.gram_g) break;
-        }
-        if (g >= 2) {
-            uint64_t top = 1;
-            for (int t = 0; t + 1 < g; ++t) top *= se;
-            const int64_t gtiles = ceil_div((int64_t)S, GT_TILE);
-            HIP_TRY(hipMemsetAsync(w.gram_flags, 0, (size_t)S, st));
-            PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_gram_mark), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P, g,
-                                                    (uint32_t)top, w.gram_flags));
-            PROF(KC_MISC, (int64_t)S, st, hipLaunchKernelGGL((k_gram_count), dim3((unsigned)gtiles), dim3(GT_THREADS), 0, st,
-                                                    (const uint8_t *)w.gram_flags, (int64_t)S, w.tcnt));
-            PROF(KC_RR_SCAN, gtiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, gtiles, w.total));
-            uint32_t D = 0;
-            { const int rcw = read_words(&D, w.total, 4, st); if (rcw) return rcw; }
-            int m = 0;
-            unsigned __int128 pw = 1;
-            while (D >= 2 && (m + 1) * g <= 64 && pw * D <= ((unsigned __int128)1 << 64)) { pw *= D; ++m; }
-            const int gram_bits = m > 0 ? bit_length((uint64_t)(pw - 1)) : 0;
-            const int plain_passes = (int)ceil_div(key_bits, RADIX_BITS), gram_passes = (int)ceil_div(gram_bits, RADIX_BITS);
-            const bool better = m > 0 && (m * g > P.k || (m * g == P.k && gram_passes < plain_passes));
-            if (trace) fprintf(stderr, "suffix_array_amd: gram keys: %u of %llu %d-grams occur -> %d symbols in %d bits (plain: %d in %d) -> %s\n",
-                               D, (unsigned long long)S, g, m * g, gram_bits, P.k, key_bits, better ? "gram keys" : "plain keys");
-            if (better) {
-                PROF(KC_MISC, (int64_t)S, st, hipLaunchKernelGGL((k_gram_table), dim3((unsigned)gtiles), dim3(GT_THREADS), 0, st,
-                                                        (const uint8_t *)w.gram_flags, (int64_t)S, (const uint32_t *)w.tcnt, w.gram_table));
-                P.gram = g; P.gram_m = m; P.gram_top = (uint32_t)top; P.gram_D = D; P.gram_table = w.gram_table;
-                P.bits = 0; P.k = m * g; P.mask = ~0ull;
-                key_bits = gram_bits;
-                local.bits_per_symbol = 0; local.symbols_per_key = P.k;
-            }
-        }
+        const int rcg = choose_gram_keys(dT, n, &P, &key_bits, w, st, tn, trace);
+        if (rcg) return rcg;
+        local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
     }
 
     // 3. packed keys, 4. initial sort: all key bits as (u64 key, u32 suffix) pairs, or only the top 32 bits as
