@@ -597,7 +597,7 @@ static int choose_gram_keys(const uint8_t *dT, int64_t n, KeyParams *Pp, int *ke
     for (int t = 0; t + 1 < g; ++t) top *= se;
     const int64_t gtiles = ceil_div((int64_t)S, GT_TILE);
     HIP_TRY(hipMemsetAsync(w.gram_flags, 0, (size_t)S, st));
-    PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_gram_mark), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P, g,
+    PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_gram_mark), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), GM_TPW)), dim3(KB_THREADS), 0, st, dT, n, P, g,
                                             (uint32_t)top, w.gram_flags));
     PROF(KC_MISC, (int64_t)S, st, hipLaunchKernelGGL((k_gram_count), dim3((unsigned)gtiles), dim3(GT_THREADS), 0, st,
                                             (const uint8_t *)w.gram_flags, (int64_t)S, w.tcnt));

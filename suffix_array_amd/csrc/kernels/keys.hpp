@@ -95,8 +95,12 @@ __device__ __forceinline__ void kb_stage_codes(const uint8_t *__restrict__ T, in
 // keys it writes -- the digit of the first radix pass -- and adds it to that pass's spine (counts[d * G + chunk], zeroed by
 // the host; chunk_elems is a multiple of KB_TILE), so the first k_radix_upsweep[32] launch and its read of every key go away.
 constexpr int KB_TPW = 8;
-constexpr int GRAM_CACHE = 4096;            // direct-mapped per-workgroup cache of gram indices already handled (mark) / of their ranks (keys)
-__device__ __forceinline__ uint32_t gram_slot(uint32_t idx) { return (idx * 2654435761u) >> 20; }     // 12 bits
+constexpr int GM_LOG = 13;
+constexpr int GRAM_CACHE = 1 << GM_LOG;     // direct-mapped per-workgroup cache of gram indices already marked (k_gram_mark)
+constexpr int GM_TPW = 64;                  // tiles per workgroup there: the cache is warm after the first few.  Measured at 256 MiB
+                                            // (cache entries, tiles): (4096, 8) 809 us, (8192, 16) 761, (8192, 64) 718, (16384, 64) 1056;
+                                            // without any flag access the kernel takes 217 us -- the misses' flag reads are the rest
+__device__ __forceinline__ uint32_t gram_slot(uint32_t idx) { return (idx * 2654435761u) >> (32 - GM_LOG); }
 
 template <bool TOP32, bool GRAM = false>
 __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__restrict__ T, int64_t n,
@@ -262,8 +266,8 @@ __global__ __launch_bounds__(KB_THREADS) void k_gram_mark(const uint8_t *__restr
     for (int i = tid; i < GRAM_CACHE; i += KB_THREADS) s_tag[i] = 0xffffffffu;
     __syncthreads();
     const int64_t tiles = (n + KB_TILE - 1) / KB_TILE;
-    const int64_t tile0 = (int64_t)blockIdx.x * KB_TPW;
-    const int64_t tile1 = tile0 + KB_TPW < tiles ? tile0 + KB_TPW : tiles;
+    const int64_t tile0 = (int64_t)blockIdx.x * GM_TPW;
+    const int64_t tile1 = tile0 + GM_TPW < tiles ? tile0 + GM_TPW : tiles;
     const uint32_t sg = (uint32_t)P.sigma;
     for (int64_t tile = tile0; tile < tile1; ++tile) {
         const int64_t base = tile * KB_TILE;
