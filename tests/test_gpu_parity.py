@@ -630,6 +630,35 @@ def test_unpack_rejects_truncated_data():
         hip.hipFree(p)
 
 
+def test_device_entry_point_with_unaligned_text(oracle, monkeypatch):
+    """sa_amd_saca_device takes the text wherever the caller has it in HBM: offsets 1, 3 and 5 from an aligned block (the
+    kernels read the text with 8- and 16-byte loads where the address allows and byte loads where it does not), gram keys
+    and plain keys, small and word-structured alphabets"""
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    L = sa.lib()
+    monkeypatch.setenv("SA_AMD_GRAM_MIN_N", "1")
+    texts = [corpus.english(150_001, 3), corpus.dna(90_000, 4), corpus.uniform(70_003, 5), np.full(33_000, 9, dtype=np.uint8)]
+    for t in texts:
+        n = int(t.size)
+        exp = oracle.sais(t)
+        wb = sa.workspace_bytes(n)
+        dt, do, dw = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dt), n + 64) == 0 and hip.hipMalloc(ctypes.byref(do), 4 * (n + 1) + 64) == 0
+        assert hip.hipMalloc(ctypes.byref(dw), wb + 512) == 0
+        work = (dw.value + 255) & ~255
+        for off in (0, 1, 3, 5):
+            assert hip.hipMemcpy(dt.value + off, t.ctypes.data, n, 1) == 0
+            assert L.sa_amd_saca_device(dt.value + off, do.value, n, work, wb, None, None) == 0
+            out = np.zeros(n + 1, dtype=np.uint32)
+            assert hip.hipMemcpy(out.ctypes.data, do.value, 4 * (n + 1), 2) == 0
+            assert np.array_equal(out, exp), (n, off)
+        for p in (dt, do, dw):
+            hip.hipFree(p)
+
+
 # ---- BASELINE.json full-size configs: size-independent properties + oracle equality ----------
 
 def _sampled_neighbours_ordered(text, arr, seed, samples=3000, width=256):
