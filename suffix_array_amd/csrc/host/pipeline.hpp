@@ -374,7 +374,8 @@ struct Refined { const uint64_t *keys; const uint32_t *vals; uint32_t *vnext; in
 // the caller sorts the list with the radix sort.  scratchU / scratchG: two free 4n-byte buffers.
 static int split_giant_groups(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *Valt, const uint32_t *Ucur, const uint32_t *Gcur,
                               uint32_t *scratchU, uint32_t *scratchG, int64_t m, int64_t n, uint32_t groups, int kb, int sort_bits,
-                              const Workspace &w, hipStream_t st, sa_amd_stats *local, Refined *out, const Tuning &tn, bool *taken)
+                              const Workspace &w, hipStream_t st, sa_amd_stats *local, Refined *out, const Tuning &tn, bool *taken,
+                              bool starts_ready)            // the gather has written the table of group starts (first array in scratchG)
 {
     *taken = false;
     const int64_t tiles = ceil_div(m, RR_TILE);
@@ -390,8 +391,9 @@ static int split_giant_groups(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint
     const size_t need_g = (size_t)(sg - (char *)scratchG) + 2 * ((cap + 63) & ~(size_t)63) * 4;
     const size_t need_u = 2 * ((cap + 31) & ~(size_t)31) * 8;
     if (need_g > (size_t)n * 4 || need_u > (size_t)n * 4) return SA_AMD_OK;
-    PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_group_starts), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, Ucur, Gcur, m,
-                                                (const uint32_t *)w.ft_cnt, groups, starts));
+    if (!starts_ready)
+        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_group_starts), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, Ucur, Gcur, m,
+                                                    (const uint32_t *)w.ft_cnt, groups, starts));
     PROF(KC_MISC, groups, st, hipLaunchKernelGGL((k_split_pivots), dim3((unsigned)ceil_div((int64_t)groups, 256)), dim3(256), 0, st,
                                              (const uint64_t *)rkA, (const uint32_t *)starts, groups, kb, pivot));
     PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_split_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)rkA, m, kb,
@@ -532,6 +534,9 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
             rekeyed = true;
         }
     }
+    const bool split_wanted = rekeyed && !tn.no_split && m >= tn.split_min && groups > 0 && (int64_t)groups * tn.split_group_min <= m &&
+                              !(split_rest && *split_rest > 0);
+    bool starts_ready = false;
     if (had_local_pass) {
         if (rekeyed)
             PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rekey_dense), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rkA, Ucur, Gcur, m,
@@ -547,23 +552,27 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
                                                         (const uint32_t *)w.ft_cnt, kb));
     } else {
         const uint32_t *th = rekeyed ? (const uint32_t *)w.ft_cnt : (const uint32_t *)nullptr;
+        // (when the three-way split may follow, the gather also writes its table of group starts: the first array in scratchG)
+        uint32_t *gs = split_wanted ? scratchG : (uint32_t *)nullptr;
+        starts_ready = gs != nullptr;
         if (K.mode == KS_TEXT)
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_keyed<KS_TEXT>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                      (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA));
+                                                      (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA, gs, groups));
         else if (K.mode == KS_LOWKEY)
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_keyed<KS_LOWKEY>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                      (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA));
+                                                      (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA, gs, groups));
         else
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_keyed<KS_RANK>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                      (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA));
+                                                      (const uint32_t *)Vcur, Ucur, Gcur, dT, P, m, n, K, th, rkA, gs, groups));
     }
     // Giant groups (runs, periodic texts, long repeats): all but a few members of a group carry the same key, so the few
     // are pulled out and sorted on their own and the rest only shifts (split_giant_groups) -- if its count pass finds that
     // they are few indeed; otherwise the radix sort below.
     if (split_rest && *split_rest > 0) --*split_rest;
-    else if (rekeyed && !tn.no_split && m >= tn.split_min && groups > 0 && (int64_t)groups * tn.split_group_min <= m) {
+    else if (split_wanted) {
         bool taken = false;
-        rc = split_giant_groups(rkA, rkB, Vcur, Valt, Ucur, Gcur, scratchU, scratchG, m, n, groups, kb, sort_bits, w, st, local, out, tn, &taken);
+        rc = split_giant_groups(rkA, rkB, Vcur, Valt, Ucur, Gcur, scratchU, scratchG, m, n, groups, kb, sort_bits, w, st, local, out, tn, &taken,
+                                starts_ready);
         if (rc || taken) return rc;
         if (split_rest) *split_rest = 3;              // (a Fibonacci word's groups fall into parts of similar size round after round)
     }

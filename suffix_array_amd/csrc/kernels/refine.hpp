@@ -1028,7 +1028,7 @@ template <int MODE>
 __global__ __launch_bounds__(RR_THREADS) void k_gather_keyed(const uint32_t *__restrict__ V, const uint32_t *__restrict__ U,
                                                               const uint32_t *__restrict__ G, const uint8_t *__restrict__ T, KeyParams P,
                                                               int64_t m, int64_t n, KeySrc K, const uint32_t *__restrict__ tile_heads,
-                                                              uint64_t *__restrict__ keys)
+                                                              uint64_t *__restrict__ keys, uint32_t *__restrict__ starts, uint32_t groups)
 {
     constexpr int NW = RR_THREADS / WAVE;
     __shared__ uint32_t wh[NW];
@@ -1067,8 +1067,10 @@ __global__ __launch_bounds__(RR_THREADS) void k_gather_keyed(const uint32_t *__r
         const int64_t i = wbase + 64 * r + l;
         const uint32_t hi = tile_heads ? heads + (uint32_t)__popcll(hm[r] & le_mask) - 1u : g[r];
         if (i < m) keys[i] = ((uint64_t)hi << K.kb) | k2[r];
+        if (starts && ((hm[r] >> l) & 1ull)) starts[hi] = (uint32_t)i;          // (what k_group_starts would write: the three-way split's table)
         heads += (uint32_t)__popcll(hm[r]);
     }
+    if (starts && blockIdx.x == 0 && threadIdx.x == 0) starts[groups] = (uint32_t)m;
 }
 
 // ------------------------------------------------------------------------------------------
