@@ -4,6 +4,7 @@
 #pragma once
 #include "support.hpp"
 #include "tuning.hpp"
+#include "pool.hpp"
 
 namespace sa {
 
@@ -49,6 +50,14 @@ static SortGrid sort_grid(int64_t count, const SortVariant &sv)
     return g;
 }
 
+// what a radix sort needs besides its ping-pong buffers
+struct SortScratch {
+    uint32_t *spine;                // RADIX * SORT_MAX_WG words: per-chunk counts (three-kernel pass) / two zones of segment counts + tickets (single-pass)
+    uint32_t *digit_tot;            // RADIX words
+    unsigned long long *status;     // single-pass scatter: 256 granules per tile (nullptr: the three-kernel pass is used)
+    uint32_t *err;                  // single-pass scatter: look-back give-ups (must stay 0)
+};
+
 // device scratch layout for a text of n bytes
 struct Workspace {
     uint64_t *keysA, *keysB, *keysC;
@@ -58,6 +67,9 @@ struct Workspace {
     uint8_t *gram_flags;       // gram keys: which g-grams occur (sigma^g <= min(n, 2^24) flags) and
     uint4 *gram_table;         //   the rank directory over them (16 bytes per 64 indices)
     uint32_t *surv_bits, *surv_cnt, *todo_bits, *ft_cnt, *ft_head;   // first refinement round straight from the sorted keys (k_finish_sorted)
+    unsigned long long *os_status;  // look-back granules of the single-pass tile scatter: 2 KiB per 8192-element tile
+    uint32_t *os_err;
+    SortScratch ss;
     size_t bytes;
 };
 
@@ -97,25 +109,159 @@ static Workspace carve(void *base, int64_t n)
     const size_t ft_tiles = (size_t)ceil_div((int64_t)N, FT_TILE) + 1;
     w.ft_cnt = (uint32_t *)take(ft_tiles * 4);
     w.ft_head = (uint32_t *)take(ft_tiles * 4);
+    w.os_status = (unsigned long long *)take(((size_t)ceil_div((int64_t)N, OS_THREADS * 8) + 1) * RADIX * 8);
+    w.os_err = (uint32_t *)take(256);
+    w.ss.spine = w.spine; w.ss.digit_tot = w.digit_tot; w.ss.status = w.os_status; w.ss.err = w.os_err;
     w.bytes = off;
     return w;
 }
 
-struct SortResult { uint64_t *keys; uint32_t *vals; int passes; int skipped; };
+
+// ------------------------------------------------------------------------------------------
+// Single-pass tile scatter (kernels/onesweep.hpp): host side of one LSD sort.
+// Scratch inside the spine slab: two ZONES of OS_ZONE words, zone = [16 tickets | RADIX * OS_NSEG segment counts].
+// Pass p reads its digit's counts from zone z and writes the next digit's counts -- and takes its tickets -- in zone z ^ 1,
+// which the host zeroes right before the launch.
+// ------------------------------------------------------------------------------------------
+constexpr int OS_ITEMS64 = 8;                  // 8192-pair tiles of (u64, u32)
+constexpr int OS_ITEMS32 = 12;                 // 12288-pair tiles of (u32, u32)
+constexpr int OS_ZONE = 16 + RADIX * OS_NSEG;  // words
+static_assert(2 * OS_ZONE <= RADIX * SORT_MAX_WG, "both zones live in the spine slab");
+
+static bool onesweep_on(const SortScratch &ss, const Tuning &tn) { return ss.status != nullptr && !tn.no_onesweep; }
+
+struct OnesweepGeom { int tiles, nseg, tiles_per_seg; int64_t seg_elems; };
+static OnesweepGeom onesweep_geom(int64_t count, int tile)
+{
+    OnesweepGeom g;
+    g.tiles = (int)ceil_div(count, tile);
+    if (g.tiles < 1) g.tiles = 1;
+    int nseg = g.tiles < OS_NSEG ? g.tiles : OS_NSEG;
+    g.tiles_per_seg = (int)ceil_div(g.tiles, nseg);
+    g.nseg = (int)ceil_div(g.tiles, g.tiles_per_seg);
+    g.seg_elems = (int64_t)g.tiles_per_seg * tile;
+    return g;
+}
+
+// Where a producer of the keys adds the counts of the first pass's digit (k_build_keys: counts[d * G + chunk]), for the
+// sort that will run on `count` pairs with this scratch: pointer, chunk size in elements, chunks.  The producer's stream
+// must zero *zero_bytes bytes at *zero_ptr first.
+struct FirstCounts { uint32_t *counts; int64_t chunk_elems; int G; void *zero_ptr; size_t zero_bytes; };
+static FirstCounts sort_first_counts(const SortScratch &ss, const Tuning &tn, int64_t count, bool keys32);
+
+static int cu_count()
+{
+    static int cus = 0;
+    if (cus > 0) return cus;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    else { (void)hipGetLastError(); cus = 256; }
+    return cus;
+}
+
 static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st);
+
+__global__ __launch_bounds__(RADIX) void k_os_digit_totals(const uint32_t *__restrict__ hist, int nseg, uint32_t *__restrict__ digit_tot)
+{
+    uint32_t s = 0;
+    for (int q = 0; q < nseg; ++q) s += hist[threadIdx.x * nseg + q];
+    digit_tot[threadIdx.x] = s;
+}
+
+template <typename KeyT, int ITEMS>
+static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit, int end_bit,
+                               const SortScratch &ss, uint32_t *final_vals, hipStream_t st, KeyT **keys_res, uint32_t **vals_res, int *passes,
+                               int *skipped, const Tuning &tn, bool iota, bool may_skip, bool first_counted)
+{
+    constexpr int TILE = OS_THREADS * ITEMS;
+    constexpr bool K64 = sizeof(KeyT) == 8;
+    const OnesweepGeom g = onesweep_geom(count, TILE);
+    uint32_t *zone[2] = { ss.spine, ss.spine + OS_ZONE };
+    int z = 0;                                    // zone that holds (or will hold) the counts of the coming pass's digit
+    bool have_counts = first_counted;
+    HIP_TRY(hipMemsetAsync(ss.status, 0, (size_t)g.tiles * RADIX * 8, st));
+    KeyT *kin = keys_in, *kout = keys_alt;
+    uint32_t *vin = vals_in, *vout = vals_alt;
+    int grid = cu_count();
+    if (grid > g.tiles) grid = g.tiles;
+    uint32_t epoch = 0;
+    for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
+        const int nb = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
+        const uint32_t dmask = (1u << nb) - 1u;
+        const bool last = shift + RADIX_BITS >= end_bit;
+        uint32_t *vdst = (last && final_vals) ? final_vals : vout;
+        if (!have_counts) {
+            // one read of the keys for the counts of this digit (first pass of a sort whose producer did not count, or the
+            // pass after a skipped one)
+            HIP_TRY(hipMemsetAsync(zone[z], 0, (size_t)OS_ZONE * 4, st));
+            int split = 2048 / g.nseg;
+            while (split > 1 && g.seg_elems / split < 8192) split /= 2;
+            const int64_t sub = K64 ? ((ceil_div(g.seg_elems, split) + 1) & ~(int64_t)1) : ((ceil_div(g.seg_elems, split) + 3) & ~(int64_t)3);
+            if (K64)
+                PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.nseg * split), dim3(SORT_THREADS), 0, st, (const uint64_t *)kin,
+                                                               zone[z] + 16, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
+            else
+                PROF(KC_UPSWEEP32, count, st, hipLaunchKernelGGL((k_radix_upsweep32), dim3(g.nseg * split), dim3(SORT_THREADS), 0, st, (const uint32_t *)kin,
+                                                                 zone[z] + 16, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
+        }
+        if (may_skip && !tn.no_run_skip && count >= tn.run_skip_min && !(iota && *passes == 0) && !(last && final_vals)) {
+            // a digit that is the same for EVERY element makes the pass the identity (the sort is stable): skip it
+            hipLaunchKernelGGL(k_os_digit_totals, dim3(1), dim3(RADIX), 0, st, (const uint32_t *)(zone[z] + 16), g.nseg, ss.digit_tot);
+            LAUNCH_CHECK(st);
+            uint32_t tot[RADIX];
+            { const int rcw = read_words(tot, ss.digit_tot, sizeof(tot), st); if (rcw) return rcw; }
+            bool constant = false;
+            for (int d = 0; d < RADIX; ++d) constant |= (int64_t)tot[d] == count;
+            if (constant) { ++*skipped; have_counts = false; continue; }
+        }
+        OnesweepPass P;
+        P.hist_cur = zone[z] + 16;
+        P.hist_next = last ? nullptr : zone[z ^ 1] + 16;
+        P.tickets = zone[z ^ 1];
+        P.status = ss.status;
+        P.err = ss.err;
+        P.n = count;
+        P.shift = shift; P.dmask = dmask;
+        P.shift_next = shift + RADIX_BITS;
+        { const int nbn = (end_bit - P.shift_next) < RADIX_BITS ? (end_bit - P.shift_next) : RADIX_BITS; P.dmask_next = last ? 0u : (1u << nbn) - 1u; }
+        P.nseg = g.nseg; P.tiles_per_seg = g.tiles_per_seg; P.tiles = g.tiles;
+        P.epoch = ++epoch;
+        P.flags = (uint32_t)tn.onesweep_flags;
+        HIP_TRY(hipMemsetAsync(zone[z ^ 1], 0, (size_t)OS_ZONE * 4, st));
+        PROF(K64 ? KC_DOWNSWEEP : KC_DOWNSWEEP32, count, st,
+             hipLaunchKernelGGL((k_onesweep<ITEMS, KeyT>), dim3(grid), dim3(OS_THREADS), 0, st, (const KeyT *)kin,
+                                (const uint32_t *)((iota && *passes == 0) ? nullptr : vin), kout, vdst, P));
+        KeyT *tk = kin; kin = kout; kout = tk;
+        uint32_t *free_v = vin;                   // the values just consumed become the next scratch target
+        vin = vdst;
+        vout = free_v;
+        ++*passes;
+        z ^= 1;
+        have_counts = !last;
+    }
+    *keys_res = kin; *vals_res = vin;
+    return SA_AMD_OK;
+}
+
+struct SortResult { uint64_t *keys; uint32_t *vals; int passes; int skipped; };
 
 // stable LSD sort of `count` pairs on key bits [begin_bit, end_bit); ping-pongs between in/alt.
 // spine: RADIX * SORT_MAX_WG words, digit_tot: RADIX words.  final_vals (optional): the LAST pass
 // writes its values there instead of into the ping-pong buffer (the initial sort delivers
 // straight into SA this way).
 static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, uint32_t *vals_alt, int64_t count,
-                      int begin_bit, int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals,
+                      int begin_bit, int end_bit, const SortScratch &ss, uint32_t *final_vals,
                       hipStream_t st, SortResult *res, const Tuning &tn, bool iota = false,   // iota: value i = index i, vals_in is scratch only
                       bool may_skip = false,                                                   // look for passes that are the identity (costs a read-back per pass)
-                      bool first_counted = false)                                              // the producer of keys_in has histogrammed the first digit into the (zeroed) spine
+                      bool first_counted = false)                                              // the producer of keys_in has histogrammed the first digit (sort_first_counts says where and how)
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0; res->skipped = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
+    if (onesweep_on(ss, tn))
+        return sort_pairs_onesweep<uint64_t, OS_ITEMS64>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
+                                                         &res->keys, &res->vals, &res->passes, &res->skipped, tn, iota, may_skip, first_counted);
+    uint32_t *spine = ss.spine, *digit_tot = ss.digit_tot;
     const SortVariant &sv = sort_variants[tn.sort_variant];
     const SortGrid g = sort_grid(count, sv);
     uint64_t *kin = keys_in, *kout = keys_alt;
@@ -200,11 +346,20 @@ static SortGrid32 sort_grid32(int64_t count, const Sort32Variant &sv)
 }
 
 static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit,
-                        int end_bit, uint32_t *spine, uint32_t *digit_tot, uint32_t *final_vals, hipStream_t st, SortResult32 *res,
+                        int end_bit, const SortScratch &ss, uint32_t *final_vals, hipStream_t st, SortResult32 *res,
                         const Tuning &tn, bool iota = false, bool first_counted = false)
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
+    if (onesweep_on(ss, tn)) {
+        int skipped = 0;
+        if (tn.onesweep32_items == 8)
+            return sort_pairs_onesweep<uint32_t, 8>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
+                                                    &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted);
+        return sort_pairs_onesweep<uint32_t, OS_ITEMS32>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
+                                                         &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted);
+    }
+    uint32_t *spine = ss.spine, *digit_tot = ss.digit_tot;
     const Sort32Variant &sv = sort32_variants[tn.sort32_variant];
     const SortGrid32 g32 = sort_grid32(count, sv);
     const int64_t SORT32_TILE = g32.tile, tiles_per_wg = g32.tiles_per_wg;
@@ -243,6 +398,28 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
     }
     res->keys = kin; res->vals = vin;
     return SA_AMD_OK;
+}
+
+static FirstCounts sort_first_counts(const SortScratch &ss, const Tuning &tn, int64_t count, bool keys32)
+{
+    FirstCounts f;
+    if (onesweep_on(ss, tn)) {
+        const int tile = OS_THREADS * (keys32 ? (tn.onesweep32_items == 8 ? 8 : OS_ITEMS32) : OS_ITEMS64);
+        const OnesweepGeom g = onesweep_geom(count, tile);
+        f.counts = ss.spine + 16; f.chunk_elems = g.seg_elems; f.G = g.nseg;
+        f.zero_ptr = ss.spine; f.zero_bytes = (size_t)OS_ZONE * 4;
+        return f;
+    }
+    f.counts = ss.spine; f.zero_ptr = ss.spine;
+    if (keys32) {
+        const SortGrid32 g32 = sort_grid32(count, sort32_variants[tn.sort32_variant]);
+        f.chunk_elems = g32.tiles_per_wg * g32.tile; f.G = g32.G;
+    } else {
+        const SortGrid g64 = sort_grid(count, sort_variants[tn.sort_variant]);
+        f.chunk_elems = g64.tiles_per_wg * g64.tile; f.G = g64.G;
+    }
+    f.zero_bytes = (size_t)RADIX * f.G * 4;
+    return f;
 }
 
 // symbol codes and key geometry from the sigma = 256 histogram; returns the number of key bits to sort
@@ -284,23 +461,25 @@ static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out, i
 
 // Small device -> host read-backs (counts that steer the host loop) go through a pinned per-thread buffer:
 // a 4-byte hipMemcpyAsync into pageable memory costs ~50-90 us per round trip, into pinned memory ~10.
+// The buffer is a block of the process-wide pool: a short-lived worker thread (sa_amd_saca_batch) hands it back when it
+// exits instead of paying hipHostMalloc / hipHostFree per call; a failed allocation is remembered, not retried per call.
 struct PinnedWords {
-    uint32_t *p = nullptr;
-    ~PinnedWords() { if (p) (void)hipHostFree(p); }
+    PinBlock b;
+    bool failed = false;
+    ~PinnedWords() { if (b.p) pool().release_pinned(b); }
 };
 static thread_local PinnedWords g_pinned;
 static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)     // bytes <= 4096; synchronises the stream
 {
-    if (!g_pinned.p && hipHostMalloc((void **)&g_pinned.p, 4096, hipHostMallocDefault) != hipSuccess) {
-        g_pinned.p = nullptr;
-        (void)hipGetLastError();
+    if (!g_pinned.b.p && !g_pinned.failed && pool().pinned(4096, -1, -1, &g_pinned.b) != SA_AMD_OK) g_pinned.failed = true;
+    if (!g_pinned.b.p) {
         HIP_TRY(hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         return SA_AMD_OK;
     }
-    HIP_TRY(hipMemcpyAsync(g_pinned.p, dsrc, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(g_pinned.b.p, dsrc, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    memcpy(dst, g_pinned.p, bytes);
+    memcpy(dst, g_pinned.b.p, bytes);
     return SA_AMD_OK;
 }
 
@@ -334,17 +513,17 @@ static int scatter_binned(uint32_t *pk, uint32_t *pv, uint32_t *altk, uint32_t *
         int rc;
         if (iota) {
             const int mid = wlog + RADIX_BITS < nb ? wlog + RADIX_BITS : nb;
-            rc = sort_pairs32(pk, nullptr, altk, altv, count, wlog, mid, w.spine, w.digit_tot, nullptr, st, &pr, tn, true);
+            rc = sort_pairs32(pk, nullptr, altk, altv, count, wlog, mid, w.ss, nullptr, st, &pr, tn, true);
             if (rc) return rc;
             if (pr.passes != 1) return SA_AMD_EINTERNAL;            // (cannot happen: nb > wlog whenever count > 1)
             local->sort_passes += 1; local->sorted_elements += count;
             if (mid < nb) {
-                rc = sort_pairs32(altk, altv, altk2, altv2, count, mid, nb, w.spine, w.digit_tot, nullptr, st, &pr, tn);
+                rc = sort_pairs32(altk, altv, altk2, altv2, count, mid, nb, w.ss, nullptr, st, &pr, tn);
                 if (rc) return rc;
                 local->sort_passes += pr.passes; local->sorted_elements += (int64_t)pr.passes * count;
             }
         } else {
-            rc = sort_pairs32(pk, pv, altk, altv, count, wlog, nb, w.spine, w.digit_tot, nullptr, st, &pr, tn);
+            rc = sort_pairs32(pk, pv, altk, altv, count, wlog, nb, w.ss, nullptr, st, &pr, tn);
             if (rc) return rc;
             local->sort_passes += pr.passes; local->sorted_elements += (int64_t)pr.passes * count;
         }
@@ -358,7 +537,7 @@ static int scatter_binned(uint32_t *pk, uint32_t *pv, uint32_t *altk, uint32_t *
         return SA_AMD_OK;
     }
     const int shift = nb > RADIX_BITS ? nb - RADIX_BITS : 0;
-    int rc = sort_pairs32(pk, pv, altk, altv, count, shift, shift + RADIX_BITS, w.spine, w.digit_tot, nullptr, st, &pr, tn, iota);
+    int rc = sort_pairs32(pk, pv, altk, altv, count, shift, shift + RADIX_BITS, w.ss, nullptr, st, &pr, tn, iota);
     if (rc) return rc;
     local->sort_passes += pr.passes; local->sorted_elements += (int64_t)pr.passes * count;
     PROF(KC_SCATTER, count, st, hipLaunchKernelGGL((k_scatter_pairs<uint32_t>), dim3((unsigned)ceil_div(count, 1024)), dim3(256), 0, st,
@@ -413,7 +592,7 @@ static int split_giant_groups(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint
                                                 (const uint32_t *)w.tcnt, (const uint32_t *)starts, groups, mps, (const uint32_t *)w.total,
                                                 mk, mv, (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr));
     SortResult s2;
-    const int rc = sort_pairs(mk, mv, mk_alt, mv_alt, minor, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &s2, tn);
+    const int rc = sort_pairs(mk, mv, mk_alt, mv_alt, minor, 0, sort_bits, w.ss, nullptr, st, &s2, tn);
     if (rc) return rc;
     local->sort_passes += s2.passes; local->sorted_elements += (int64_t)s2.passes * minor;
     PROF(KC_MISC, groups, st, hipLaunchKernelGGL((k_split_less), dim3((unsigned)ceil_div((int64_t)groups, 256)), dim3(256), 0, st,
@@ -501,7 +680,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
                 PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_flag_gather), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                             (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, Ucur, Gcur, m,
                                                             (const uint32_t *)w.tcnt, (const uint32_t *)w.ft_cnt, kb, rkB, Valt, scratchU));
-                rc = sort_pairs(rkB, Valt, rkB + half, Valt + half, m_big, 0, kb + idx_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn, false, true);
+                rc = sort_pairs(rkB, Valt, rkB + half, Valt + half, m_big, 0, kb + idx_bits, w.ss, nullptr, st, &sr, tn, false, true);
                 if (rc) return rc;
                 local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m_big;
                 PROF(KC_SCATTER, m_big, st, hipLaunchKernelGGL((k_scatter_back), dim3((unsigned)ceil_div(m_big, 256)), dim3(256), 0, st,
@@ -576,7 +755,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         if (rc || taken) return rc;
         if (split_rest) *split_rest = 3;              // (a Fibonacci word's groups fall into parts of similar size round after round)
     }
-    rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, sort_bits, w.spine, w.digit_tot, nullptr, st, &sr, tn, false, true);
+    rc = sort_pairs(rkA, Vcur, rkB, Valt, m, 0, sort_bits, w.ss, nullptr, st, &sr, tn, false, true);
     if (rc) return rc;
     local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * m;
     out->keys = sr.keys; out->vals = sr.vals; out->m_global = m;
@@ -649,6 +828,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     Workspace w = carve(dWork, n);
     if ((int64_t)w.bytes > work_bytes) return SA_AMD_EINVAL;
     uint32_t *SA = dSA + 1;
+    HIP_TRY(hipMemsetAsync(w.os_err, 0, 16, st));          // look-back give-ups of the single-pass scatter: checked at the end
 
     // 1. sigma = 256 histogram -> symbol codes, bits per symbol, symbols per key
     HIP_TRY(hipMemsetAsync(w.hist, 0, 256 * 4, st));
@@ -744,35 +924,35 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     if (top_shift) {
         uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
         // the first radix pass's digit histogram comes out of k_build_keys (keys in registers there): one read of every key less
-        const SortGrid32 g32 = sort_grid32(n, sort32_variants[tn.sort32_variant]);
+        const FirstCounts fc = sort_first_counts(w.ss, tn, n, true);
         const bool counted = n > 1;
-        if (counted) HIP_TRY(hipMemsetAsync(w.spine, 0, (size_t)RADIX * g32.G * 4, st));
+        if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
         PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
                                                       (uint64_t *)nullptr, vals0, k32a, top_shift, packed_out,
-                                                      counted ? w.spine : (uint32_t *)nullptr, g32.tiles_per_wg * g32.tile, g32.G, 0xffu));
+                                                      counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, 0xffu));
         SortResult32 s32;
-        rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.spine, w.digit_tot, SA, st, &s32, tn, iota, counted);
+        rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.ss, SA, st, &s32, tn, iota, counted);
         if (rc) return rc;
         local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
         sorted32 = s32.keys;
         sr.vals = s32.vals; sr.passes = s32.passes;
         sr.keys = (s32.keys == k32a) ? w.keysA : w.keysB;      // the 8n-byte buffer that now holds the sorted 32-bit keys
     } else {
-        const SortGrid g64 = sort_grid(n, sort_variants[tn.sort_variant]);
+        const FirstCounts fc = sort_first_counts(w.ss, tn, n, false);
         const bool counted = n > 1 && key_bits > 0;
         const int nb0 = key_bits < RADIX_BITS ? key_bits : RADIX_BITS;
-        if (counted) HIP_TRY(hipMemsetAsync(w.spine, 0, (size_t)RADIX * g64.G * 4, st));
+        if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
         if (P.gram > 0)
             PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false, true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
                                                           w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
-                                                          counted ? w.spine : (uint32_t *)nullptr, g64.tiles_per_wg * g64.tile, g64.G, (1u << nb0) - 1u));
+                                                          counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, (1u << nb0) - 1u));
         else
             PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
                                                           w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
-                                                          counted ? w.spine : (uint32_t *)nullptr, g64.tiles_per_wg * g64.tile, g64.G, (1u << nb0) - 1u));
+                                                          counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, (1u << nb0) - 1u));
         // (a text of ONE byte value -- a zero-filled file -- has the same key everywhere but at its end: its passes are the identity
         // and are looked for; any other text does not pay the read-backs)
-        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.spine, w.digit_tot, SA, st, &sr, tn, iota, sigma == 1, counted);
+        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.ss, SA, st, &sr, tn, iota, sigma == 1, counted);
         if (rc) return rc;
         local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
     }
@@ -1157,7 +1337,12 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     }
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);   // reference src/saca.rs:13
     LAUNCH_CHECK(st);
-    HIP_TRY(hipStreamSynchronize(st));
+    {
+        // (synchronises the stream) a look-back that gave up means a tile scatter wrote nothing useful: never a silent wrong array
+        uint32_t gave_up = 0;
+        const int rcw = read_words(&gave_up, w.os_err, 4, st); if (rcw) return rcw;
+        if (gave_up) return SA_AMD_EINTERNAL;
+    }
     g_prof.resolve();
     g_last_stats = local;
     if (stats) *stats = local;

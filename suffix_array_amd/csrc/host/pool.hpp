@@ -1,0 +1,163 @@
+// host/pool.hpp -- process-wide pool of device blocks, streams and pinned host blocks (mutex-protected).
+// One device block = text + SA + workspace of one build, so neither repeated calls of the host-pointer entry points
+// (the contract of `saca()`, reference src/saca.rs:9-15) nor the worker threads of sa_amd_saca_batch pay hipMalloc /
+// hipFree per call; the pool retains at most SA_AMD_CACHE_MAX_BYTES (default 64 GiB of the 288 GB) and
+// sa_amd_release_cache() empties it.  Pinned blocks remember the NUMA node they were first touched on (helpers.hpp).
+#pragma once
+#include "helpers.hpp"
+
+#include <mutex>
+
+namespace sa {
+
+static size_t cache_limit()
+{
+    return (size_t)env_int("SA_AMD_CACHE_MAX_BYTES", (int64_t)64 << 30, 0, (int64_t)1 << 50);
+}
+
+// ---- pool of device blocks, streams and pinned staging buffers (process-wide, mutex-protected) ----
+struct DevBlock { int device = -1; void *p = nullptr; size_t bytes = 0; };
+struct PinBlock { void *p = nullptr; size_t bytes = 0; int node = -1; };      // node: NUMA node its pages were first touched on (-1: wherever)
+
+class ResourcePool {
+    std::mutex mu_;
+    std::vector<DevBlock> blocks_;                 // free device blocks
+    std::vector<std::pair<int, hipStream_t>> streams_;
+    std::vector<PinBlock> pinned_;
+    size_t retained_ = 0;
+
+public:
+    // a free block of `device` with at least `need` bytes (the smallest such), else a new allocation
+    int acquire(int device, size_t need, DevBlock *out)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            int best = -1;
+            for (int i = 0; i < (int)blocks_.size(); ++i)
+                if (blocks_[i].device == device && blocks_[i].bytes >= need && (best < 0 || blocks_[i].bytes < blocks_[best].bytes)) best = i;
+            if (best >= 0) {
+                *out = blocks_[best];
+                retained_ -= out->bytes;
+                blocks_.erase(blocks_.begin() + best);
+                return SA_AMD_OK;
+            }
+        }
+        // slack: a slowly growing series of texts reuses the block -- but never so much that a block which fits the cache
+        // limit is pushed over it and dropped on release (a 1 GiB text needs 57.9 GiB: with an eighth on top it was 65.1 GiB
+        // against the default 64 GiB limit, and every call of that size paid hipMalloc + hipFree)
+        size_t want = need + need / 8;
+        {
+            const size_t limit = cache_limit();
+            if (want > limit) want = need > limit ? need : limit;
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            trim(device, 0);                                         // give the pool's memory back and try the exact size
+            want = need;
+            e = hipMalloc(&p, want);
+            if (e != hipSuccess) { (void)hipGetLastError(); return hip_status(e); }
+        }
+        out->device = device; out->p = p; out->bytes = want;
+        return SA_AMD_OK;
+    }
+    void release(const DevBlock &b)
+    {
+        if (!b.p) return;
+        const size_t limit = cache_limit();
+        std::vector<DevBlock> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (b.bytes > limit) drop.push_back(b);
+            else {
+                // evict the largest blocks until the newcomer fits (it is the size the caller is working at)
+                while (retained_ + b.bytes > limit && !blocks_.empty()) {
+                    int big = 0;
+                    for (int i = 1; i < (int)blocks_.size(); ++i) if (blocks_[i].bytes > blocks_[big].bytes) big = i;
+                    retained_ -= blocks_[big].bytes;
+                    drop.push_back(blocks_[big]);
+                    blocks_.erase(blocks_.begin() + big);
+                }
+                blocks_.push_back(b);
+                retained_ += b.bytes;
+            }
+        }
+        for (auto &d : drop) (void)hipFree(d.p);
+    }
+    void trim(int device, size_t keep_bytes)                          // device < 0: all devices
+    {
+        std::vector<DevBlock> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (int i = (int)blocks_.size() - 1; i >= 0 && retained_ > keep_bytes; --i)
+                if (device < 0 || blocks_[i].device == device) {
+                    retained_ -= blocks_[i].bytes;
+                    drop.push_back(blocks_[i]);
+                    blocks_.erase(blocks_.begin() + i);
+                }
+        }
+        for (auto &d : drop) (void)hipFree(d.p);
+    }
+    int stream(int device, hipStream_t *out)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (int i = 0; i < (int)streams_.size(); ++i)
+                if (streams_[i].first == device) { *out = streams_[i].second; streams_.erase(streams_.begin() + i); return SA_AMD_OK; }
+        }
+        return hip_status(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    }
+    void release_stream(int device, hipStream_t s)
+    {
+        if (!s) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        streams_.push_back(std::make_pair(device, s));
+    }
+    // a pinned host block of at least `bytes`, first-touched on NUMA node `node` (-1: no placement).  New blocks of a node
+    // are allocated by a helper thread that runs on that node's CPUs (helpers.hpp): hipHostMalloc pins -- touches -- the
+    // pages from the allocating thread, and the default memory policy puts them on the node it runs on.
+    int pinned(size_t bytes, int node, int device, PinBlock *out)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (int i = 0; i < (int)pinned_.size(); ++i)
+                if (pinned_[i].bytes >= bytes && pinned_[i].node == node) { *out = pinned_[i]; pinned_.erase(pinned_.begin() + i); return SA_AMD_OK; }
+        }
+        void *p = nullptr;
+        hipError_t e = hipErrorUnknown;
+        auto alloc = [&]() {
+            if (device >= 0) (void)hipSetDevice(device);
+            e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        };
+        if (node >= 0) helper_pool(node).run_on_helper(alloc); else alloc();
+        if (e != hipSuccess) { (void)hipGetLastError(); return hip_status(e); }
+        out->p = p; out->bytes = bytes; out->node = node;
+        return SA_AMD_OK;
+    }
+    void release_pinned(const PinBlock &b)
+    {
+        if (!b.p) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        pinned_.push_back(b);
+    }
+    void clear()
+    {
+        std::vector<DevBlock> drop; std::vector<PinBlock> pdrop; std::vector<std::pair<int, hipStream_t>> sdrop;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            drop.swap(blocks_); pdrop.swap(pinned_); sdrop.swap(streams_);
+            retained_ = 0;
+        }
+        for (auto &d : drop) (void)hipFree(d.p);
+        for (auto &d : pdrop) (void)hipHostFree(d.p);
+        for (auto &s : sdrop) (void)hipStreamDestroy(s.second);
+    }
+};
+static ResourcePool &pool()
+{
+    static ResourcePool *p = new ResourcePool();      // intentionally never destroyed: no HIP calls during static destruction
+    return *p;
+}
+
+}  // namespace sa

@@ -3,6 +3,7 @@
 #include "../kernels/common.hpp"
 #include "../kernels/keys.hpp"
 #include "../kernels/radix_sort.hpp"
+#include "../kernels/onesweep.hpp"
 #include "../kernels/rerank.hpp"
 #include "../kernels/refine.hpp"
 #include "../kernels/isa.hpp"
@@ -21,6 +22,8 @@
 #include <thread>
 #include <vector>
 #include <chrono>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace sa {
 
@@ -122,6 +125,12 @@ struct Profiler {
     }
     bool open = false;
     void end(hipStream_t st) { if (open && !recs.empty()) (void)hipEventRecord(recs.back().b, st); open = false; }
+    ~Profiler()      // (a worker thread of sa_amd_saca_batch that profiled must not leak its events)
+    {
+        if ((long)syscall(SYS_gettid) == (long)getpid()) return;      // the main thread's copy dies at process exit: no HIP calls then
+        for (auto &r : recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
+        for (auto e : pool) if (e) (void)hipEventDestroy(e);
+    }
     void resolve()   // call after the stream has been synchronised
     {
         for (auto &r : recs) {

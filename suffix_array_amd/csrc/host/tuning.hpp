@@ -64,6 +64,9 @@ struct Tuning {
     bool no_gram_keys = false;       // SA_AMD_NO_GRAM_KEYS: never key the initial sort by ranks of g-grams
     int64_t gram_min_n = (int64_t)1 << 22;   // SA_AMD_GRAM_MIN_N: smallest text whose g-grams are looked at (measured: -4 % at 4 MiB, +5 % at 1 MiB)
     int gram_g = 0;                  // SA_AMD_GRAM_G: gram length (0 = the longest whose table fits, else 2..8, still subject to the fit)
+    bool no_onesweep = false;        // SA_AMD_NO_ONESWEEP: the three-kernel radix pass (histogram, spine, chunk-owned scatter) instead of the single-pass one
+    int onesweep_flags = 0;          // SA_AMD_ONESWEEP_FLAGS: bit 0 = next tile's keys loaded behind the stores (scheduling A/B, same result)
+    int onesweep32_items = 12;       // SA_AMD_ONESWEEP32_ITEMS: keys per thread of the single-pass scatter of (u32, u32) pairs, 8 or 12
 #ifdef SA_AMD_DIAG
     bool timing_only_initial_sort = false;     // SA_AMD_TIMING_ONLY_INITIAL_SORT (diag library only: the array is NOT finished)
 #endif
@@ -105,6 +108,9 @@ struct Tuning {
         t.no_gram_keys = env_flag("SA_AMD_NO_GRAM_KEYS");
         t.gram_min_n = env_int("SA_AMD_GRAM_MIN_N", (int64_t)1 << 22, 1, (int64_t)1 << 40);
         t.gram_g = (int)env_int("SA_AMD_GRAM_G", 0, 0, 8);
+        t.no_onesweep = env_flag("SA_AMD_NO_ONESWEEP");
+        t.onesweep_flags = (int)env_int("SA_AMD_ONESWEEP_FLAGS", 0, 0, 255);
+        t.onesweep32_items = env_int("SA_AMD_ONESWEEP32_ITEMS", 12, 8, 12) == 8 ? 8 : 12;
 #ifdef SA_AMD_DIAG
         t.timing_only_initial_sort = env_flag("SA_AMD_TIMING_ONLY_INITIAL_SORT");
 #endif

@@ -29,8 +29,14 @@ def test_device_visible():
 @pytest.mark.parametrize("count,bits", [(1, (0, 64)), (2, (0, 64)), (63, (0, 64)), (4095, (0, 64)), (4096, (0, 64)),
                                         (4097, (0, 64)), (100_000, (0, 64)), (1_000_003, (0, 64)),
                                         (300_000, (0, 24)), (300_000, (8, 40)), (300_000, (5, 62)),
-                                        (5_000_000, (0, 64))])
-def test_radix_sort_pairs(count, bits):
+                                        (5_000_000, (0, 64)),
+                                        # tile / segment geometry of the single-pass scatter (8192-pair tiles, up to 8 segments)
+                                        (8191, (0, 16)), (8192, (0, 16)), (8193, (0, 16)), (8192 * 8, (0, 24)), (8192 * 8 + 1, (0, 24)),
+                                        (8192 * 9 + 5, (3, 21)), (8192 * 17 - 1, (0, 9)), (20_000_003, (0, 40))])
+@pytest.mark.parametrize("engine", ["single-pass", "three-kernel"])
+def test_radix_sort_pairs(count, bits, engine, monkeypatch):
+    if engine == "three-kernel":
+        monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")
     rng = np.random.default_rng(count + bits[1])
     keys = rng.integers(0, 2**64, count, dtype=np.uint64)
     if count > 10:
@@ -47,8 +53,15 @@ def test_radix_sort_pairs(count, bits):
 
 
 @pytest.mark.parametrize("count,bits", [(1, (0, 32)), (3, (0, 32)), (16383, (0, 32)), (16384, (0, 32)), (16385, (0, 32)),
-                                        (100_001, (0, 32)), (2_000_003, (0, 32)), (300_000, (8, 24)), (5_000_000, (0, 32))])
-def test_radix_sort_pairs_32bit_keys(count, bits):
+                                        (100_001, (0, 32)), (2_000_003, (0, 32)), (300_000, (8, 24)), (5_000_000, (0, 32)),
+                                        (12287, (0, 16)), (12288, (0, 16)), (12289, (0, 16)), (12288 * 8 + 1, (0, 24)),
+                                        (12288 * 9 + 5, (3, 21)), (8192 * 9 + 5, (0, 32)), (30_000_001, (0, 32))])
+@pytest.mark.parametrize("engine", ["single-pass", "single-pass-8", "three-kernel"])
+def test_radix_sort_pairs_32bit_keys(count, bits, engine, monkeypatch):
+    if engine == "three-kernel":
+        monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")
+    if engine == "single-pass-8":
+        monkeypatch.setenv("SA_AMD_ONESWEEP32_ITEMS", "8")
     rng = np.random.default_rng(count + bits[1])
     keys = rng.integers(0, 2**32, count, dtype=np.uint32)
     if count > 10:
@@ -63,7 +76,10 @@ def test_radix_sort_pairs_32bit_keys(count, bits):
     assert np.array_equal(v2, vals[order]) and np.array_equal(k2, keys[order])
 
 
-def test_radix_sort_constant_and_skewed_digits():
+@pytest.mark.parametrize("engine", ["single-pass", "three-kernel"])
+def test_radix_sort_constant_and_skewed_digits(engine, monkeypatch):
+    if engine == "three-kernel":
+        monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")
     count = 777_777
     keys = np.full(count, 0x0102030405060708, dtype=np.uint64)
     keys[::1000] = 7
@@ -490,6 +506,7 @@ def test_first_round_from_sorted_keys(oracle, monkeypatch, gen, n, seed, cap):
 def test_sort_kernel_variants(oracle, monkeypatch, v64, v32):
     """the non-default tile-scatter kernel shapes of the product library (no prefetch, 512 x 16, granule 8; out-of-range
     values fall back to the default) give the same arrays"""
+    monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")            # (the shapes belong to the three-kernel pass)
     monkeypatch.setenv("SA_AMD_SORT_VARIANT", v64)
     monkeypatch.setenv("SA_AMD_SORT32_VARIANT", v32)
     for gen, n, seed in (("english", 400_000, 21), ("uniform", 300_000, 22)):
@@ -500,6 +517,26 @@ def test_sort_kernel_variants(oracle, monkeypatch, v64, v32):
             monkeypatch.delenv("SA_AMD_NO_TOP32", raising=False)
             monkeypatch.setenv(top32, "1")
             assert np.array_equal(build(text), exp)
+
+
+@pytest.mark.parametrize("engine", ["single-pass", "single-pass-8", "three-kernel"])
+def test_sort_engines_full_path(oracle, monkeypatch, engine):
+    """the single-pass tile scatter (default), its 8-keys-per-thread shape for 32-bit keys and the three-kernel pass it
+    replaced give the same arrays on every route of the pipeline (several tiles per segment: 3 MiB texts)"""
+    if engine == "three-kernel":
+        monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")
+    if engine == "single-pass-8":
+        monkeypatch.setenv("SA_AMD_ONESWEEP32_ITEMS", "8")
+    for gen, n, seed in (("english_corpus", 3_000_001, 31), ("uniform", 3_145_728, 32), ("dna", 2_999_999, 33), ("dna_repeats", 1_500_000, 34)):
+        text = getattr(corpus, gen)(n, seed)
+        exp = oracle.sais(text)
+        for switch in (None, "SA_AMD_FORCE_TOP32", "SA_AMD_NO_TOP32", "SA_AMD_FORCE_DENSE", "SA_AMD_BINNED_ISA_ALWAYS"):
+            if switch:
+                monkeypatch.setenv(switch, "1")
+            got = build(text)
+            if switch:
+                monkeypatch.delenv(switch)
+            assert np.array_equal(got, exp), (engine, gen, switch)
 
 
 def test_randomised_inputs_and_regimes(oracle, monkeypatch):
@@ -542,6 +579,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
+             "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP32_ITEMS", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
