@@ -109,7 +109,7 @@ static Workspace carve(void *base, int64_t n)
     const size_t ft_tiles = (size_t)ceil_div((int64_t)N, FT_TILE) + 1;
     w.ft_cnt = (uint32_t *)take(ft_tiles * 4);
     w.ft_head = (uint32_t *)take(ft_tiles * 4);
-    w.os_status = (unsigned long long *)take(((size_t)ceil_div((int64_t)N, OS_THREADS * 8) + 1) * RADIX * 8);
+    w.os_status = (unsigned long long *)take(((size_t)ceil_div((int64_t)N, OS_MIN_TILE) + 1) * RADIX * 8);
     w.os_err = (uint32_t *)take(256);
     w.ss.spine = w.spine; w.ss.digit_tot = w.digit_tot; w.ss.status = w.os_status; w.ss.err = w.os_err;
     w.bytes = off;
@@ -123,8 +123,15 @@ static Workspace carve(void *base, int64_t n)
 // Pass p reads its digit's counts from zone z and writes the next digit's counts -- and takes its tickets -- in zone z ^ 1,
 // which the host zeroes right before the launch.
 // ------------------------------------------------------------------------------------------
-constexpr int OS_ITEMS64 = 8;                  // 8192-pair tiles of (u64, u32)
-constexpr int OS_ITEMS32 = 12;                 // 12288-pair tiles of (u32, u32)
+// Tile shapes (threads, keys per thread, values through the keys' LDS buffer, workgroups per CU).  SA_AMD_ONESWEEP64_SHAPE /
+// SA_AMD_ONESWEEP32_SHAPE select one for A/B measurements; every shape sorts correctly.
+struct OsShape { int threads, items; bool seq; int wg_per_cu; };
+static const OsShape os_shapes64[] = { { 1024, 8, false, 1 }, { 512, 16, true, 2 }, { 512, 8, false, 2 } };
+static const OsShape os_shapes32[] = { { 1024, 12, false, 1 }, { 512, 16, true, 2 }, { 512, 12, false, 2 }, { 1024, 8, false, 1 } };
+// (measured slower at 256 MiB, profiles/r03_onesweep_shapes.txt: 1024 x 16 and larger tiles -- spills at the 128-register limit of a
+// 1024-thread workgroup --, 512 x 24 likewise; two workgroups per CU bought nothing at equal tile size)
+constexpr int N_OS_SHAPES64 = (int)(sizeof(os_shapes64) / sizeof(os_shapes64[0]));
+constexpr int N_OS_SHAPES32 = (int)(sizeof(os_shapes32) / sizeof(os_shapes32[0]));
 constexpr int OS_ZONE = 16 + RADIX * OS_NSEG;  // words
 static_assert(2 * OS_ZONE <= RADIX * SORT_MAX_WG, "both zones live in the spine slab");
 
@@ -169,12 +176,13 @@ __global__ __launch_bounds__(RADIX) void k_os_digit_totals(const uint32_t *__res
     digit_tot[threadIdx.x] = s;
 }
 
-template <typename KeyT, int ITEMS>
+template <typename KeyT, int THREADS, int ITEMS, bool SEQ>
 static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit, int end_bit,
                                const SortScratch &ss, uint32_t *final_vals, hipStream_t st, KeyT **keys_res, uint32_t **vals_res, int *passes,
                                int *skipped, const Tuning &tn, bool iota, bool may_skip, bool first_counted)
 {
-    constexpr int TILE = OS_THREADS * ITEMS;
+    constexpr int TILE = THREADS * ITEMS;
+    static_assert(TILE >= OS_MIN_TILE, "the granule slab is sized for tiles of at least OS_MIN_TILE elements");
     constexpr bool K64 = sizeof(KeyT) == 8;
     const OnesweepGeom g = onesweep_geom(count, TILE);
     uint32_t *zone[2] = { ss.spine, ss.spine + OS_ZONE };
@@ -183,7 +191,8 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
     HIP_TRY(hipMemsetAsync(ss.status, 0, (size_t)g.tiles * RADIX * 8, st));
     KeyT *kin = keys_in, *kout = keys_alt;
     uint32_t *vin = vals_in, *vout = vals_alt;
-    int grid = cu_count();
+    constexpr int WG_PER_CU = THREADS <= 512 ? 2 : 1;
+    int grid = cu_count() * WG_PER_CU;
     if (grid > g.tiles) grid = g.tiles;
     uint32_t epoch = 0;
     for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
@@ -230,7 +239,7 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         P.flags = (uint32_t)tn.onesweep_flags;
         HIP_TRY(hipMemsetAsync(zone[z ^ 1], 0, (size_t)OS_ZONE * 4, st));
         PROF(K64 ? KC_DOWNSWEEP : KC_DOWNSWEEP32, count, st,
-             hipLaunchKernelGGL((k_onesweep<ITEMS, KeyT>), dim3(grid), dim3(OS_THREADS), 0, st, (const KeyT *)kin,
+             hipLaunchKernelGGL((k_onesweep<THREADS, ITEMS, KeyT, SEQ, WG_PER_CU>), dim3(grid), dim3(THREADS), 0, st, (const KeyT *)kin,
                                 (const uint32_t *)((iota && *passes == 0) ? nullptr : vin), kout, vdst, P));
         KeyT *tk = kin; kin = kout; kout = tk;
         uint32_t *free_v = vin;                   // the values just consumed become the next scratch target
@@ -258,9 +267,16 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0; res->skipped = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
-    if (onesweep_on(ss, tn))
-        return sort_pairs_onesweep<uint64_t, OS_ITEMS64>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
-                                                         &res->keys, &res->vals, &res->passes, &res->skipped, tn, iota, may_skip, first_counted);
+    if (onesweep_on(ss, tn)) {
+#define OS_CALL64(T, I, S) sort_pairs_onesweep<uint64_t, T, I, S>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st, \
+                                                                 &res->keys, &res->vals, &res->passes, &res->skipped, tn, iota, may_skip, first_counted)
+        switch (tn.onesweep64_shape) {
+        case 1: return OS_CALL64(512, 16, true);
+        case 2: return OS_CALL64(512, 8, false);
+        default: return OS_CALL64(1024, 8, false);
+        }
+#undef OS_CALL64
+    }
     uint32_t *spine = ss.spine, *digit_tot = ss.digit_tot;
     const SortVariant &sv = sort_variants[tn.sort_variant];
     const SortGrid g = sort_grid(count, sv);
@@ -353,11 +369,15 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
     if (onesweep_on(ss, tn)) {
         int skipped = 0;
-        if (tn.onesweep32_items == 8)
-            return sort_pairs_onesweep<uint32_t, 8>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
-                                                    &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted);
-        return sort_pairs_onesweep<uint32_t, OS_ITEMS32>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
-                                                         &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted);
+#define OS_CALL32(T, I, S) sort_pairs_onesweep<uint32_t, T, I, S>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st, \
+                                                                 &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted)
+        switch (tn.onesweep32_shape) {
+        case 1: return OS_CALL32(512, 16, true);
+        case 2: return OS_CALL32(512, 12, false);
+        case 3: return OS_CALL32(1024, 8, false);
+        default: return OS_CALL32(1024, 12, false);
+        }
+#undef OS_CALL32
     }
     uint32_t *spine = ss.spine, *digit_tot = ss.digit_tot;
     const Sort32Variant &sv = sort32_variants[tn.sort32_variant];
@@ -404,7 +424,8 @@ static FirstCounts sort_first_counts(const SortScratch &ss, const Tuning &tn, in
 {
     FirstCounts f;
     if (onesweep_on(ss, tn)) {
-        const int tile = OS_THREADS * (keys32 ? (tn.onesweep32_items == 8 ? 8 : OS_ITEMS32) : OS_ITEMS64);
+        const OsShape &sh = keys32 ? os_shapes32[tn.onesweep32_shape] : os_shapes64[tn.onesweep64_shape];
+        const int tile = sh.threads * sh.items;
         const OnesweepGeom g = onesweep_geom(count, tile);
         f.counts = ss.spine + 16; f.chunk_elems = g.seg_elems; f.G = g.nseg;
         f.zero_ptr = ss.spine; f.zero_bytes = (size_t)OS_ZONE * 4;
@@ -813,7 +834,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
                         sa_amd_stats *stats)
 {
     const int64_t n = n32;
-    const Tuning tn = Tuning::from_env(N_SORT_VARIANTS, N_SORT32_VARIANTS);
+    const Tuning tn = Tuning::from_env(N_SORT_VARIANTS, N_SORT32_VARIANTS, N_OS_SHAPES64, N_OS_SHAPES32);
     const bool trace = env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 3;      // one line per refinement round on stderr
     double trace_t = now_ms();
     auto lap = [&]() { const double t = now_ms(), d = t - trace_t; trace_t = t; return d; };

@@ -65,13 +65,14 @@ struct Tuning {
     int64_t gram_min_n = (int64_t)1 << 22;   // SA_AMD_GRAM_MIN_N: smallest text whose g-grams are looked at (measured: -4 % at 4 MiB, +5 % at 1 MiB)
     int gram_g = 0;                  // SA_AMD_GRAM_G: gram length (0 = the longest whose table fits, else 2..8, still subject to the fit)
     bool no_onesweep = false;        // SA_AMD_NO_ONESWEEP: the three-kernel radix pass (histogram, spine, chunk-owned scatter) instead of the single-pass one
-    int onesweep_flags = 0;          // SA_AMD_ONESWEEP_FLAGS: bit 0 = next tile's keys loaded behind the stores (scheduling A/B, same result)
-    int onesweep32_items = 12;       // SA_AMD_ONESWEEP32_ITEMS: keys per thread of the single-pass scatter of (u32, u32) pairs, 8 or 12
+    int onesweep_flags = 0;          // SA_AMD_ONESWEEP_FLAGS: scheduling switches of the single-pass scatter (kernels/onesweep.hpp, OnesweepPass::flags), same result
+    int onesweep64_shape = 0;        // SA_AMD_ONESWEEP64_SHAPE / SA_AMD_ONESWEEP32_SHAPE: tile shape of the single-pass scatter (host/pipeline.hpp,
+    int onesweep32_shape = 0;        //   os_shapes64 / os_shapes32; out of range = default)
 #ifdef SA_AMD_DIAG
     bool timing_only_initial_sort = false;     // SA_AMD_TIMING_ONLY_INITIAL_SORT (diag library only: the array is NOT finished)
 #endif
 
-    static Tuning from_env(int n_sort_variants, int n_sort32_variants)
+    static Tuning from_env(int n_sort_variants, int n_sort32_variants, int n_os64 = 1, int n_os32 = 1)
     {
         Tuning t;
         t.sort_variant = (int)env_int("SA_AMD_SORT_VARIANT", 0, 0, 1 << 20);
@@ -110,7 +111,10 @@ struct Tuning {
         t.gram_g = (int)env_int("SA_AMD_GRAM_G", 0, 0, 8);
         t.no_onesweep = env_flag("SA_AMD_NO_ONESWEEP");
         t.onesweep_flags = (int)env_int("SA_AMD_ONESWEEP_FLAGS", 0, 0, 255);
-        t.onesweep32_items = env_int("SA_AMD_ONESWEEP32_ITEMS", 12, 8, 12) == 8 ? 8 : 12;
+        t.onesweep64_shape = (int)env_int("SA_AMD_ONESWEEP64_SHAPE", 0, 0, 1 << 20);
+        if (t.onesweep64_shape >= n_os64) t.onesweep64_shape = 0;
+        t.onesweep32_shape = (int)env_int("SA_AMD_ONESWEEP32_SHAPE", 0, 0, 1 << 20);
+        if (t.onesweep32_shape >= n_os32) t.onesweep32_shape = 0;
 #ifdef SA_AMD_DIAG
         t.timing_only_initial_sort = env_flag("SA_AMD_TIMING_ONLY_INITIAL_SORT");
 #endif

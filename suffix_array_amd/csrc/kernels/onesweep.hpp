@@ -20,8 +20,8 @@
 //   * Look-back: per tile and digit one 8-byte granule {epoch << 2 | flag, value} written by ONE agent-scope store and
 //     polled with agent-scope loads (no fences: the data is its own flag, MI355X guide R2).  flag 1 = the tile's own count
 //     (published right after the ranking), flag 2 = the inclusive prefix of the segment up to and including the tile.
-//     A tile sums its predecessors' counts backwards until it meets an inclusive prefix; the workgroup reads the granules
-//     of the 16 tiles in front of it in one go and the loads stay in flight while the tile's keys and values are staged.
+//     A tile sums its predecessors' counts backwards until it meets an inclusive prefix, four predecessors per round trip;
+//     the first look comes after the tile has been staged in LDS, when its neighbours' counts have had time to become visible.
 //     A tile only ever waits for tiles with smaller tickets, which are held by running workgroups: no co-residency
 //     assumption, no deadlock when another stream shares the device.
 // Algorithmic traffic per pass: sizeof(key) + 4 read, the same written, + 16 bytes of granules per 256 / TILE elements.
@@ -32,9 +32,8 @@
 namespace sa {
 
 constexpr int OS_NSEG = 8;           // segments per pass (one per XCD; fewer when there are fewer tiles)
-constexpr int OS_LB = 4;             // granule loads per thread and look-back round
-constexpr int OS_LB_ROWS = 16;       // predecessors the whole workgroup reads in one go (OS_LB per thread, four threads per digit)
-constexpr int OS_THREADS = 1024;
+constexpr int OS_LB = 4;             // predecessors read speculatively per look-back round
+constexpr int OS_MIN_TILE = 4096;    // smallest tile of any shape in use (the granule slab is sized by it)
 
 __device__ __forceinline__ unsigned os_xcc_id()
 {
@@ -54,30 +53,35 @@ struct OnesweepPass {
     uint32_t dmask, dmask_next;
     int nseg, tiles_per_seg, tiles;
     uint32_t epoch;                 // pass number + 1
-    uint32_t flags;                 // bit 0: load the next tile's keys behind this tile's stores, not in front of them (A/B)
+    uint32_t flags;                 // bit 0: look at the predecessors' granules before the staging, not after (scheduling A/B, same
+                                    // result); bit 7 (diagnostic library only): phase stamps
 };
 
-template <int ITEMS, typename KeyT>
-__global__ __launch_bounds__(OS_THREADS) void k_onesweep(const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                          KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, OnesweepPass P)
+// THREADS x ITEMS elements per tile.  SEQ = false: keys and values are staged in LDS side by side (one workgroup per CU at the
+// sizes in use); SEQ = true: the values go through the keys' buffer once the keys are out, which leaves room for TWO
+// workgroups per CU -- while one waits (look-back, barriers, the ranking's ALU work) the other one's loads and stores flow.
+template <int THREADS, int ITEMS, typename KeyT, bool SEQ, int WG_PER_CU>
+__global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep(
+    const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+    OnesweepPass P)
 {
-    constexpr int THREADS = OS_THREADS;
     constexpr int TILE = THREADS * ITEMS;
     constexpr int NWAVES = THREADS / WAVE;
     constexpr int WAVE_ELEMS = WAVE * ITEMS;
+    static_assert(THREADS >= RADIX, "thread d owns digit d");
     static_assert(TILE < 65536, "16-bit tile-local counters");
+    static_assert(ITEMS % 4 == 0, "digits are packed four to a register, tile positions two");
     __shared__ __attribute__((aligned(16))) KeyT lds_k[TILE];
-    __shared__ __attribute__((aligned(16))) uint32_t lds_v[TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_v_sep[SEQ ? 1 : TILE];
     __shared__ uint16_t wave_hist[NWAVES][RADIX];
     __shared__ uint32_t digit_base[RADIX];     // first stage slot of digit d
     __shared__ uint32_t goff[RADIX];           // global position = goff + stage slot
-    __shared__ uint32_t seg0[RADIX];           // next pass: segment of the digit run's first element ...
-    __shared__ uint32_t bnd[RADIX];            // ... and the first global position that belongs to the segment after it
-    __shared__ uint32_t segbase[RADIX];        // where the current segment's run of digit d starts
+    __shared__ uint32_t bnd[RADIX];            // next pass: first global position behind the segment the digit run starts in ...
+    __shared__ uint8_t seg0[RADIX];            // ... and that segment
     __shared__ uint32_t hist2[RADIX * OS_NSEG];
-    __shared__ unsigned long long lbx[OS_LB_ROWS][RADIX];   // the granules of the last OS_LB_ROWS tiles, as the look-back found them
     __shared__ uint32_t scan_lds[NWAVES + 1];
     __shared__ int s_tile, s_seg;
+    uint32_t *lds_v = SEQ ? (uint32_t *)lds_k : lds_v_sep;
 
     const int tid = threadIdx.x, l = lane_id(), w = wave_id();
     const unsigned xcc = os_xcc_id();
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_onesweep(const KeyT *__restrict_
     for (int i = tid; i < RADIX * OS_NSEG; i += THREADS) hist2[i] = 0;
     int cand = 0;                              // index into my list of candidate segments: my XCD's first, then all
     int cur_seg = -1;
+    uint32_t my_segbase = 0;                   // thread d: where the current segment's run of digit d starts
     uint16_t *my_hist = wave_hist[w];
     const int e0 = w * WAVE_ELEMS + l;
     const uint32_t seg_elems = (uint32_t)P.tiles_per_seg * (uint32_t)TILE;
@@ -122,36 +127,36 @@ __global__ __launch_bounds__(OS_THREADS) void k_onesweep(const KeyT *__restrict_
         *sg = -1;
         return -1;
     };
-    // Tickets are taken ONE TILE AHEAD and not waited for: the atomic for the tile after the next is issued in the middle of
-    // a tile and looked at in the middle of the following one.  Every workgroup does so at the same point of its loop, so
-    // ticket order is still the order in which tiles start.
-    // The NEXT tile's keys are loaded (into the key registers, dead once the tile is staged in LDS) before this tile's
-    // stores are issued: they travel while the stores drain and are there when the ranking of the next tile begins.
-    int pend_s = -1, pend_k = 0x7fffffff;
-    auto ask = [&]() {                                             // tid 0: issue the atomic, do not wait
-        pend_s = cand < own + nseg ? cand_seg(cand) : -1;
-        pend_k = (pend_s >= 0 && seg_tiles(pend_s) > 0) ? (int)atomicAdd(&P.tickets[pend_s], 1u) : 0x7fffffff;
-    };
-    auto answer = [&](int *sg) -> int {                            // tid 0: the tile of the pending atomic (or the next one there is)
-        if (pend_s >= 0 && pend_k < seg_tiles(pend_s)) { *sg = pend_s; return pend_s * P.tiles_per_seg + pend_k; }
-        if (pend_s >= 0) ++cand;
-        return take_ticket(sg);
-    };
-    KeyT key[ITEMS];
-    auto load_keys = [&](int tt) {
-        const int64_t b = (int64_t)tt * TILE;
-        const int vd = (P.n - b) >= TILE ? TILE : (int)(P.n - b);
+    // Tickets are taken ONE TILE AHEAD and not waited for: the atomic for the next tile is issued at the top of a tile (its
+    // round trip hides behind the tile's key loads) and looked at when the tile is done.  Every workgroup does so at the
+    // same point of its loop, so ticket order is still the order in which tiles start.
+    int next_t = -1, next_seg = -1, pend_s = -1, pend_k = 0x7fffffff;
+    if (tid == 0) next_t = take_ticket(&next_seg);
+    for (;;) {
+        if (tid == 0) { s_tile = next_t; s_seg = next_seg; }
+        __syncthreads();                       // (also: the previous tile's LDS stage is free)
+        const int t = s_tile, seg = s_seg;
+        if (t < 0) break;
+        if (tid == 0) {
+            pend_s = cand < own + nseg ? cand_seg(cand) : -1;
+            pend_k = (pend_s >= 0 && seg_tiles(pend_s) > 0) ? (int)atomicAdd(&P.tickets[pend_s], 1u) : 0x7fffffff;
+        }
+        const int seg_first = seg * P.tiles_per_seg;
+        // (opaque copies: the per-item offsets derived from them are recomputed per tile instead of being hoisted out of the
+        // tile loop into forty registers that then spill)
+        int e0v = e0, tidv = tid;
+        asm volatile("" : "+v"(e0v), "+v"(tidv));
+        const int64_t base = (int64_t)t * TILE;
+        const int valid = (P.n - base) >= TILE ? TILE : (int)(P.n - base);
+        const bool full = valid == TILE;
+        KeyT key[ITEMS];
+        uint32_t val[ITEMS], pp[ITEMS / 2];    // pp: tile positions (< 65536), two to a register
+#define OS_POS(j) ((pp[(j) >> 1] >> (16 * ((j) & 1))) & 0xffffu)
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const int e = e0 + j * WAVE;
-            key[j] = (vd == TILE || e < vd) ? keys_in[b + e] : (KeyT)~(KeyT)0;
+            const int e = e0v + j * WAVE;
+            key[j] = (full || e < valid) ? keys_in[base + e] : (KeyT)~(KeyT)0;
         }
-    };
-    if (tid == 0) { int sg; s_tile = take_ticket(&sg); s_seg = sg; ask(); }
-    __syncthreads();
-    int t = s_tile, seg = s_seg;
-    if (t >= 0) load_keys(t);
-    while (t >= 0) {
         if (seg != cur_seg) {                  // (uniform) where do this segment's digit runs start?
             uint32_t tot = 0, below = 0;
             if (tid < RADIX) {
@@ -163,22 +168,16 @@ __global__ __launch_bounds__(OS_THREADS) void k_onesweep(const KeyT *__restrict_
             }
             uint32_t all;
             const uint32_t dstart = block_excl_sum<THREADS>(tot, scan_lds, &all);
-            if (tid < RADIX) segbase[tid] = dstart + below;
+            my_segbase = dstart + below;
             cur_seg = seg;
-            __syncthreads();
         }
-        const int seg_first = seg * P.tiles_per_seg;
-        const int64_t base = (int64_t)t * TILE;
-        const int valid = (P.n - base) >= TILE ? TILE : (int)(P.n - base);
-        const bool full = valid == TILE;
-        uint32_t val[ITEMS], pos[ITEMS];
         for (int i = tid; i < NWAVES * RADIX / 2; i += THREADS) ((uint32_t *)&wave_hist[0][0])[i] = 0;
-        lds_barrier();                         // (the keys' loads are waited for by their first use, not here)
-        stamp(0);      // segment switch, counters zeroed, barrier
+        __syncthreads();
+        stamp(0);      // ticket, key loads issued, segment switch, counters zeroed, barrier (waits for the keys)
         // ---- rank inside the wave: lanes with my digit below me (8 ballots + mbcnt), wave totals in LDS ----
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const bool ok = full || (e0 + j * WAVE) < valid;
+            const bool ok = full || (e0v + j * WAVE) < valid;
             const uint32_t d = digit_of(key[j], P.shift, P.dmask);
             const uint64_t okm = __ballot(ok);
             uint32_t xlo = ~(uint32_t)okm, xhi = ~(uint32_t)(okm >> 32);
@@ -193,21 +192,25 @@ __global__ __launch_bounds__(OS_THREADS) void k_onesweep(const KeyT *__restrict_
             const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
             const uint32_t prior = my_hist[d];
             if (ok && below == 0) my_hist[d] = (uint16_t)(prior + (uint32_t)(__popc(mlo) + __popc(mhi)));
-            pos[j] = prior + below;
+            if ((j & 1) == 0) pp[j >> 1] = prior + below; else pp[j >> 1] |= (prior + below) << 16;
             __builtin_amdgcn_sched_barrier(0);
         }
-        stamp(1);      // ranking (includes the wait for the keys)
+        stamp(1);      // ranking
         // the values are loaded only now (registers), and stay in flight across the LDS-only barriers below
+        // (SEQ: later still, when the keys' registers are free)
+        auto load_vals = [&]() {
         if (vals_in) {
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
-                const int e = e0 + j * WAVE;
+                const int e = e0v + j * WAVE;
                 val[j] = (full || e < valid) ? vals_in[base + e] : 0u;
             }
         } else {                               // no values array: the value is the index itself
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) val[j] = (uint32_t)(base + e0 + j * WAVE);
+            for (int j = 0; j < ITEMS; ++j) val[j] = (uint32_t)(base + e0v + j * WAVE);
         }
+        };
+        if (!SEQ) load_vals();
         lds_barrier();
         stamp(2);      // value loads issued + barrier
         // ---- thread d: per-wave offsets, the tile's count of digit d ----
@@ -220,72 +223,79 @@ __global__ __launch_bounds__(OS_THREADS) void k_onesweep(const KeyT *__restrict_
                 tot += cnt;
             }
         }
-        // publish the count, start the look-back: the whole workgroup reads the granules of the OS_LB_ROWS tiles in front of
-        // this one in one go (thread (q, d) takes rows q, q + 4, q + 8, q + 12 of digit d: 32 contiguous KiB); the loads stay in
-        // flight while the tile is staged.  With 32 tiles of a segment in flight on an XCD the nearest inclusive prefix is
-        // 10 to 20 tiles back: a walk of four tiles per round trip spent a fifth of the tile's time here.
+        // publish the count, start the look-back: OS_LB predecessors read in one go, consumed after the key staging
         unsigned long long lb[OS_LB];
-        const bool first_of_seg = t == seg_first;
-        if (tid < RADIX && !first_of_seg)
+        const bool walk = tid < RADIX && t > seg_first;
+        // The first look at the predecessors comes only when the tile is staged: a granule published a microsecond ago is not
+        // visible yet, and 256 threads per workgroup polling for it cost more than the round trip they tried to hide (measured:
+        // 256 MiB random text, four 32-bit passes 5.56 -> 5.37 ms; C3-iid, seven 64-bit passes 13.6 -> 12.9 ms).  flags bit 0: look early (A/B)
+        const bool late_look = (P.flags & 1u) == 0;
+        if (walk) {
             __hip_atomic_store(status + (int64_t)t * RADIX + tid, tagA | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!late_look) {
 #pragma unroll
-        for (int q = 0; q < OS_LB; ++q) {
-            const int k = t - 1 - (q * 4 + (tid >> 8));
-            lb[q] = k >= seg_first ? __hip_atomic_load(status + (int64_t)k * RADIX + (tid & 255), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                for (int q = 0; q < OS_LB; ++q) {
+                    const int k = t - 1 - q;
+                    lb[q] = k >= seg_first ? __hip_atomic_load(status + (int64_t)k * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+            }
         }
         uint32_t tile_total;
         const uint32_t dbase = block_excl_sum_b<THREADS, true>(tot, scan_lds, &tile_total);
         if (tid < RADIX) digit_base[tid] = dbase;
         lds_barrier();
         stamp(3);      // digit totals, count published, look-back loads issued, tile prefix (3 barriers)
-        // ---- keys and values: stage in sorted order ----
+        // ---- keys (and, side by side, values): stage in sorted order ----
+        uint32_t dpack[SEQ ? ITEMS / 4 : 1];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const uint32_t d = digit_of(key[j], P.shift, P.dmask);
-            pos[j] += digit_base[d] + my_hist[d];
-            if (full || (e0 + j * WAVE) < valid) lds_k[pos[j]] = key[j];
+            const uint32_t ps = OS_POS(j) + digit_base[d] + my_hist[d];
+            if ((j & 1) == 0) pp[j >> 1] = (pp[j >> 1] & 0xffff0000u) | ps; else pp[j >> 1] = (pp[j >> 1] & 0xffffu) | (ps << 16);
+            if (full || (e0v + j * WAVE) < valid) lds_k[ps] = key[j];
         }
-        // (the values second: their loads -- and, in the look-back waves, the granule loads behind them -- have had the time of
-        // the key staging to arrive)
+        if (!SEQ) {
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
-            if (full || (e0 + j * WAVE) < valid) lds_v[pos[j]] = val[j];
-        stamp(4);      // keys and values staged in LDS (includes the wait for the values)
-        // ---- tid 0: which tile comes next (the answer of the atomic issued a tile ago), and ask for the one after it ----
-        if (tid == 0) { int sg; s_tile = answer(&sg); s_seg = sg; }
-        // ---- the granules go to LDS, thread d sums its digit's column backwards until it meets an inclusive prefix ----
+            for (int j = 0; j < ITEMS; ++j)
+                if (full || (e0v + j * WAVE) < valid) lds_v[OS_POS(j)] = val[j];
+        } else load_vals();                    // (the keys' registers are free: the values travel while the keys go out)
+        if (walk && late_look) {
 #pragma unroll
-        for (int q = 0; q < OS_LB; ++q) lbx[q * 4 + (tid >> 8)][tid & 255] = lb[q];
-        lds_barrier();
+            for (int q = 0; q < OS_LB; ++q) {
+                const int k = t - 1 - q;
+                lb[q] = k >= seg_first ? __hip_atomic_load(status + (int64_t)k * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+        }
+        stamp(4);      // staged in LDS
+        // ---- thread d: finish the look-back ----
         if (tid < RADIX) {
-            uint32_t g = segbase[tid];                              // (first tile of its segment: nothing in front)
-            if (!first_of_seg) {
+            uint32_t g = my_segbase;                                // (first tile of its segment: nothing in front)
+            if (walk) {
                 uint32_t acc = 0;
+                int k = t - 1;
                 bool done = false;
                 unsigned spins = 0;
-                // a granule that was not there yet when the workgroup looked is polled by its digit's thread
-                auto settle = [&](unsigned long long x, int k) -> bool {          // true: inclusive prefix met
-                    for (;;) {
-                        const unsigned long long tg = x & 0xffffffff00000000ull;
-                        if (tg == tagI) { acc += (uint32_t)x; return true; }
-                        if (tg == tagA) { acc += (uint32_t)x; return false; }
-                        if (++spins > (1u << 22)) { atomicAdd(P.err, 1u); return true; }
-                        __builtin_amdgcn_s_sleep(1);
-                        x = __hip_atomic_load(status + (int64_t)k * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (!done) {
+#pragma unroll
+                    for (int q = 0; q < OS_LB; ++q) {
+                        if (done || k - q < seg_first) break;
+                        unsigned long long x = lb[q];
+                        for (;;) {
+                            const unsigned long long tg = x & 0xffffffff00000000ull;
+                            if (tg == tagI) { acc += (uint32_t)x; done = true; break; }
+                            if (tg == tagA) { acc += (uint32_t)x; break; }
+                            if (++spins > (1u << 22)) { atomicAdd(P.err, 1u); done = true; break; }
+                            __builtin_amdgcn_s_sleep(2);
+                            x = __hip_atomic_load(status + (int64_t)(k - q) * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
-                };
-                int k = t - 1;
-                for (int r = 0; r < OS_LB_ROWS && !done && k >= seg_first; ++r, --k) done = settle(lbx[r][tid], k);
-                while (!done) {                                     // (rare: further back, four tiles per round trip)
-                    if (k < seg_first) { atomicAdd(P.err, 1u); break; }          // (cannot happen: the segment's first tile publishes an inclusive prefix)
-                    unsigned long long y[OS_LB];
-#pragma unroll
-                    for (int q = 0; q < OS_LB; ++q)
-                        y[q] = k - q >= seg_first ? __hip_atomic_load(status + (int64_t)(k - q) * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-#pragma unroll
-                    for (int q = 0; q < OS_LB; ++q)
-                        if (!done && k - q >= seg_first) done = settle(y[q], k - q);
                     k -= OS_LB;
+                    if (!done) {
+                        if (k < seg_first) { atomicAdd(P.err, 1u); break; }      // (cannot happen: the segment's first tile publishes an inclusive prefix)
+#pragma unroll
+                        for (int q = 0; q < OS_LB; ++q)
+                            lb[q] = k - q >= seg_first ? __hip_atomic_load(status + (int64_t)(k - q) * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    }
                 }
                 g = acc;                                            // (the inclusive prefix the walk ended on carries the segment's start)
             }
@@ -293,32 +303,30 @@ __global__ __launch_bounds__(OS_THREADS) void k_onesweep(const KeyT *__restrict_
             goff[tid] = g - dbase;
             if (count_next) {
                 const uint32_t s0 = g / seg_elems;
-                seg0[tid] = s0;
+                seg0[tid] = (uint8_t)s0;
                 bnd[tid] = (s0 + 1u) * seg_elems;
             }
         }
-        // (only now: the atomic's round trip must not sit in front of the look-back's loads in wave 0's memory counter)
-        if (tid == 0) ask();
-        lds_barrier();
-        stamp(5);      // next ticket, look-back finished, barrier
-        const int nt = s_tile, nsg = s_seg;
-        if (nt >= 0 && !(P.flags & 1u)) load_keys(nt);            // in flight during the stores below
+        __syncthreads();
+        stamp(5);      // look-back finished, barrier
         // ---- LDS -> global, digit runs coalesced; the next pass's digit is counted on the way ----
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const int idx = tid + j * THREADS;
+            const int idx = tidv + j * THREADS;
             const bool ok = full || idx < valid;
             KeyT kx = 0;
             uint32_t d = 0, gp = 0;
+            if (SEQ && (j & 3) == 0) dpack[j >> 2] = 0;
             if (ok) {
                 kx = lds_k[idx];
                 d = digit_of(kx, P.shift, P.dmask);
                 gp = goff[d] + (uint32_t)idx;
                 keys_out[gp] = kx;
-                vals_out[gp] = lds_v[idx];
+                if (!SEQ) vals_out[gp] = lds_v[idx];
+                else dpack[j >> 2] |= d << (8 * (j & 3));
             }
             if (count_next) {
-                const uint32_t slot = ok ? digit_of(kx, P.shift_next, P.dmask_next) * OS_NSEG + seg0[d] + (gp >= bnd[d] ? 1u : 0u) : 0u;
+                const uint32_t slot = ok ? digit_of(kx, P.shift_next, P.dmask_next) * OS_NSEG + (uint32_t)seg0[d] + (gp >= bnd[d] ? 1u : 0u) : 0u;
                 const uint64_t act = __ballot(ok);
                 const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
                 // one (digit, segment) for the whole wave (constant high digits, runs): one add, not 64 on one address
@@ -327,13 +335,30 @@ __global__ __launch_bounds__(OS_THREADS) void k_onesweep(const KeyT *__restrict_
                     if (act && l == 0) atomicAdd(&hist2[f], (uint32_t)__popcll(act));
                 } else if (ok) atomicAdd(&hist2[slot], 1u);
             }
-            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (four items' LDS reads in flight at a time: the next tile's keys hold ITEMS registers)
         }
-        stamp(6);      // LDS -> global
-        lds_barrier();                         // the LDS stage is free (s_tile / s_seg are rewritten two barriers from here)
-        if (nt >= 0 && (P.flags & 1u)) load_keys(nt);             // (A/B: the keys only behind the stores)
-        stamp(7);      // barrier + next tile's key loads issued
-        t = nt; seg = nsg;
+        stamp(6);      // keys (and values) LDS -> global
+        if (SEQ) {
+            // ---- the values through the same stage ----
+            lds_barrier();                     // every key has been read
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (full || (e0v + j * WAVE) < valid) lds_v[OS_POS(j)] = val[j];
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int idx = tidv + j * THREADS;
+                if (full || idx < valid) {
+                    const uint32_t d = (dpack[j >> 2] >> (8 * (j & 3))) & 255u;
+                    vals_out[goff[d] + (uint32_t)idx] = lds_v[idx];
+                }
+            }
+        }
+        stamp(7);      // values through the stage (SEQ)
+#undef OS_POS
+        if (tid == 0) {                        // the ticket asked for at the top of this tile
+            if (pend_s >= 0 && pend_k < seg_tiles(pend_s)) { next_t = pend_s * P.tiles_per_seg + pend_k; next_seg = pend_s; }
+            else { if (pend_s >= 0) ++cand; next_t = take_ticket(&next_seg); }
+        }
     }
     // ---- the next pass's counts: [digit][segment] ----
     if (count_next) {

@@ -33,10 +33,12 @@ def test_device_visible():
                                         # tile / segment geometry of the single-pass scatter (8192-pair tiles, up to 8 segments)
                                         (8191, (0, 16)), (8192, (0, 16)), (8193, (0, 16)), (8192 * 8, (0, 24)), (8192 * 8 + 1, (0, 24)),
                                         (8192 * 9 + 5, (3, 21)), (8192 * 17 - 1, (0, 9)), (20_000_003, (0, 40))])
-@pytest.mark.parametrize("engine", ["single-pass", "three-kernel"])
+@pytest.mark.parametrize("engine", ["single-pass", "shape1", "shape2", "three-kernel"])
 def test_radix_sort_pairs(count, bits, engine, monkeypatch):
     if engine == "three-kernel":
         monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")
+    if engine.startswith("shape"):
+        monkeypatch.setenv("SA_AMD_ONESWEEP64_SHAPE", engine[5:])
     rng = np.random.default_rng(count + bits[1])
     keys = rng.integers(0, 2**64, count, dtype=np.uint64)
     if count > 10:
@@ -61,7 +63,7 @@ def test_radix_sort_pairs_32bit_keys(count, bits, engine, monkeypatch):
     if engine == "three-kernel":
         monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")
     if engine == "single-pass-8":
-        monkeypatch.setenv("SA_AMD_ONESWEEP32_ITEMS", "8")
+        monkeypatch.setenv("SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "8")
     rng = np.random.default_rng(count + bits[1])
     keys = rng.integers(0, 2**32, count, dtype=np.uint32)
     if count > 10:
@@ -526,7 +528,7 @@ def test_sort_engines_full_path(oracle, monkeypatch, engine):
     if engine == "three-kernel":
         monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")
     if engine == "single-pass-8":
-        monkeypatch.setenv("SA_AMD_ONESWEEP32_ITEMS", "8")
+        monkeypatch.setenv("SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "8")
     for gen, n, seed in (("english_corpus", 3_000_001, 31), ("uniform", 3_145_728, 32), ("dna", 2_999_999, 33), ("dna_repeats", 1_500_000, 34)):
         text = getattr(corpus, gen)(n, seed)
         exp = oracle.sais(text)
@@ -579,7 +581,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP32_ITEMS", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS",
+             "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 

@@ -12,7 +12,7 @@
 //   mode 4  = 1 with the offsets coming from a real decoupled look-back (8-byte {tag, value} granules, agent scope)
 //   mode 5  = 2 with the look-back inside each segment (segment bases known beforehand)
 //   build:  hipcc -O3 --offload-arch=gfx950 -o tools/bin/scatter_probe tools/scatter_probe.hip
-//   run:    tools/bin/scatter_probe [log2 n = 28] [key bytes = 8] [items per thread = 8] [skew = 0]
+//   run:    tools/bin/scatter_probe [log2 n = 28] [key bytes = 8] [items per thread = 8] [skew = 0] [no values = 0]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -62,7 +62,7 @@ struct Params {
     uint32_t *tickets;         // [0] global ticket, [16 * (1 + s)] ticket of segment s
     uint32_t *err;
     int64_t n;
-    int tile, tiles, mode, nseg, tiles_per_seg, tiles_per_wg, epoch;
+    int tile, tiles, mode, nseg, tiles_per_seg, tiles_per_wg, epoch, novals;
 };
 
 template <typename KeyT, int ITEMS>
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(THREADS) void k_scatter(const KeyT *__restrict__ ki
                     gp = goff[lo] + (uint32_t)e;
                 }
                 kout[gp] = key[j];
-                vout[gp] = (uint32_t)(base + e);
+                if (!P.novals) vout[gp] = (uint32_t)(base + e);
             }
         }
         __syncthreads();
@@ -187,10 +187,11 @@ int main(int argc, char **argv)
     const int kbytes = argc > 2 ? atoi(argv[2]) : 8;
     const int items = argc > 3 ? atoi(argv[3]) : 8;
     const int skew = argc > 4 ? atoi(argv[4]) : 0;
+    const int novals = argc > 5 ? atoi(argv[5]) : 0;      // 1: one stream only (packed (key, value) pairs as one 8-byte word)
     const int64_t n = (int64_t)1 << lg;
     const int tile = THREADS * items;
     const int tiles = (int)((n + tile - 1) / tile);
-    printf("scatter probe: n = 2^%d, %d-byte keys + 4-byte values, tile %d (%d tiles), %s digits\n", lg, kbytes, tile, tiles, skew ? "skewed" : "uniform");
+    printf("scatter probe: n = 2^%d, %d-byte keys%s, tile %d (%d tiles), %s digits\n", lg, kbytes, novals ? ", no values" : " + 4-byte values", tile, tiles, skew ? "skewed" : "uniform");
     void *kin, *kout; uint32_t *vout, *counts, *offs, *segbase, *tickets, *err; unsigned long long *status;
     CK(hipMalloc(&kin, (size_t)n * kbytes)); CK(hipMalloc(&kout, (size_t)n * kbytes)); CK(hipMalloc(&vout, (size_t)n * 4));
     CK(hipMalloc(&counts, (size_t)tiles * RADIX * 4)); CK(hipMalloc(&offs, (size_t)tiles * RADIX * 4));
@@ -211,7 +212,7 @@ int main(int argc, char **argv)
     CK(hipMemcpy(offs, ho.data(), ho.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     int epoch = 0;
-    const double bytes = (double)n * (2.0 * kbytes + 4.0);
+    const double bytes = (double)n * (2.0 * kbytes + (novals ? 0.0 : 4.0));
     struct Cfg { int mode, wgs, nseg; const char *name; };
     const Cfg cfgs[] = {
         { 3, 256, 0, "sequential stores (ceiling)            " },
@@ -226,7 +227,7 @@ int main(int argc, char **argv)
     for (const Cfg &c : cfgs) {
         Params P;
         P.counts = counts; P.offs = offs; P.segbase = segbase; P.status = status; P.tickets = tickets; P.err = err;
-        P.n = n; P.tile = tile; P.tiles = tiles; P.mode = c.mode; P.nseg = c.nseg ? c.nseg : 1;
+        P.n = n; P.tile = tile; P.tiles = tiles; P.mode = c.mode; P.nseg = c.nseg ? c.nseg : 1; P.novals = novals;
         P.tiles_per_seg = (tiles + P.nseg - 1) / P.nseg;
         P.tiles_per_wg = (tiles + c.wgs - 1) / c.wgs;
         if (c.mode >= 4) {
@@ -246,6 +247,7 @@ int main(int argc, char **argv)
             else if (kbytes == 4 && items == 8) hipLaunchKernelGGL((k_scatter<uint32_t, 8>), dim3(c.wgs), dim3(THREADS), 0, 0, (const uint32_t *)kin, (uint32_t *)kout, vout, P);
             else if (kbytes == 4 && items == 12) hipLaunchKernelGGL((k_scatter<uint32_t, 12>), dim3(c.wgs), dim3(THREADS), 0, 0, (const uint32_t *)kin, (uint32_t *)kout, vout, P);
             else if (kbytes == 4 && items == 16) hipLaunchKernelGGL((k_scatter<uint32_t, 16>), dim3(c.wgs), dim3(THREADS), 0, 0, (const uint32_t *)kin, (uint32_t *)kout, vout, P);
+            else if (kbytes == 8 && items == 12) hipLaunchKernelGGL((k_scatter<uint64_t, 12>), dim3(c.wgs), dim3(THREADS), 0, 0, (const uint64_t *)kin, (uint64_t *)kout, vout, P);
             else if (kbytes == 8 && items == 4) hipLaunchKernelGGL((k_scatter<uint64_t, 4>), dim3(c.wgs), dim3(THREADS), 0, 0, (const uint64_t *)kin, (uint64_t *)kout, vout, P);
             else { fprintf(stderr, "unsupported key bytes / items\n"); return 2; }
             CK(hipEventRecord(e1, 0));
@@ -263,13 +265,14 @@ int main(int argc, char **argv)
         std::vector<uint32_t> a((size_t)1 << 20), b((size_t)1 << 20);
         CK(hipMemcpy(a.data(), vout, a.size() * 4, hipMemcpyDeviceToHost));
         Params P; P.counts = counts; P.offs = offs; P.segbase = segbase; P.status = status; P.tickets = tickets; P.err = err;
-        P.n = n; P.tile = tile; P.tiles = tiles; P.mode = 1; P.nseg = 1; P.tiles_per_seg = tiles; P.tiles_per_wg = (tiles + 255) / 256; P.epoch = ++epoch;
+        P.n = n; P.tile = tile; P.tiles = tiles; P.mode = 1; P.nseg = 1; P.novals = 0; P.tiles_per_seg = tiles; P.tiles_per_wg = (tiles + 255) / 256; P.epoch = ++epoch;
         CK(hipMemsetAsync(tickets, 0, 16 * (1 + NSEG_MAX) * 4, 0));
         CK(hipMemsetAsync(vout, 0, (size_t)n * 4, 0));
         if (kbytes == 8 && items == 8) hipLaunchKernelGGL((k_scatter<uint64_t, 8>), dim3(256), dim3(THREADS), 0, 0, (const uint64_t *)kin, (uint64_t *)kout, vout, P);
         else if (kbytes == 4 && items == 8) hipLaunchKernelGGL((k_scatter<uint32_t, 8>), dim3(256), dim3(THREADS), 0, 0, (const uint32_t *)kin, (uint32_t *)kout, vout, P);
         else if (kbytes == 4 && items == 12) hipLaunchKernelGGL((k_scatter<uint32_t, 12>), dim3(256), dim3(THREADS), 0, 0, (const uint32_t *)kin, (uint32_t *)kout, vout, P);
         else if (kbytes == 4 && items == 16) hipLaunchKernelGGL((k_scatter<uint32_t, 16>), dim3(256), dim3(THREADS), 0, 0, (const uint32_t *)kin, (uint32_t *)kout, vout, P);
+        else if (kbytes == 8 && items == 12) hipLaunchKernelGGL((k_scatter<uint64_t, 12>), dim3(256), dim3(THREADS), 0, 0, (const uint64_t *)kin, (uint64_t *)kout, vout, P);
         else hipLaunchKernelGGL((k_scatter<uint64_t, 4>), dim3(256), dim3(THREADS), 0, 0, (const uint64_t *)kin, (uint64_t *)kout, vout, P);
         CK(hipMemcpy(b.data(), vout, b.size() * 4, hipMemcpyDeviceToHost));
         printf("look-back offsets %s the table offsets (first 2^20 outputs)\n", a == b ? "reproduce" : "DIFFER FROM");
