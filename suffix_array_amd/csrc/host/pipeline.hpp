@@ -238,7 +238,7 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         P.epoch = ++epoch;
         P.flags = (uint32_t)tn.onesweep_flags;
         HIP_TRY(hipMemsetAsync(zone[z ^ 1], 0, (size_t)OS_ZONE * 4, st));
-        PROF(K64 ? KC_DOWNSWEEP : KC_DOWNSWEEP32, count, st,
+        PROF(K64 ? KC_ONESWEEP : KC_ONESWEEP32, count, st,
              hipLaunchKernelGGL((k_onesweep<THREADS, ITEMS, KeyT, SEQ, WG_PER_CU>), dim3(grid), dim3(THREADS), 0, st, (const KeyT *)kin,
                                 (const uint32_t *)((iota && *passes == 0) ? nullptr : vin), kout, vdst, P));
         KeyT *tk = kin; kin = kout; kout = tk;

@@ -49,13 +49,26 @@ class OracleStandIn:
         pass
 
     def kernel_names(self):
-        return ["k_radix_downsweep", "k_radix_downsweep32"]
+        return ["k_onesweep", "k_onesweep32", "k_group_sort", "misc"]
 
     def profile_begin(self, mask):
         self.mask = mask
 
     def profile_end(self):
-        return [(2.0, 4, 4 * self.n), (0.0, 0, 0)]
+        # (ms, launches, units) per class; classes outside the mask get no events
+        rows = [(2.0, 4, 4 * self.n), (0.0, 0, 0), (3.0, 2, self.n), (0.1, 5, 10)]
+        return [r if (self.mask >> i) & 1 else (0.0, 0, 0) for i, r in enumerate(rows)]
+
+    def device_count(self):
+        return 1
+
+    def build_batch(self, texts, outs):
+        for t, o in zip(texts, outs):
+            o[:] = self.orc.sais(t)
+        return 0, [0] * len(texts)
+
+    def check_host(self, text_h, sa_h):
+        return self.orc.verify(text_h, sa_h) == 1
 
     def verify(self):
         return self.orc.verify(self.text, self.out) == 1
@@ -115,19 +128,28 @@ def test_world_size_2_gloo_runs_bench_rank_logic():
     assert out0["config"]["n_bytes"] == n and out0["cpu_baseline"] is None
     assert out0["end_to_end"]["reused_buffer"]["MB_per_s"] > 0 and out0["end_to_end"]["fresh_buffer"]["ms"] > 0
     assert out0["batch_c5"]["texts"] == 2 and out0["batch_c5"]["verified"] is True
-    assert out0["roofline"]["kernel"] == "k_radix_downsweep" and out0["roofline"]["bound"] == "hbm"
+    # the dominant class is the one with the most measured time, not a fixed name; classes under 5 % get no events
+    rf = out0["roofline"]
+    assert rf["kernel"] == "k_group_sort" and rf["bound"] == "hbm" and rf["algorithmic_bytes_per_element"] == 29
+    assert [k["name"] for k in rf["kernels"]] == ["k_group_sort", "k_onesweep"] and rf["kernels"][1]["achieved"] > 0
+    assert out0["batch_api"] is None                          # (N = 1 only)
     json.dumps(out0)                                          # serialisable as the one line the driver reads
-    assert b0 == b1 and b0 >= 1 + 3 + 1                       # warm-up + timed + the extra profiled build, on every rank
+    assert b0 == b1 and b0 >= 2 + 1 + 3                       # first touch + profiled build, warm-up, timed steps -- on every rank
 
 
 def test_single_rank_path_with_stand_in():
     sys.path.insert(0, ROOT)
     import bench
     args = bench.parse(["--steps", "2", "--warmup", "0", "--workload", "c4_dna_1g", "--n", "30000", "--cpu-sample", "20000",
-                        "--e2e-calls", "1"])
+                        "--e2e-calls", "1", "--batch-texts", "3"])
     out = bench.run(args, OracleStandIn(), 0, 1)
     assert out["n_gpus"] == 1 and out["verified"] is True and out["batch_c5"] is None
-    assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port"
+    assert out["batch_api"]["texts"] == 3 and out["batch_api"]["verified"] is True and out["batch_api"]["MB_per_s"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["kind"] in ("port", "reference") and len(cb["probe"]) >= 1
+    # the probe order of SURVEY.md 8d: cargo + crate, system library, python package, stand-in
+    assert cb["probe"][0]["step"].startswith("cargo")
+    assert (cb["kind"] == "port") == (cb["probe"][-1]["step"].startswith("stand-in"))
     assert out["host"]["nproc"] >= 1 and "H0_bits_per_byte" in out["config"]
 
 
