@@ -93,6 +93,39 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     HostTiming tm;
     const int node = device_numa_node(cur);                       // staging buffers and copy helpers live next to the GPU's PCIe root
     const double t_begin = wall_ms();
+    const int small_max = (int)env_int("SA_AMD_SMALL_MAX", 8192, 0, SM_MAX_N);
+    if (n <= small_max) {
+        // Small texts: copy -> ONE launch -> copy.  The kernel reads the text from and writes the array to a pooled PINNED host
+        // block over PCIe (zero-copy; hipHostMalloc memory is mapped into the device), so there is no device block, no
+        // hipMemcpy and no read-back: 0.2 ms -> tens of microseconds for the sizes of the reference's own tests (src/tests.rs:14).
+        const size_t tb = align_up((size_t)n, 256), need = tb + ((size_t)n + 1) * 4;
+        PinBlock pb;
+        hipStream_t st = nullptr;
+        int rc = pool().stream(cur, &st);
+        if (rc != SA_AMD_OK) return rc;
+        rc = pool().pinned(need < ((size_t)64 << 10) ? ((size_t)64 << 10) : need, -1, cur, &pb);
+        if (rc != SA_AMD_OK) { pool().release_stream(cur, st); return rc; }
+        void *dbase = nullptr;
+        rc = hip_status(hipHostGetDevicePointer(&dbase, pb.p, 0));
+        if (rc == SA_AMD_OK) {
+            memcpy(pb.p, T, (size_t)n);
+            hipLaunchKernelGGL((k_small_sa), dim3(1), dim3(SM_THREADS), 0, st, (const uint8_t *)dbase, (uint32_t *)((char *)dbase + tb), (int)n,
+                               (uint32_t *)nullptr);
+            rc = hip_status(hipGetLastError());
+            const int rs = hip_status(hipStreamSynchronize(st));
+            if (rc == SA_AMD_OK) rc = rs;
+            if (rc == SA_AMD_OK) {
+                const uint32_t *src = (const uint32_t *)((const char *)pb.p + tb);
+                if (with_sentinel) memcpy(SA_host, src, ((size_t)n + 1) * 4); else memcpy(SA_host, src + 1, (size_t)n * 4);
+            }
+        }
+        pool().release_pinned(pb);
+        pool().release_stream(cur, st);
+        { sa_amd_stats z; memset(&z, 0, sizeof(z)); g_last_stats = z; }
+        tm.total = tm.build = wall_ms() - t_begin;
+        g_host_timing = tm;
+        return rc;
+    }
     const size_t wb = (size_t)sa_amd_workspace_bytes(n);
     const size_t tb = align_up((size_t)n, 256), sb = align_up(((size_t)n + 1) * 4, 256);
     const size_t need = tb + sb + wb;

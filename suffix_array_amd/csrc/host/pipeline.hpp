@@ -848,6 +848,17 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     }
     Workspace w = carve(dWork, n);
     if ((int64_t)w.bytes > work_bytes) return SA_AMD_EINVAL;
+    if (n <= tn.small_max) {
+        // small texts: the whole construction in one launch of one workgroup, everything in LDS (kernels/small.hpp)
+        PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_small_sa), dim3(1), dim3(SM_THREADS), 0, st, dT, dSA, (int)n, w.total));
+        uint32_t rounds = 0;
+        { const int rcw = read_words(&rounds, w.total, 4, st); if (rcw) return rcw; }
+        local.rounds = (int)rounds;
+        g_prof.resolve();
+        g_last_stats = local;
+        if (stats) *stats = local;
+        return SA_AMD_OK;
+    }
     uint32_t *SA = dSA + 1;
     HIP_TRY(hipMemsetAsync(w.os_err, 0, 16, st));          // look-back give-ups of the single-pass scatter: checked at the end
 

@@ -8,6 +8,7 @@
 #include "../kernels/refine.hpp"
 #include "../kernels/isa.hpp"
 #include "../kernels/extras.hpp"
+#include "../kernels/small.hpp"
 #ifdef SA_AMD_DIAG
 #include "../kernels/radix_sort_diag.hpp"
 #include "../kernels/induce_proto.hpp"

@@ -64,6 +64,7 @@ struct Tuning {
     bool no_gram_keys = false;       // SA_AMD_NO_GRAM_KEYS: never key the initial sort by ranks of g-grams
     int64_t gram_min_n = (int64_t)1 << 22;   // SA_AMD_GRAM_MIN_N: smallest text whose g-grams are looked at (measured: -4 % at 4 MiB, +5 % at 1 MiB)
     int gram_g = 0;                  // SA_AMD_GRAM_G: gram length (0 = the longest whose table fits, else 2..8, still subject to the fit)
+    int small_max = 8192;            // SA_AMD_SMALL_MAX: texts of up to this many bytes are built by ONE launch of one workgroup (kernels/small.hpp), 0..8192
     bool no_onesweep = false;        // SA_AMD_NO_ONESWEEP: the three-kernel radix pass (histogram, spine, chunk-owned scatter) instead of the single-pass one
     int onesweep_flags = 0;          // SA_AMD_ONESWEEP_FLAGS: scheduling switches of the single-pass scatter (kernels/onesweep.hpp, OnesweepPass::flags), same result
     int onesweep64_shape = 0;        // SA_AMD_ONESWEEP64_SHAPE / SA_AMD_ONESWEEP32_SHAPE: tile shape of the single-pass scatter (host/pipeline.hpp,
@@ -109,6 +110,7 @@ struct Tuning {
         t.no_gram_keys = env_flag("SA_AMD_NO_GRAM_KEYS");
         t.gram_min_n = env_int("SA_AMD_GRAM_MIN_N", (int64_t)1 << 22, 1, (int64_t)1 << 40);
         t.gram_g = (int)env_int("SA_AMD_GRAM_G", 0, 0, 8);
+        t.small_max = (int)env_int("SA_AMD_SMALL_MAX", 8192, 0, 8192);
         t.no_onesweep = env_flag("SA_AMD_NO_ONESWEEP");
         t.onesweep_flags = (int)env_int("SA_AMD_ONESWEEP_FLAGS", 0, 0, 255);
         t.onesweep64_shape = (int)env_int("SA_AMD_ONESWEEP64_SHAPE", 0, 0, 1 << 20);

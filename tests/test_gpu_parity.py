@@ -58,12 +58,12 @@ def test_radix_sort_pairs(count, bits, engine, monkeypatch):
                                         (100_001, (0, 32)), (2_000_003, (0, 32)), (300_000, (8, 24)), (5_000_000, (0, 32)),
                                         (12287, (0, 16)), (12288, (0, 16)), (12289, (0, 16)), (12288 * 8 + 1, (0, 24)),
                                         (12288 * 9 + 5, (3, 21)), (8192 * 9 + 5, (0, 32)), (30_000_001, (0, 32))])
-@pytest.mark.parametrize("engine", ["single-pass", "single-pass-8", "three-kernel"])
+@pytest.mark.parametrize("engine", ["single-pass", "shape1", "shape2", "shape3", "three-kernel"])
 def test_radix_sort_pairs_32bit_keys(count, bits, engine, monkeypatch):
     if engine == "three-kernel":
         monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")
-    if engine == "single-pass-8":
-        monkeypatch.setenv("SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "8")
+    if engine.startswith("shape"):
+        monkeypatch.setenv("SA_AMD_ONESWEEP32_SHAPE", engine[5:])
     rng = np.random.default_rng(count + bits[1])
     keys = rng.integers(0, 2**32, count, dtype=np.uint32)
     if count > 10:
@@ -107,12 +107,61 @@ def test_build_keys(gen, n):
 
 # ---- the path itself --------------------------------------------------------------------------
 
+@pytest.fixture(params=["one-launch small kernel", "general pipeline"])
+def small_path(request, monkeypatch):
+    """texts of up to 8192 bytes are built by one launch of one workgroup (kernels/small.hpp); SA_AMD_SMALL_MAX=0 sends them
+    through the general pipeline, which the small-input tests must keep covering"""
+    if request.param == "general pipeline":
+        monkeypatch.setenv("SA_AMD_SMALL_MAX", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("text,expected", KNOWN_ANSWERS)
-def test_known_answers(text, expected):
+def test_known_answers(text, expected, small_path):
     assert build(text).tolist() == expected
 
 
-def test_golden_fixtures():
+def test_small_kernel_every_length_and_the_adversarial_families(oracle):
+    """the one-launch kernel on its whole domain: every n up to 300 and n around the powers of two up to 8192 for several
+    alphabets, plus runs, periods, Fibonacci words and text ++ text at its largest sizes (up to 13 doubling rounds in LDS);
+    host-pointer and device-pointer entry points"""
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    rng = np.random.default_rng(99)
+    sizes = list(range(0, 301)) + [511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192]
+    for n in sizes:
+        sigma = int(rng.choice([1, 2, 4, 7, 256]))
+        s = (rng.integers(0, sigma, n) + int(rng.integers(0, 257 - sigma))).astype(np.uint8)
+        assert np.array_equal(build(s), oracle.sais(s)), (n, sigma)
+    fams = {"run": np.full(8192, 255, dtype=np.uint8), "zeros": np.zeros(8191, dtype=np.uint8),
+            "abab": np.resize(np.frombuffer(b"ab", dtype=np.uint8), 8192).copy(),
+            "period 1000": np.resize(rng.integers(0, 256, 1000, dtype=np.uint8), 8000).copy(),
+            "fibonacci": np.frombuffer(fibonacci_word(19)[:8192], dtype=np.uint8).copy(),
+            "twice": np.tile(rng.integers(0, 256, 4096, dtype=np.uint8), 2),
+            "0xff 0x00": np.resize(np.array([255, 0, 255], dtype=np.uint8), 7001).copy()}
+    for name, s in fams.items():
+        exp = oracle.sais(s)
+        assert np.array_equal(build(s), exp), name
+        # the device-pointer entry point takes the same kernel
+        n = int(s.size)
+        wb = sa.workspace_bytes(n)
+        dt, do, dw = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dt), n + 64) == 0 and hip.hipMalloc(ctypes.byref(do), 4 * (n + 1) + 64) == 0
+        assert hip.hipMalloc(ctypes.byref(dw), wb + 512) == 0
+        assert hip.hipMemcpy(dt.value, s.ctypes.data, n, 1) == 0
+        st = sa.Stats()
+        assert sa.lib().sa_amd_saca_device(dt.value, do.value, n, (dw.value + 255) & ~255, wb, None, ctypes.byref(st)) == 0
+        out = np.zeros(n + 1, dtype=np.uint32)
+        assert hip.hipMemcpy(out.ctypes.data, do.value, 4 * (n + 1), 2) == 0
+        for ptr in (dt, do, dw):
+            hip.hipFree(ptr)
+        assert np.array_equal(out, exp), name
+        assert st.sort_passes == 0                                  # (no radix pass ran: it was the small kernel)
+
+
+def test_golden_fixtures(small_path):
     manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
     for name in manifest:
         text = open(os.path.join(GOLDEN, name + ".text"), "rb").read()
@@ -121,12 +170,12 @@ def test_golden_fixtures():
 
 
 @pytest.mark.parametrize("name", sorted(adversarial_cases()))
-def test_adversarial(oracle, name):
+def test_adversarial(oracle, name, small_path):
     s = adversarial_cases()[name]
     assert np.array_equal(build(s), oracle.sais(s))
 
 
-def test_conversion_correctness(oracle):
+def test_conversion_correctness(oracle, small_path):
     """reference src/tests.rs:13-17: random bytes, n in [0, 4096): new().into_parts() must pass
     from_parts (check_integrity) -- and here also equal the oracle bit for bit."""
     rng = np.random.default_rng(20240)
@@ -139,7 +188,7 @@ def test_conversion_correctness(oracle):
         assert np.array_equal(arr, oracle.sais(s))
 
 
-def test_small_alphabets_and_ragged_lengths(oracle):
+def test_small_alphabets_and_ragged_lengths(oracle, small_path):
     rng = np.random.default_rng(7)
     for it in range(120):
         n = int(rng.integers(0, 20000))
@@ -149,7 +198,7 @@ def test_small_alphabets_and_ragged_lengths(oracle):
         assert np.array_equal(build(s), oracle.sais(s)), (n, sigma, base)
 
 
-def test_set_reuses_buffer_with_stale_contents(oracle):
+def test_set_reuses_buffer_with_stale_contents(oracle, small_path):
     """reference src/sa.rs:30-33: set() re-runs construction into a previously used buffer"""
     obj = sa.SuffixArray(b"mississippi")
     obj.set(b"banana")
@@ -521,14 +570,18 @@ def test_sort_kernel_variants(oracle, monkeypatch, v64, v32):
             assert np.array_equal(build(text), exp)
 
 
-@pytest.mark.parametrize("engine", ["single-pass", "single-pass-8", "three-kernel"])
+@pytest.mark.parametrize("engine", ["single-pass", "shapes-1-1", "shapes-2-2", "shapes-0-3", "early-look", "three-kernel"])
 def test_sort_engines_full_path(oracle, monkeypatch, engine):
-    """the single-pass tile scatter (default), its 8-keys-per-thread shape for 32-bit keys and the three-kernel pass it
-    replaced give the same arrays on every route of the pipeline (several tiles per segment: 3 MiB texts)"""
+    """the single-pass tile scatter in its default and its other tile shapes (two workgroups per CU, values through the keys'
+    LDS buffer), with the early look-back, and the three-kernel pass it replaced give the same arrays on every route of the
+    pipeline (several tiles per segment: 3 MiB texts)"""
     if engine == "three-kernel":
         monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")
-    if engine == "single-pass-8":
-        monkeypatch.setenv("SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "8")
+    if engine == "early-look":
+        monkeypatch.setenv("SA_AMD_ONESWEEP_FLAGS", "1")
+    if engine.startswith("shapes"):
+        monkeypatch.setenv("SA_AMD_ONESWEEP64_SHAPE", engine.split("-")[1])
+        monkeypatch.setenv("SA_AMD_ONESWEEP32_SHAPE", engine.split("-")[2])
     for gen, n, seed in (("english_corpus", 3_000_001, 31), ("uniform", 3_145_728, 32), ("dna", 2_999_999, 33), ("dna_repeats", 1_500_000, 34)):
         text = getattr(corpus, gen)(n, seed)
         exp = oracle.sais(text)
@@ -541,7 +594,7 @@ def test_sort_engines_full_path(oracle, monkeypatch, engine):
             assert np.array_equal(got, exp), (engine, gen, switch)
 
 
-def test_randomised_inputs_and_regimes(oracle, monkeypatch):
+def test_randomised_inputs_and_regimes(oracle, monkeypatch, small_path):
     """short form of tools/stress.py: random sizes, alphabets and structures with the regime switches
     toggled at random; every array equals the oracle's"""
     rng = np.random.default_rng(2026)
@@ -581,7 +634,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS",
+             "SA_AMD_SMALL_MAX", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
