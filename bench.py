@@ -293,7 +293,7 @@ class HipBackend:
     def verify(self):
         """reference src/sa.rs:72-84 in linear time on the device (k_ci_scatter / k_ci_check), on the array the last
         step left in HBM; outside the timed region"""
-        ci_bytes = 4 * (self.n + 1) + 256
+        ci_bytes = int(self.L.sa_amd_check_integrity_work_bytes(self.n))       # (the streaming form of the check)
         ci_work = self.torch.empty(ci_bytes, dtype=self.torch.uint8, device=self.dev)
         rc = self.L.sa_amd_check_integrity_device(self.text.data_ptr(), self.n, self.out.data_ptr(), ci_work.data_ptr(),
                                                   ci_bytes, self.stream)

@@ -128,8 +128,12 @@ int32_t sa_amd_bucket_table_device(const uint8_t *dT, const uint32_t *dSA, int32
  * `check_integrity` (reference src/sa.rs:72-84), the validation behind `from_parts` and every
  * `load*` (src/sa.rs:57-64, :293-361), in linear time: returns 1 (true), 0 (false; also when
  * sa_len != n + 1, src/sa.rs:73-75), SA_AMD_ERANGE when an entry exceeds n (the reference panics
- * on the slice index there), or another negative status.  dWork: 4 * (n + 1) + 256 bytes.
+ * on the slice index there), or another negative status.  dWork: at least 4 * (n + 1) + 256 bytes
+ * (random-store inverse permutation); with sa_amd_check_integrity_work_bytes(n) bytes, 256-byte
+ * aligned, and a 16-byte aligned dSA the check runs at streaming cost (binned inverse permutation,
+ * one random rank line per slot: 25 -> ~10 ms at 256 MiB).
  */
+int64_t sa_amd_check_integrity_work_bytes(int32_t n);
 int32_t sa_amd_check_integrity(const uint8_t *T, int32_t n, const uint32_t *SA, int64_t sa_len);
 int32_t sa_amd_check_integrity_device(const uint8_t *dT, int32_t n, const uint32_t *dSA, void *dWork,
                                       int64_t work_bytes, void *stream);

@@ -115,6 +115,8 @@ def lib() -> ctypes.CDLL:
         L.sa_amd_profile_begin_classes.restype = None
         L.sa_amd_check_integrity_device.argtypes = [c_vp, ctypes.c_int32, c_vp, c_vp, ctypes.c_int64, c_vp]
         L.sa_amd_check_integrity_device.restype = ctypes.c_int32
+        L.sa_amd_check_integrity_work_bytes.argtypes = [ctypes.c_int32]
+        L.sa_amd_check_integrity_work_bytes.restype = ctypes.c_int64
         _lib = L
     return _lib
 

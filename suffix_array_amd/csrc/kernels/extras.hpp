@@ -73,6 +73,116 @@ __global__ __launch_bounds__(256) void k_ci_check(const uint8_t *__restrict__ T,
     if (__any(bad) && lane_id() == 0) atomicOr(flags, 2u);
 }
 
+// ---- the same check at streaming cost (round 3) ----
+// The inverse permutation comes from the engine's binned scatter (two radix passes on the top bits of the suffix position,
+// then windows of the rank array assembled in LDS: host/pipeline.hpp, scatter_binned) instead of n random 4-byte stores
+// that each cost a read-modify-write of an HBM burst; the check pass fetches ONE random line of the rank array per slot
+// -- rank[b] and rank[b + 1] are neighbours, and slot i's rank[b + 1] is slot i + 1's rank[a + 1], handed over by a wave
+// shuffle, like T[b] -- instead of three.
+__global__ __launch_bounds__(256) void k_ci_range(const uint32_t *__restrict__ SA, int64_t n, uint32_t *__restrict__ flags)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    bool over = false, bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= n; i += stride) {
+        const uint32_t v = SA[i];
+        over |= (int64_t)v > n;
+        bad |= ((int64_t)v == n) != (i == 0);             // the empty suffix sits in slot 0 and nowhere else
+    }
+    if (__any(over) && lane_id() == 0) atomicOr(flags, 1u);
+    if (__any(bad) && lane_id() == 0) atomicOr(flags, 2u);
+}
+
+// Where the first bytes change along the array.  The claimed array is not trusted: the 257 binary searches (first slot
+// whose suffix starts with a byte >= c) only PROPOSE boundaries, a running maximum makes them monotone, and
+// k_ci_first_bytes then proves them: if rank is a bijection onto the slots 1 .. n and every suffix v sits inside the slot range
+// of its own first byte, the ranges (disjoint, covering) hold exactly the suffixes of their byte -- the first bytes are
+// non-decreasing along the array -- and two neighbouring slots have equal first bytes iff no boundary lies between them.
+__global__ __launch_bounds__(512) void k_ci_starts(const uint8_t *__restrict__ T, const uint32_t *__restrict__ SA, int64_t n,
+                                                    uint32_t *__restrict__ starts, uint32_t *__restrict__ bitmap)
+{
+    __shared__ uint32_t lds[512 / WAVE + 1];
+    const int c = threadIdx.x;
+    uint32_t s = 0;
+    if (c <= 256) {
+        int64_t lo = 1, hi = n + 1;
+        if (c == 256) lo = n + 1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            const uint32_t v = SA[mid];
+            const uint32_t cv = (int64_t)v < n ? (uint32_t)T[v] : 0u;       // (an entry out of place was flagged by k_ci_range)
+            if (cv < (uint32_t)c) lo = mid + 1; else hi = mid;
+        }
+        s = (uint32_t)lo;
+    }
+    uint32_t all;
+    const uint32_t m = block_incl_max<512>(c <= 256 ? s : 0u, lds, &all);
+    if (c <= 256) {
+        starts[c] = c == 256 ? (uint32_t)(n + 1) : m;
+        if (c < 256 && (int64_t)m <= n) atomicOr(&bitmap[m >> 5], 1u << (m & 31u));
+    }
+}
+
+// text order, streaming: suffix v must sit in the slot range of its first byte
+__global__ __launch_bounds__(256) void k_ci_first_bytes(const uint8_t *__restrict__ T, int64_t n, const uint32_t *__restrict__ rank,
+                                                         const uint32_t *__restrict__ starts, uint32_t *__restrict__ flags)
+{
+    __shared__ uint32_t st[257];
+    for (int i = threadIdx.x; i < 257; i += 256) st[i] = starts[i];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    bool bad = false;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += stride) {
+        const uint32_t c = T[v], r = rank[v];
+        bad |= r < st[c] || r >= st[c + 1];
+    }
+    if (__any(bad) && lane_id() == 0) atomicOr(flags, 2u);
+}
+
+constexpr int CI_THREADS = 256;
+constexpr int CI_ITEMS = 8;
+struct __attribute__((packed, aligned(4))) CiPair { uint32_t x, y; };      // two neighbouring ranks, fetched by one 4-byte aligned 8-byte load
+// slot order: rank[v] = slot of suffix v for v < n (written by the binned scatter; the slab has n + 1 entries), the empty
+// suffix (v = n) has rank 0.  Slot i: rank[SA[i]] == i (the scatter really is the inverse: no value twice), and for a
+// neighbour with the same first byte rank[a + 1] < rank[b + 1].  ONE gather per slot: rank[b] and rank[b + 1] together.
+__global__ __launch_bounds__(CI_THREADS) void k_ci_check_shared(const uint32_t *__restrict__ SA, int64_t n, const uint32_t *__restrict__ rank,
+                                                                  const uint32_t *__restrict__ bitmap, uint32_t *__restrict__ flags)
+{
+    const int64_t base = (int64_t)blockIdx.x * (CI_THREADS * CI_ITEMS) + 1;       // slots 1 .. n
+    const int l = lane_id();
+    bool bad = false;
+    uint32_t b[CI_ITEMS], rb[CI_ITEMS], rb1[CI_ITEMS];
+#pragma unroll
+    for (int k = 0; k < CI_ITEMS; ++k) {
+        const int64_t i = base + k * CI_THREADS + threadIdx.x;
+        b[k] = i <= n ? SA[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int k = 0; k < CI_ITEMS; ++k) {
+        rb[k] = 0; rb1[k] = 0;
+        if ((int64_t)b[k] < n) {                            // (values >= n in these slots were flagged by k_ci_range)
+            const CiPair q = *(const CiPair *)(rank + b[k]);
+            rb[k] = q.x;
+            rb1[k] = (int64_t)b[k] + 1 < n ? q.y : 0u;      // (the suffix behind the last byte is the empty one: rank 0)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CI_ITEMS; ++k) {
+        const int64_t i = base + k * CI_THREADS + threadIdx.x;
+        // rank[a + 1] of the slot in front of mine: my left neighbour's rb1, or (first lane of a wave) fetched here
+        uint32_t ra1 = (uint32_t)__shfl_up((int)rb1[k], 1, WAVE);
+        if (l == 0 && i >= 2 && i <= n) {
+            const uint32_t a = SA[i - 1];
+            ra1 = ((int64_t)a + 1 < n) ? rank[a + 1] : 0u;
+        }
+        if (i > n || (int64_t)b[k] >= n) continue;          // (past the end / flagged already)
+        if (rb[k] != (uint32_t)i) { bad = true; continue; }      // not the inverse: some value is there twice
+        const bool new_byte = (bitmap[i >> 5] >> (i & 31)) & 1u;  // a first-byte boundary between slots i - 1 and i
+        if (i == 1 || new_byte) continue;                   // (k_ci_first_bytes proves the order of the first bytes)
+        if (ra1 >= rb1[k]) bad = true;
+    }
+    if (__any(bad) && l == 0) atomicOr(flags, 2u);
+}
+
 }  // namespace sa
 
 // ------------------------------------------------------------------------------------------

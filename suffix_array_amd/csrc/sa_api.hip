@@ -115,17 +115,92 @@ SA_EXPORT int32_t sa_amd_bucket_table_device(const uint8_t *dT, const uint32_t *
     return hipStreamSynchronize(st) == hipSuccess ? SA_AMD_OK : SA_AMD_EHIP;
 }
 
+// layout of the larger work block (fast form): flags | rank | four pair buffers | spine + digit totals | granules + error word
+struct CiLayout { size_t flags, rank, alt, alt_elems, spine, status, err, starts, bitmap, bitmap_bytes, bytes; };
+static CiLayout ci_layout(int32_t n)
+{
+    CiLayout L;
+    const size_t N1 = (size_t)n + 1;
+    size_t off = 0;
+    auto take = [&](size_t b) { const size_t o = off; off = sa::align_up(off + b, 256); return o; };
+    L.flags = take(256);
+    L.rank = take(N1 * 4);
+    L.alt_elems = (N1 + 67) & ~(size_t)3;
+    L.alt = take(4 * L.alt_elems * 4);
+    L.spine = take(((size_t)sa::RADIX * sa::SORT_MAX_WG + sa::RADIX) * 4);
+    L.status = take(((size_t)sa::ceil_div((int64_t)N1, sa::OS_MIN_TILE) + 1) * sa::RADIX * 8);
+    L.err = take(256);
+    L.starts = take(257 * 4);
+    L.bitmap_bytes = ((N1 + 31) / 32 + 1) * 4;
+    L.bitmap = take(L.bitmap_bytes);
+    L.bytes = off;
+    return L;
+}
+
+SA_EXPORT int64_t sa_amd_check_integrity_work_bytes(int32_t n)
+{
+    if (n < 0) return -1;
+    return (int64_t)ci_layout(n).bytes;
+}
+
 SA_EXPORT int32_t sa_amd_check_integrity_device(const uint8_t *dT, int32_t n, const uint32_t *dSA, void *dWork,
                                                 int64_t work_bytes, void *stream)
 {
     if (n < 0 || !dSA || !dWork || (n > 0 && !dT)) return SA_AMD_EINVAL;
     if (work_bytes < ((int64_t)n + 1) * 4 + 256) return SA_AMD_EINVAL;
+    SA_ABI_GUARD_BEGIN
+    using namespace sa;
     hipStream_t st = (hipStream_t)stream;
     uint32_t *flags = (uint32_t *)dWork;
     uint32_t *rank = (uint32_t *)((char *)dWork + 256);
-    if (hipMemsetAsync(flags, 0, 4, st) != hipSuccess) return SA_AMD_EHIP;
+    HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
     int64_t blocks = ((int64_t)n + 1 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
+    const CiLayout L = ci_layout(n);
+    if (work_bytes >= (int64_t)L.bytes && (((uintptr_t)dWork) & 255u) == 0 && (((uintptr_t)dSA) & 15u) == 0 && n >= 2) {
+        // ---- streaming form: range check, binned inverse permutation, one random rank line per slot ----
+        hipLaunchKernelGGL(k_ci_range, dim3((unsigned)blocks), dim3(256), 0, st, dSA, (int64_t)n, flags);
+        HIP_TRY(hipGetLastError());
+        uint32_t f = 0;
+        { const int rcw = read_words(&f, flags, 4, st); if (rcw) return rcw; }
+        if (f & 1u) return SA_AMD_ERANGE;
+        if (f & 2u) return 0;
+        char *base = (char *)dWork;
+        Workspace w;
+        memset(&w, 0, sizeof(w));
+        w.isa = (uint32_t *)(base + L.rank);
+        w.spine = (uint32_t *)(base + L.spine);
+        w.digit_tot = w.spine + (size_t)RADIX * SORT_MAX_WG;
+        w.os_status = (unsigned long long *)(base + L.status);
+        w.os_err = (uint32_t *)(base + L.err);
+        w.ss.spine = w.spine; w.ss.digit_tot = w.digit_tot; w.ss.status = w.os_status; w.ss.err = w.os_err;
+        HIP_TRY(hipMemsetAsync(w.os_err, 0, 16, st));
+        uint32_t *alt = (uint32_t *)(base + L.alt);
+        const Tuning tn = Tuning::from_env(N_SORT_VARIANTS, N_SORT32_VARIANTS, N_OS_SHAPES64, N_OS_SHAPES32);
+        sa_amd_stats local;
+        memset(&local, 0, sizeof(local));
+        // pairs (SA[i], i), i = 0 .. n, binned by the suffix position; the scatter skips the empty suffix (value n)
+        const int rcs = scatter_binned((uint32_t *)dSA, nullptr, alt, alt + L.alt_elems, (int64_t)n + 1, (int64_t)n, w, st, &local, tn, true,
+                                       alt + 2 * L.alt_elems, alt + 3 * L.alt_elems);
+        if (rcs) return rcs;
+        // first bytes: boundaries proposed from the array, proved in text order (streaming); then the slot-order check
+        uint32_t *starts = (uint32_t *)(base + L.starts), *bitmap = (uint32_t *)(base + L.bitmap);
+        HIP_TRY(hipMemsetAsync(bitmap, 0, L.bitmap_bytes, st));
+        hipLaunchKernelGGL(k_ci_starts, dim3(1), dim3(512), 0, st, dT, dSA, (int64_t)n, starts, bitmap);
+        int64_t fblocks = ceil_div((int64_t)n, 256 * 16);
+        if (fblocks > 16384) fblocks = 16384;
+        hipLaunchKernelGGL(k_ci_first_bytes, dim3((unsigned)fblocks), dim3(256), 0, st, dT, (int64_t)n, (const uint32_t *)w.isa, (const uint32_t *)starts, flags);
+        const int64_t cblocks = ceil_div((int64_t)n, (int64_t)CI_THREADS * CI_ITEMS);
+        hipLaunchKernelGGL(k_ci_check_shared, dim3((unsigned)cblocks), dim3(CI_THREADS), 0, st, dSA, (int64_t)n, (const uint32_t *)w.isa,
+                           (const uint32_t *)bitmap, flags);
+        HIP_TRY(hipGetLastError());
+        uint32_t words[2] = { 0, 0 };
+        { const int rcw = read_words(&words[0], flags, 4, st); if (rcw) return rcw; }
+        { const int rcw = read_words(&words[1], w.os_err, 4, st); if (rcw) return rcw; }
+        if (words[1]) return SA_AMD_EINTERNAL;
+        return (words[0] & 2u) ? 0 : 1;
+    }
+    // ---- small work block (4 (n + 1) + 256 bytes): random-store inverse, three rank reads per slot ----
     hipLaunchKernelGGL(sa::k_ci_scatter, dim3((unsigned)blocks), dim3(256), 0, st, dSA, (int64_t)n, rank, flags);
     hipLaunchKernelGGL(sa::k_ci_check, dim3((unsigned)blocks), dim3(256), 0, st, dT, dSA, (int64_t)n, (const uint32_t *)rank, flags);
     if (hipGetLastError() != hipSuccess) return SA_AMD_EHIP;
@@ -134,6 +209,7 @@ SA_EXPORT int32_t sa_amd_check_integrity_device(const uint8_t *dT, int32_t n, co
     if (hipStreamSynchronize(st) != hipSuccess) return SA_AMD_EHIP;
     if (f & 1u) return SA_AMD_ERANGE;
     return (f & 2u) ? 0 : 1;
+    SA_ABI_GUARD_END(0)
 }
 
 // host buffers; which = 1: bucket table, 2: integrity check, 3: build SA (into SA, n + 1 entries) then bucket table
@@ -165,8 +241,10 @@ static int32_t extras_host(const uint8_t *T, int32_t n, uint32_t *SA, int64_t sa
         HIP_TRY(hipMemcpy(bkt, dB.p, (size_t)BKT_LEN * 4, hipMemcpyDeviceToHost));
         return SA_AMD_OK;
     }
-    const int64_t wb = ((int64_t)n + 1) * 4 + 256;
-    if ((rc = dW.alloc((size_t)wb))) return rc;
+    int64_t wb = sa_amd_check_integrity_work_bytes(n);              // the streaming form; the small block if that much is not to be had
+    rc = dW.alloc((size_t)wb);
+    if (rc == SA_AMD_ENOMEM) { (void)hipGetLastError(); wb = ((int64_t)n + 1) * 4 + 256; rc = dW.alloc((size_t)wb); }
+    if (rc) return rc;
     return sa_amd_check_integrity_device(dT.as<uint8_t>(), n, dSA.as<uint32_t>(), dW.p, wb, nullptr);
 }
 
@@ -273,11 +351,18 @@ SA_EXPORT int32_t sa_amd_index_check_integrity(const sa_amd_index *ix)
     if (!ix) return SA_AMD_EINVAL;
     sa::DeviceGuard guard(ix->device);
     if (guard.rc != SA_AMD_OK) return guard.rc;
-    sa::DevBuf dW;
-    const int64_t wb = ((int64_t)ix->n + 1) * 4 + 256;
-    int32_t rc;
-    if ((rc = dW.alloc((size_t)wb))) return rc;
-    return sa_amd_check_integrity_device(ix->dT, ix->n, ix->dSA, dW.p, wb, nullptr);
+    // the work block of the streaming form comes from the process-wide pool (a 5.5 GB hipMalloc / hipFree per call would
+    // cost more than the check); the small block if that much is not to be had
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return SA_AMD_EHIP;
+    sa::DevBlock blk;
+    int64_t wb = sa_amd_check_integrity_work_bytes(ix->n);
+    int32_t rc = sa::pool().acquire(cur, (size_t)wb, &blk);
+    if (rc == SA_AMD_ENOMEM) { wb = ((int64_t)ix->n + 1) * 4 + 256; rc = sa::pool().acquire(cur, (size_t)wb, &blk); }
+    if (rc) return rc;
+    rc = sa_amd_check_integrity_device(ix->dT, ix->n, ix->dSA, blk.p, wb, nullptr);
+    sa::pool().release(blk);
+    return rc;
 }
 
 SA_EXPORT int32_t sa_amd_index_search(const sa_amd_index *ix, const uint8_t *pat_data, const int64_t *pat_off, int32_t count,

@@ -912,6 +912,51 @@ def test_check_integrity_matches_reference_restatement(oracle):
                 sa.check_integrity(s, oob)
 
 
+def test_check_integrity_device_forms_on_a_large_array(oracle):
+    """both forms of sa_amd_check_integrity_device -- the small work block (random-store inverse permutation) and the
+    streaming one (binned inverse permutation through two radix passes, one random rank line per slot) -- on a 40 M-entry
+    array: the good array, adjacent swaps, a duplicate, the empty suffix in a wrong slot, an entry out of range"""
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    L = sa.lib()
+    t = corpus.english_corpus(40_000_003, 77)
+    n = int(t.size)
+    good = build(t)
+    assert oracle.verify_mt(t, good) == 1
+    big, small = int(L.sa_amd_check_integrity_work_bytes(n)), 4 * (n + 1) + 256
+    assert big > 5 * small // 2
+    dt, ds, dw = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dt), n + 64) == 0 and hip.hipMalloc(ctypes.byref(ds), 4 * (n + 1) + 64) == 0
+    assert hip.hipMalloc(ctypes.byref(dw), big + 512) == 0
+    work = (dw.value + 255) & ~255
+    assert hip.hipMemcpy(dt.value, t.ctypes.data, n, 1) == 0
+    rng = np.random.default_rng(3)
+
+    def both(arr):
+        assert hip.hipMemcpy(ds.value, arr.ctypes.data, 4 * (n + 1), 1) == 0
+        return (L.sa_amd_check_integrity_device(dt.value, n, ds.value, work, big, None),
+                L.sa_amd_check_integrity_device(dt.value, n, ds.value, work, small, None))
+
+    assert both(good) == (1, 1)
+    for _ in range(3):
+        bad = good.copy()
+        i = int(rng.integers(1, n))
+        bad[i], bad[i + 1] = bad[i + 1], bad[i]
+        assert both(bad) == (0, 0), i
+    bad = good.copy(); bad[n // 3] = bad[n // 3 + 1]                     # a value twice, another one missing
+    assert both(bad) == (0, 0)
+    bad = good.copy(); bad[0], bad[5] = bad[5], bad[0]                   # the empty suffix not in slot 0
+    assert both(bad) == (0, 0)
+    bad = good.copy(); bad[n // 2] = n + 7                               # the reference panics on the slice index
+    assert both(bad) == (-6, -6)
+    bad = good.copy(); bad[1:] = np.roll(good[1:], 1)                    # a rotation: a permutation, almost everywhere in order
+    assert both(bad) == (0, 0)
+    for p in (dt, ds, dw):
+        hip.hipFree(p)
+
+
 def test_from_parts_uses_gpu_check(oracle):
     s = corpus.english(50_000, 4)
     good = oracle.sais(s)

@@ -15,7 +15,9 @@ text = torch.from_numpy(t).to(dev)
 out = torch.empty(n + 1, dtype=torch.int32, device=dev)
 wb = sa.workspace_bytes(n)
 work = torch.empty(wb, dtype=torch.uint8, device=dev)
-ci = torch.empty(4 * (n + 1) + 256, dtype=torch.uint8, device=dev)
+L = sa.lib()
+ci_bytes = int(L.sa_amd_check_integrity_work_bytes(n))
+ci = torch.empty(ci_bytes, dtype=torch.uint8, device=dev)
 st = sa.Stats()
 L = sa.lib()
 for spec in sys.argv[2:]:
@@ -29,6 +31,6 @@ for spec in sys.argv[2:]:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         sa.saca_device_ptr(text.data_ptr(), out.data_ptr(), n, work.data_ptr(), wb, 0, st)
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-    ok = L.sa_amd_check_integrity_device(text.data_ptr(), n, out.data_ptr(), ci.data_ptr(), 4 * (n + 1) + 256, None)
+    ok = L.sa_amd_check_integrity_device(text.data_ptr(), n, out.data_ptr(), ci.data_ptr(), ci_bytes, None)
     print(f"{name} [{spec}]: {best*1e3:8.2f} ms  rounds {st.rounds} (text {st.text_rounds}) passes {st.sort_passes} verified {ok == 1}", flush=True)
     os.environ.clear(); os.environ.update(saved)
