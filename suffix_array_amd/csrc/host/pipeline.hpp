@@ -692,8 +692,10 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         uint32_t tot9[9] = { 0 };                             // [0] flagged members, [8] flagged groups
         { const int rcw = read_words(tot9, w.total, sizeof(tot9), st); if (rcw) return rcw; }
         const int64_t m_big = tot9[0];
-        const size_t half = (((size_t)n / 2 + 1) & ~(size_t)1);
-        if ((size_t)m_big <= half) {
+        // the flagged members are sorted in the first `half` entries of rkB / Valt with the second half as the alternate
+        // buffers: half is even (16-byte aligned 8-byte keys) and half + m_big never exceeds the n entries the slabs hold
+        const size_t half = ((size_t)n / 2) & ~(size_t)1;
+        if ((size_t)m_big <= half && half + (size_t)m_big <= (size_t)n) {
             if (m_big > 0) {
                 // groups no tile owns: global sort of (index of the group among them, key2), then back to their list positions
                 // (a text that is one long run has ONE such group: no index bits at all, four passes instead of eight)
@@ -830,23 +832,613 @@ static int choose_gram_keys(const uint8_t *dT, int64_t n, KeyParams *Pp, int *ke
     return SA_AMD_OK;
 }
 
+// One device-resident build, phase by phase.  The members are what the phases hand to each other; every phase returns an
+// SA_AMD_* status.  The blocking 4-byte read-backs that steer the host (how many suffixes are still tied, how many groups,
+// how many ranks changed) are the read_words calls inside the phases: each one names what it reads.
+struct DeviceBuild {
+    // ---- inputs ----
+    const uint8_t *dT;
+    uint32_t *dSA, *SA;                 // SA = dSA + 1: the n sorted suffixes behind the sentinel slot
+    int64_t n;
+    hipStream_t st;
+    Tuning tn;
+    Workspace w;
+    sa_amd_stats local;
+    bool trace = false;
+    double trace_t = 0;
+    double lap() { const double t = now_ms(), d = t - trace_t; trace_t = t; return d; }
+    bool timing_only() const            // diag library only: stop after the initial sort (array NOT finished)
+    {
+#ifdef SA_AMD_DIAG
+        return tn.timing_only_initial_sort;
+#else
+        return false;
+#endif
+    }
+    // ---- key geometry and route (geometry_and_probes) ----
+    KeyParams P, Ptext;
+    int sigma = 0, key_bits = 0, g_bits = 0, top_shift = 0;
+    bool force_dense = false, text_ok = false, local_ok = false, probe_dense = false;
+    // ---- initial order (initial_sort) ----
+    SortResult sr;
+    const uint32_t *sorted32 = nullptr; // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
+    uint64_t *sorted0 = nullptr;        // the initial keys in SA order (kept for the rank look-ups)
+    // ---- the tied list and its buffers (from first_round_from_sorted_keys on) ----
+    uint32_t *Ucur = nullptr, *Unext = nullptr, *Gcur = nullptr, *Gnext = nullptr, *Vcur = nullptr;
+    uint64_t *rkA = nullptr, *rkB = nullptr;
+    int64_t tiles = 0, m = 0, depth = 0;
+    uint32_t m32 = 0;
+    bool lists_ready = false, finished32 = false, fused64 = false, sparse = false;
+    int s_sym = 0, tkb = 0, key2_bits = 0;
+
+
+    // 1-2. which byte values occur -> symbol codes and key geometry; entropy probe, repeat probe, gram keys (read-backs: the 256 presence flags, two duplicate counts, the number of grams in use)
+    int geometry_and_probes()
+    {
+        int rc = SA_AMD_OK; (void)rc;
+        // 1. sigma = 256 histogram -> symbol codes, bits per symbol, symbols per key
+        HIP_TRY(hipMemsetAsync(w.hist, 0, 256 * 4, st));
+        {
+            int64_t blocks = ceil_div(ceil_div(n, 16), BH_THREADS);
+            if (blocks > 2048) blocks = 2048;
+            if (blocks < 1) blocks = 1;
+            PROF(KC_BYTE_HIST, n, st, hipLaunchKernelGGL((k_byte_hist), dim3((unsigned)blocks), dim3(BH_THREADS), 0, st, dT, n, w.hist));
+        }
+        uint32_t hist[256];
+        { const int rcw = read_words(hist, w.hist, sizeof(hist), st); if (rcw) return rcw; }
+        key_bits = make_key_params(hist, &P, &sigma, tn.key_bits_max);      // (gram keys, step 2c, may shorten it)
+        local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
+
+        g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
+        force_dense = tn.force_dense;
+        text_ok = !force_dense && !tn.no_text_rounds;
+        local_ok = !tn.no_local_sort;
+
+        // 2. entropy probe: do the top 32 key bits already separate (almost) all suffixes?  Then the initial
+        //    sort only needs those 4 digits and a cheap round on the low bits finishes the few ties.
+        top_shift = 0;
+        if (text_ok && local_ok && key_bits > 32 && !tn.no_top32) {
+            bool use = tn.force_top32;
+            if (!use && n >= ((int64_t)1 << 24)) {
+                const int64_t S = (int64_t)1 << 20;
+                PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_keys), dim3((unsigned)ceil_div(S, GK_THREADS)), dim3(GK_THREADS), 0, st, dT, P, n, S,
+                                                        key_bits - 32, w.keysA));
+                // duplicates counted in a hash table (4 entries per sample, in the other key buffer) instead of sorting the sample
+                const uint32_t H = (uint32_t)S * 4u;
+                HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
+                HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
+                PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
+                                                        (unsigned long long *)w.keysB, H - 1u, w.total));
+                uint32_t dups = 0;
+                { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
+                // c - 1 per value seen c times under-counts pairs only when values repeat often, which is the
+                // "do not" case anyway; expected number of other suffixes sharing the top bits with a given one:
+                const double q = 2.0 * (double)dups / ((double)S * (double)S);
+                use = (double)n * q < 0.5;
+            }
+            if (use) top_shift = key_bits - 32;
+        }
+        local.top32_first = top_shift ? 1 : 0;
+        // 2b. repeat probe (texts the first probe did not send to the 32-bit route): the fraction of suffixes that share
+        //     2k symbols with another suffix.  Many (copied passages, a corpus): the text-keyed rounds cannot finish, so rank
+        //     doubling starts right after the initial sort (measured on C3: 64 ms against 68 ms); few: text-keyed rounds.
+        probe_dense = false;
+        if (text_ok && local_ok && !top_shift && !force_dense && !tn.no_repeat_probe && n >= ((int64_t)1 << 24)) {
+            const int64_t S = (int64_t)1 << 20;
+            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_repeat_keys), dim3((unsigned)ceil_div(S, GK_THREADS)), dim3(GK_THREADS), 0, st, dT, P, n, S,
+                                                    w.keysA));
+            const uint32_t H = (uint32_t)S * 4u;
+            HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
+            HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
+            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
+                                                    (unsigned long long *)w.keysB, H - 1u, w.total));
+            uint32_t dups = 0;
+            { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
+            const double chance = (double)S * (double)S / 8589934592.0;           // 32-bit hash collisions among S samples
+            const double frac = ((double)dups - chance) * (double)n / ((double)S * (double)S);
+            probe_dense = frac > 0.04;
+            if (trace) fprintf(stderr, "suffix_array_amd: repeat probe: %u duplicates among %lld samples (repeat index %.3f, threshold 0.04) -> %s\n",
+                               dups, (long long)S, frac, probe_dense ? "rank doubling from the start" : "text-keyed rounds");
+        }
+
+        // 2c. gram keys (texts that did not take the 32-bit route): choose_gram_keys measures and decides; the probes above keep
+        //     using the plain key
+        if (!top_shift && !tn.no_gram_keys && n >= tn.gram_min_n && n >= 2 && sigma >= 2 && tn.key_bits_max == 64) {
+            const int rcg = choose_gram_keys(dT, n, &P, &key_bits, w, st, tn, trace);
+            if (rcg) return rcg;
+            local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
+        }
+
+        return SA_AMD_OK;
+    }
+
+    // 3-4. packed keys and the initial LSD sort, the last pass writing straight into SA
+    int initial_sort()
+    {
+        int rc = SA_AMD_OK; (void)rc;
+        // 3. packed keys, 4. initial sort: all key bits as (u64 key, u32 suffix) pairs, or only the top 32 bits as
+        //    (u32, u32) pairs in 12 Ki-element tiles -- two thirds of the bytes per pass and half the passes
+        sr.keys = w.keysA; sr.vals = w.valsA; sr.passes = 0;
+        sorted32 = nullptr;               // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
+        // value of pair i = i: not stored by k_build_keys, the first sort pass takes the index (saves 8 B / suffix)
+        const bool iota = n >= 2 && key_bits > 0;
+        uint32_t *vals0 = iota ? (uint32_t *)nullptr : w.valsA;
+        // alphabets of 2, 4 or 16 symbols: k_build_keys also writes the text as bit-packed codes, which every later random
+        // read of the text uses instead (a key becomes a bit field of two words; DNA shrinks to a quarter: cache-resident)
+        uint8_t *packed_out = nullptr;
+        if ((P.bits == 1 || P.bits == 2 || P.bits == 4) && n >= 64 && !tn.no_packed_text) {
+            packed_out = w.packed;
+            HIP_TRY(hipMemsetAsync(packed_out + (size_t)(n >> 3) * P.bits, 0, 64, st));     // the padding behind the last whole group
+        }
+        if (top_shift) {
+            uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
+            // the first radix pass's digit histogram comes out of k_build_keys (keys in registers there): one read of every key less
+            const FirstCounts fc = sort_first_counts(w.ss, tn, n, true);
+            const bool counted = n > 1;
+            if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
+            PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                          (uint64_t *)nullptr, vals0, k32a, top_shift, packed_out,
+                                                          counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, 0xffu));
+            SortResult32 s32;
+            rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.ss, SA, st, &s32, tn, iota, counted);
+            if (rc) return rc;
+            local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
+            sorted32 = s32.keys;
+            sr.vals = s32.vals; sr.passes = s32.passes;
+            sr.keys = (s32.keys == k32a) ? w.keysA : w.keysB;      // the 8n-byte buffer that now holds the sorted 32-bit keys
+        } else {
+            const FirstCounts fc = sort_first_counts(w.ss, tn, n, false);
+            const bool counted = n > 1 && key_bits > 0;
+            const int nb0 = key_bits < RADIX_BITS ? key_bits : RADIX_BITS;
+            if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
+            if (P.gram > 0)
+                PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false, true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                              w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
+                                                              counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, (1u << nb0) - 1u));
+            else
+                PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                              w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
+                                                              counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, (1u << nb0) - 1u));
+            // (a text of ONE byte value -- a zero-filled file -- has the same key everywhere but at its end: its passes are the identity
+            // and are looked for; any other text does not pay the read-backs)
+            rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.ss, SA, st, &sr, tn, iota, sigma == 1, counted);
+            if (rc) return rc;
+            local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
+        }
+        P.packed = packed_out;
+        if (sr.vals != SA) {   // n == 1: no pass ran, the values are still in the input buffer
+            PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_copy_u32), dim3(1), dim3(256), 0, st, sr.vals, SA, n));
+        }
+
+        return SA_AMD_OK;
+    }
+
+    // list buffers; the fast finish of the 32-bit first stage / the opt-in fused first text round (read-backs: tied counts)
+    int first_round_from_sorted_keys()
+    {
+        int rc = SA_AMD_OK; (void)rc;
+        // 4. group heads of the initial order; how many suffixes are still tied with a neighbour
+        Ucur = w.U0; Unext = w.U1; Gcur = w.G0; Gnext = w.G1;
+        Vcur = w.valsA;
+        tiles = ceil_div(n, RR_TILE);
+        m32 = 0;
+        m = 0;
+        rkA = w.keysA; rkB = w.keysB;          // key buffers of the refinement rounds
+        sorted0 = sr.keys;                      // the initial keys in SA order (kept for the rank look-ups)
+        lists_ready = false;                         // (Ucur, Gcur, Vcur) already hold the tied suffixes
+        depth = P.k;                               // symbols the current order is sorted by
+        // Text-keyed rounds pack their symbols as bit fields of ceil(log2 sigma) bits whatever the alphabet: a secondary key only
+        // has to preserve the order inside one round, and the base-sigma form costs a 64-bit multiply per symbol in kernels
+        // that are instruction-bound (k_group_sort: 26 ps per suffix however small the text).  English-like sigma = 56: six
+        // symbols in 36 bits either way.
+        Ptext = P;
+        if (P.bits == 0) Ptext.bits = bit_length(P.sigma - 1);
+        Ptext.gram = 0;                                    // (gram ranks are the initial keys' business only)
+        s_sym = 0; tkb = 0;                            // symbols per round, bits of their packed key
+        {
+            const int room = 64 - g_bits;                   // bits left below the group head
+            s_sym = room / Ptext.bits;
+            if (s_sym > 64) s_sym = 64;
+            tkb = s_sym * Ptext.bits;
+        }
+        finished32 = false; fused64 = false;
+        if (top_shift && local_ok && !tn.no_fused_finish && !timing_only()) {
+            // fast finish of the 32-bit first stage: one pass orders every small group by its low key bits in place
+            // (k_finish_sorted); only if some group is too large for it does the general path below run instead
+            const int cap = tn.group_cap;
+            uint32_t *surv_bits = w.surv_bits, *surv_head = w.isa;  // (the ISA is not in use before the doubling rounds)
+            HIP_TRY(hipMemsetAsync(surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
+            HIP_TRY(hipMemsetAsync(w.tcnt, 0, (size_t)tiles * 4, st));
+            HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
+            HIP_TRY(hipMemsetAsync(w.total, 0, 16, st));
+            HIP_TRY(hipMemsetAsync(w.chg, 0, (size_t)RR_CHG_COUNTERS * 32 * 4, st));
+            KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
+            PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint32_t, KS_LOWKEY, false>), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS),
+                                                     0, st, sorted32, SA, dT, P, n, K, cap, surv_bits, surv_head, w.tcnt, w.total, (uint32_t *)nullptr,
+                                                     (uint32_t *)nullptr, (uint32_t *)nullptr));
+            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+            uint32_t cnt3[3] = { 0, 0, 0 };                       // still tied on 64 bits, members of groups nobody owned, tied on 32 bits
+            {
+                uint32_t words[64 + RR_CHG_COUNTERS * 32];         // (the tied-slot counts are spread over w.chg, directly behind w.total)
+                const int rcw = read_words(words, w.total, sizeof(words), st); if (rcw) return rcw;
+                cnt3[0] = words[0]; cnt3[1] = words[1];
+                for (int c = 0; c < RR_CHG_COUNTERS; ++c) cnt3[2] += words[64 + c * 32];
+            }
+            if (cnt3[1] == 0) {
+                finished32 = true;
+                m = cnt3[0];
+                local.locally_sorted += cnt3[2];
+                local.unresolved_after_initial = m;
+                if (m > 0) {
+                    PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_surv_compact), dim3((unsigned)tiles), dim3(256), 0, st, (const uint32_t *)surv_bits,
+                                                                (const uint32_t *)surv_head, (const uint32_t *)SA, n, (const uint32_t *)w.tcnt,
+                                                                (const uint32_t *)w.total, Ucur, Gcur, Vcur));
+                    rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+                    rkB = w.keysC;
+                    lists_ready = true;
+                }
+            }
+        }
+        // (SA_AMD_SPARSE_DIV moves the text-round / doubling boundary for the tests: then the general route decides, as before)
+        // Opt-in (SA_AMD_FUSED64=1): measured on C3 the one-pass round costs 8.2 ms against the 4.3 ms of k_group_sort on the tied
+        // list -- with 68 % of the slots tied the work list is six entries per thread -- and the whole build 31.0 instead of 28.8 ms.
+        if (!top_shift && text_ok && local_ok && s_sym > 0 && tn.fused64 && !tn.no_fused_finish && !tn.sparse_div_set && !timing_only()) {
+            // the first text-keyed round straight from the sorted keys (k_finish_sorted): groups of up to `cap` members are
+            // ordered in place by the next s_sym symbols, their still-tied members recorded by slot; the members of larger
+            // groups are listed (k_todo_compact) and take the general route (refine_list + re-rank), joining the same record;
+            // k_surv_compact then lists everything that is still tied, in slot order, for the second round
+            const int cap = tn.group_cap;
+            const int64_t ft_tiles = ceil_div(n, FT_TILE);
+            uint32_t *surv_head = w.isa;
+            HIP_TRY(hipMemsetAsync(w.surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
+            HIP_TRY(hipMemsetAsync(w.todo_bits, 0, ((size_t)n + 31) / 32 * 4, st));
+            HIP_TRY(hipMemsetAsync(w.ft_cnt, 0, (size_t)(ft_tiles + 1) * 4, st));
+            HIP_TRY(hipMemsetAsync(w.ft_head, 0, (size_t)(ft_tiles + 1) * 4, st));
+            HIP_TRY(hipMemsetAsync(w.surv_cnt, 0, (size_t)tiles * 4, st));
+            HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
+            HIP_TRY(hipMemsetAsync(w.total, 0, 32, st));
+            HIP_TRY(hipMemsetAsync(w.chg, 0, (size_t)RR_CHG_COUNTERS * 32 * 4, st));
+            KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
+            PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint64_t, KS_TEXT, true>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
+                                                     (const uint64_t *)sorted0, SA, dT, Ptext, n, K, cap, w.surv_bits, surv_head, w.surv_cnt, w.total,
+                                                     w.todo_bits, w.ft_cnt, w.ft_head));
+            PROF(KC_RR_SCAN, ft_tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, ft_tiles, w.total + 3));
+            uint32_t cnt4[4] = { 0, 0, 0, 0 };                    // [2] tied after the initial sort, [3] members left to the general route
+            {
+                uint32_t words[64 + RR_CHG_COUNTERS * 32];
+                const int rcw = read_words(words, w.total, sizeof(words), st); if (rcw) return rcw;
+                cnt4[0] = words[0]; cnt4[1] = words[1]; cnt4[3] = words[3];
+                for (int c = 0; c < RR_CHG_COUNTERS; ++c) cnt4[2] += words[64 + c * 32];
+            }
+            local.unresolved_after_initial = cnt4[2];
+            const int64_t m_todo = cnt4[3];
+            local.locally_sorted += (int64_t)cnt4[2] - m_todo;
+            rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+            rkB = w.keysC;
+            if (m_todo > 0) {
+                PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_todo_compact<uint64_t>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
+                                                            (const uint64_t *)sorted0, (const uint32_t *)SA, n, (const uint32_t *)w.todo_bits,
+                                                            (const uint32_t *)w.ft_cnt, (const uint32_t *)w.ft_head, (const uint32_t *)(w.total + 3),
+                                                            Ucur, Gcur, Vcur));
+                uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+                Refined rf;
+                bool big_local = true;                             // (large groups: the global sort does the work either way)
+                rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m_todo, n, dT, Ptext, K, g_bits, &big_local, w, st, &local, &rf, tn);
+                if (rc) return rc;
+                const int64_t tt = ceil_div(m_todo, RR_TILE);
+                PROF(KC_RR_COUNT, m_todo, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st, rf.keys,
+                                                            (const uint32_t *)Ucur, m_todo, w.ft_cnt, w.ft_head, 0, (uint32_t *)nullptr, 0));
+                PROF(KC_RR_SCAN, tt, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, tt, w.total + 4));
+                PROF(KC_RR_APPLY, m_todo, st, hipLaunchKernelGGL((k_rr_apply<false, true, 4>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st,
+                                                            rf.keys, rf.vals, (const uint32_t *)Ucur, m_todo, (const uint32_t *)w.ft_cnt,
+                                                            (const uint32_t *)w.ft_head, SA, surv_head, Unext, Gnext, rf.vnext, (uint32_t)n,
+                                                            w.surv_bits, 0, (uint64_t *)nullptr, w.surv_cnt, (const uint32_t *)(w.total + 4), 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
+            }
+            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.surv_cnt, w.thead, tiles, w.total));
+            { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+            m = m32;
+            Ucur = w.U0; Gcur = w.G0; Vcur = w.valsA; Unext = w.U1; Gnext = w.G1;
+            if (m > 0)
+                PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_surv_compact), dim3((unsigned)tiles), dim3(256), 0, st, (const uint32_t *)w.surv_bits,
+                                                            (const uint32_t *)surv_head, (const uint32_t *)SA, n, (const uint32_t *)w.surv_cnt,
+                                                            (const uint32_t *)w.total, Ucur, Gcur, Vcur));
+            fused64 = true;
+            lists_ready = true;
+            depth += s_sym;
+            local.text_rounds++;
+            local.rounds++;
+        }
+        return SA_AMD_OK;
+    }
+
+    // 4. group heads of the initial order: how many suffixes are still tied (read-back: that count)
+    int group_heads()
+    {
+        int rc = SA_AMD_OK; (void)rc;
+        if (!finished32 && !fused64) {
+        if (top_shift)
+            PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sorted32,
+                                                        (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
+        else
+            PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)sr.keys,
+                                                        (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+        { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+        m = m32;
+        local.unresolved_after_initial = m;
+        if (timing_only()) m = 0;   // diag library: ablation kernels produce wrong orders; stop here
+        }
+        return SA_AMD_OK;
+    }
+
+    // the suffixes tied on the top 32 key bits are ordered by their low key bits (read-back: tied on all 64 bits)
+    int finish_top32_ties()
+    {
+        int rc = SA_AMD_OK; (void)rc;
+        if (!finished32 && top_shift && m > 0) {
+            // finish the initial sort: the suffixes tied on the top 32 bits are ordered by their low key bits
+            rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+            rkB = w.keysC;
+            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        sorted32, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
+                                                        (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
+                                                        w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
+            uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+            Refined rf;
+            KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
+            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn);
+            if (rc) return rc;
+            tiles = ceil_div(m, RR_TILE);
+            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rf.keys,
+                                                        (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
+            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                        rf.keys, rf.vals, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
+                                                        (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, rf.vnext, (uint32_t)n,
+                                                        (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                                        (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
+            { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+            m = m32;
+            uint32_t *t;
+            t = Ucur; Ucur = Unext; Unext = t;
+            t = Gcur; Gcur = Gnext; Gnext = t;
+            Vcur = rf.vnext;
+            lists_ready = true;
+            local.unresolved_after_initial = m;           // now: tied on the whole 64-bit key, as after a full sort
+        }
+        return SA_AMD_OK;
+    }
+
+    // 5. dense route: ranks + ISA; otherwise compaction and the text-keyed rounds (read-back per round: tied count)
+    int rank_setup_and_text_rounds()
+    {
+        int rc = SA_AMD_OK; (void)rc;
+        // 5. refinement of the tied suffixes.  Three regimes:
+        //   text rounds  while more than n / SPARSE_DIV suffixes are tied: secondary key = the next symbols of
+        //                the text itself (no rank array needed yet), depth grows by s symbols per round;
+        //   sparse       few tied suffixes: prefix doubling, ranks looked up without an ISA (sparse_key2);
+        //   dense        prefix doubling with a full ISA (repetitive texts, or forced for A/B measurements).
+        key2_bits = bit_length((uint64_t)(2 * n));
+        const int64_t sparse_div = tn.sparse_div;      // (SA_AMD_SPARSE_DIV moves the boundary for tests / A-B)
+        const int64_t sparse_limit = n / sparse_div;
+        sparse = false;
+        const bool dense_first = m > 0 && !lists_ready && (force_dense || (!text_ok && m > sparse_limit) || (probe_dense && m > sparse_limit));
+        if (m > 0 && dense_first) {
+            // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
+            if (binned(n, n, tn)) {
+                uint64_t *pk = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+                PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                            SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
+                rc = scatter_binned((uint32_t *)pk, w.U1, (uint32_t *)sr.keys, w.G1, n, n, w, st, &local, tn);
+                if (rc) return rc;
+            } else {
+                PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                            SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0,
+                                                            (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
+            }
+        } else if (m > 0) {
+            // compaction only; the sorted initial keys stay intact for the rank look-ups
+            HIP_TRY(hipMemsetAsync(w.has_isa, 0, ((size_t)n + 31) / 32 * 4, st));
+            if (!lists_ready) {
+                rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+                rkB = w.keysC;
+                PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            (const uint64_t *)sorted0, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
+                                                            (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
+                                                            w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
+            }
+            // ---- text-keyed rounds ----
+            bool progressing = true;     // a text round that resolves little (runs, long repeats) is the last one
+
+            while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < tn.max_text_rounds && progressing) {
+                const int64_t m_before = m;
+                uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+                Refined rf;
+                KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
+                rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, Ptext, K, g_bits, &local_ok, w, st, &local, &rf, tn);
+                if (rc) return rc;
+                const uint64_t *keysS = rf.keys;                  // (group, text key) pairs ordered inside every group
+                const uint32_t *valsS = rf.vals;
+                uint32_t *Vnext = rf.vnext;
+                tiles = ceil_div(m, RR_TILE);
+                PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS,
+                                                            (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
+                PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            keysS, valsS, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
+                                                            (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                            (uint32_t)n, (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                                            (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
+                { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+                m = m32;
+                uint32_t *t;
+                t = Ucur; Ucur = Unext; Unext = t;
+                t = Gcur; Gcur = Gnext; Gnext = t;
+                Vcur = Vnext;
+                depth += s_sym;
+                local.text_rounds++;
+                local.rounds++;
+                progressing = m * 4 <= m_before * 3;
+                if (trace) fprintf(stderr, "suffix_array_amd: text round %d depth %lld: tied %lld -> %lld  (%.2f ms)\n", local.text_rounds, (long long)depth, (long long)m_before, (long long)m, lap());
+            }
+            if (m > sparse_limit) {
+                // still many ties (repetitive text): build the ISA of the current order and double densely
+                int64_t blocks = ceil_div(n, 256);
+                if (blocks > 16384) blocks = 16384;
+                if (binned(n, n, tn) && (((uintptr_t)dSA) & 15) == 0) {
+                    // inverse permutation without n random 4-byte stores: dSA[0 .. n] itself is the key array (dSA[0] = n, the
+                    // sentinel, is skipped by the scatter), the value is the index = rank; one 32-bit radix pass bins the pairs by
+                    // the top 8 bits of the suffix position, the scatter then works window by window (10.0 -> ~2.5 ms at 256 MiB)
+                    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);
+                    LAUNCH_CHECK(st);
+                    const size_t H = ((size_t)n + 1 + 3) & ~(size_t)3;      // keys in the first half of an 8(n + 64)-byte buffer, values in the second
+                    rc = scatter_binned(dSA, nullptr, (uint32_t *)rkB, (uint32_t *)rkB + H, n + 1, n, w, st, &local, tn, true,
+                                        (uint32_t *)rkA, (uint32_t *)rkA + H);
+                    if (rc) return rc;
+                } else
+                    PROF(KC_SCATTER, n, st, hipLaunchKernelGGL((k_isa_from_sa), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)SA, w.isa, n));
+                blocks = ceil_div(m, 256);
+                if (blocks > 16384) blocks = 16384;
+                PROF(KC_SCATTER, m, st, hipLaunchKernelGGL((k_isa_tied), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)Vcur,
+                                                           (const uint32_t *)Gcur, w.isa, m, n));
+            } else {
+                sparse = m > 0;
+            }
+        }
+        local.sparse_mode = sparse ? 1 : 0;
+        if (trace) fprintf(stderr, "suffix_array_amd: initial sort + text rounds + rank set-up done, %lld tied (%.2f ms since the last line)\n", (long long)m, lap());
+
+        return SA_AMD_OK;
+    }
+
+    // prefix doubling on what is still tied, dense (ISA) or sparse (read-backs per round: tied count, ranks written)
+    int doubling_rounds()
+    {
+        int rc = SA_AMD_OK; (void)rc;
+        // prefix doubling on what is still tied; `depth` symbols are sorted, so the first offset is `depth`
+        const int64_t depth_text = depth;
+        int64_t h = depth;
+        bool chase_ok = false;
+        int split_rest = 0;                               // rounds the three-way split sits out (refine_list)
+        bool parent_tail = false;                         // the ranks in the ISA are tail ranks (set by the first dense round)
+        int64_t changed_prev = 0;                         // ranks the last dense round wrote
+        int64_t m_local_off = m;                          // size of the tied list when the local pass was last in use
+        int rounds_local_off = 0;
+        while (m > 0) {
+            if (local.rounds >= 48) return SA_AMD_EINTERNAL;
+            uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
+            // the same refinement machinery as the text rounds, keyed by ranks -- small groups (a long repeat gives millions of
+            // pairs) are ordered in LDS, only large groups go through the global sort.  Dense: ranks from the ISA; sparse:
+            // looked up without one (sparse_key2)
+            KeySrc K = KeySrc();
+            K.mode = sparse ? KS_SPARSE : KS_RANK; K.h = h; K.kb = key2_bits; K.isa = w.isa;
+            // dense rounds chase (up to `chase` rank look-ups per member inside one launch) once a round has had no group left
+            // for the global sort: from then on every surviving group is known to share (iters + 1) * h symbols
+            // the local pass was given up because (nearly) every member sat in a group no tile can own: it is tried again when the
+            // list has halved, and every third round -- if refine_list then finds the average group small enough for a tile (large
+            // lists count their groups anyway; a Fibonacci word's groups shrink while the list does not, a periodic text's never do)
+            if (!local_ok && !tn.no_local_sort && m * 2 < m_local_off) local_ok = true;
+            const bool retry_local = !local_ok && ++rounds_local_off >= 3;
+            K.iters = (!sparse && local_ok && chase_ok) ? (m >= tn.chase_big_min ? tn.chase_big : tn.chase) : 1;
+            if (K.iters > 1) K.mode = KS_CHASE;
+            K.has_isa = w.has_isa; K.sorted_keys = sorted0; K.sorted_top32 = sorted32; K.sa = SA; K.depth = depth_text; K.top_shift = top_shift;
+            Refined rf;
+            if (local_ok) { m_local_off = m; rounds_local_off = 0; }
+            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn, retry_local, &split_rest);
+            if (rc) return rc;
+            if (retry_local && rf.m_global < m) { m_local_off = m; rounds_local_off = 0; }      // (the local pass ran again)
+            const uint64_t *keysS = rf.keys; const uint32_t *valsS = rf.vals; uint32_t *Vnext = rf.vnext;
+            tiles = ceil_div(m, RR_TILE);
+            // dense rounds: a group's rank is its last slot + 1 and a parent's last subgroup keeps it (k_rr_apply, TAIL); the tiles
+            // then also need the first group start BEHIND them (k_rr_scan_next)
+            if (sparse)
+                PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m, w.tcnt,
+                                   w.thead, 0, (uint32_t *)nullptr, 0));
+            else
+                PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false, uint64_t, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m,
+                                   w.tcnt, w.thead, 0, w.tnext, key2_bits));
+            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+            if (!sparse)
+                PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan_next), dim3(1), dim3(SPINE_THREADS), 0, st, w.tnext, tiles, w.chg));
+            // binned or direct ISA stores: by the number of ranks this round is expected to write -- all of them when the parents'
+            // ranks are not tail ranks yet, otherwise about as many as the round before wrote
+            const int64_t expect = (!parent_tail || m < changed_prev) ? m : changed_prev;
+            if (sparse) {
+                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                            (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
+            } else if (binned(n, expect, tn)) {
+                // Gcur has been consumed by the gather, the other key buffer by nothing: they take the pairs
+                uint64_t *pk = (keysS == rkA) ? rkB : rkA;
+                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                            (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total, 0,
+                                                            (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg));
+                // (only the ranks that change became pairs; their number is in the counters)
+                uint32_t chg[RR_CHG_COUNTERS * 32];
+                { const int rcw = read_words(chg, w.chg, sizeof(chg), st); if (rcw) return rcw; }
+                int64_t pairs = 0;
+                for (int c = 0; c < RR_CHG_COUNTERS; ++c) pairs += chg[c * 32];
+                if (pairs > 0) {
+                    rc = scatter_binned((uint32_t *)pk, Gcur, (uint32_t *)keysS, (uint32_t *)valsS, pairs, n, w, st, &local, tn);
+                    if (rc) return rc;
+                }
+            } else {
+                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                            (uint32_t)n, (uint32_t *)nullptr, key2_bits, (uint64_t *)nullptr,
+                                                            (uint32_t *)nullptr, (const uint32_t *)w.total, 0,
+                                                            (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg));
+            }
+            {
+                // w.total (64 words) and the changed-rank counters behind it (w.chg) in one read-back
+                uint32_t words[64 + RR_CHG_COUNTERS * 32];
+                const int rcw = read_words(words, w.total, sparse ? 4 : sizeof(words), st); if (rcw) return rcw;
+                m32 = words[0];
+                if (!sparse) {
+                    changed_prev = 0;
+                    for (int c = 0; c < RR_CHG_COUNTERS; ++c) changed_prev += words[64 + c * 32];
+                    parent_tail = true;
+                }
+            }
+            if (trace) fprintf(stderr, "suffix_array_amd: doubling round %d h %lld (%s, %d look-ups, %lld through the global sort): tied %lld -> %u, %lld ranks written\n", local.rounds + 1, (long long)h, sparse ? "sparse" : "dense", K.iters, (long long)rf.m_global, (long long)m, m32, sparse ? -1ll : (long long)changed_prev), fprintf(stderr, "    (%.2f ms)\n", lap());
+            m = m32;
+            uint32_t *t;
+            t = Ucur; Ucur = Unext; Unext = t;
+            t = Gcur; Gcur = Gnext; Gnext = t;
+            Vcur = Vnext;
+            // every group that is still tied went through K.iters look-ups -- unless some went through the global sort (one look-up)
+            h *= (K.iters > 1 && rf.m_global == 0) ? (int64_t)(K.iters + 1) : 2;
+            chase_ok = rf.m_global == 0;
+            local.rounds++;
+        }
+        return SA_AMD_OK;
+    }
+
+};
+
 static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWork, int64_t work_bytes, hipStream_t st,
                         sa_amd_stats *stats)
 {
     const int64_t n = n32;
-    const Tuning tn = Tuning::from_env(N_SORT_VARIANTS, N_SORT32_VARIANTS, N_OS_SHAPES64, N_OS_SHAPES32);
-    const bool trace = env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 3;      // one line per refinement round on stderr
-    double trace_t = now_ms();
-    auto lap = [&]() { const double t = now_ms(), d = t - trace_t; trace_t = t; return d; };
-    sa_amd_stats local;
-    memset(&local, 0, sizeof(local));
+    DeviceBuild B;
+    B.dT = dT; B.dSA = dSA; B.SA = dSA + 1; B.n = n; B.st = st;
+    B.tn = Tuning::from_env(N_SORT_VARIANTS, N_SORT32_VARIANTS, N_OS_SHAPES64, N_OS_SHAPES32);
+    B.trace = env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 3;      // one line per refinement round on stderr
+    B.trace_t = now_ms();
+    memset(&B.local, 0, sizeof(B.local));
+    const Tuning &tn = B.tn;
+    sa_amd_stats &local = B.local;
     if (n == 0) {
         PROF(KC_MISC, 1, st, hipLaunchKernelGGL((k_set_u32), dim3(1), dim3(1), 0, st, dSA, 0u));
         HIP_TRY(hipStreamSynchronize(st));
         if (stats) *stats = local;
         return SA_AMD_OK;
     }
-    Workspace w = carve(dWork, n);
+    B.w = carve(dWork, n);
+    const Workspace &w = B.w;
     if ((int64_t)w.bytes > work_bytes) return SA_AMD_EINVAL;
     if (n <= tn.small_max) {
         // small texts: the whole construction in one launch of one workgroup, everything in LDS (kernels/small.hpp)
@@ -859,514 +1451,15 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         if (stats) *stats = local;
         return SA_AMD_OK;
     }
-    uint32_t *SA = dSA + 1;
     HIP_TRY(hipMemsetAsync(w.os_err, 0, 16, st));          // look-back give-ups of the single-pass scatter: checked at the end
-
-    // 1. sigma = 256 histogram -> symbol codes, bits per symbol, symbols per key
-    HIP_TRY(hipMemsetAsync(w.hist, 0, 256 * 4, st));
-    {
-        int64_t blocks = ceil_div(ceil_div(n, 16), BH_THREADS);
-        if (blocks > 2048) blocks = 2048;
-        if (blocks < 1) blocks = 1;
-        PROF(KC_BYTE_HIST, n, st, hipLaunchKernelGGL((k_byte_hist), dim3((unsigned)blocks), dim3(BH_THREADS), 0, st, dT, n, w.hist));
-    }
-    uint32_t hist[256];
-    { const int rcw = read_words(hist, w.hist, sizeof(hist), st); if (rcw) return rcw; }
-    KeyParams P;
-    int sigma;
-    int key_bits = make_key_params(hist, &P, &sigma, tn.key_bits_max);      // (gram keys, step 2c, may shorten it)
-    local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
-
-    const int g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
-    const bool force_dense = tn.force_dense;
-    const bool text_ok = !force_dense && !tn.no_text_rounds;
-    bool local_ok = !tn.no_local_sort;
-
-    // 2. entropy probe: do the top 32 key bits already separate (almost) all suffixes?  Then the initial
-    //    sort only needs those 4 digits and a cheap round on the low bits finishes the few ties.
-    int top_shift = 0;
-    if (text_ok && local_ok && key_bits > 32 && !tn.no_top32) {
-        bool use = tn.force_top32;
-        if (!use && n >= ((int64_t)1 << 24)) {
-            const int64_t S = (int64_t)1 << 20;
-            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_keys), dim3((unsigned)ceil_div(S, GK_THREADS)), dim3(GK_THREADS), 0, st, dT, P, n, S,
-                                                    key_bits - 32, w.keysA));
-            // duplicates counted in a hash table (4 entries per sample, in the other key buffer) instead of sorting the sample
-            const uint32_t H = (uint32_t)S * 4u;
-            HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
-            HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
-            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
-                                                    (unsigned long long *)w.keysB, H - 1u, w.total));
-            uint32_t dups = 0;
-            { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
-            // c - 1 per value seen c times under-counts pairs only when values repeat often, which is the
-            // "do not" case anyway; expected number of other suffixes sharing the top bits with a given one:
-            const double q = 2.0 * (double)dups / ((double)S * (double)S);
-            use = (double)n * q < 0.5;
-        }
-        if (use) top_shift = key_bits - 32;
-    }
-    local.top32_first = top_shift ? 1 : 0;
-    // 2b. repeat probe (texts the first probe did not send to the 32-bit route): the fraction of suffixes that share
-    //     2k symbols with another suffix.  Many (copied passages, a corpus): the text-keyed rounds cannot finish, so rank
-    //     doubling starts right after the initial sort (measured on C3: 64 ms against 68 ms); few: text-keyed rounds.
-    bool probe_dense = false;
-    if (text_ok && local_ok && !top_shift && !force_dense && !tn.no_repeat_probe && n >= ((int64_t)1 << 24)) {
-        const int64_t S = (int64_t)1 << 20;
-        PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_repeat_keys), dim3((unsigned)ceil_div(S, GK_THREADS)), dim3(GK_THREADS), 0, st, dT, P, n, S,
-                                                w.keysA));
-        const uint32_t H = (uint32_t)S * 4u;
-        HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
-        HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
-        PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
-                                                (unsigned long long *)w.keysB, H - 1u, w.total));
-        uint32_t dups = 0;
-        { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
-        const double chance = (double)S * (double)S / 8589934592.0;           // 32-bit hash collisions among S samples
-        const double frac = ((double)dups - chance) * (double)n / ((double)S * (double)S);
-        probe_dense = frac > 0.04;
-        if (trace) fprintf(stderr, "suffix_array_amd: repeat probe: %u duplicates among %lld samples (repeat index %.3f, threshold 0.04) -> %s\n",
-                           dups, (long long)S, frac, probe_dense ? "rank doubling from the start" : "text-keyed rounds");
-    }
-
-    // 2c. gram keys (texts that did not take the 32-bit route): choose_gram_keys measures and decides; the probes above keep
-    //     using the plain key
-    if (!top_shift && !tn.no_gram_keys && n >= tn.gram_min_n && n >= 2 && sigma >= 2 && tn.key_bits_max == 64) {
-        const int rcg = choose_gram_keys(dT, n, &P, &key_bits, w, st, tn, trace);
-        if (rcg) return rcg;
-        local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
-    }
-
-    // 3. packed keys, 4. initial sort: all key bits as (u64 key, u32 suffix) pairs, or only the top 32 bits as
-    //    (u32, u32) pairs in 12 Ki-element tiles -- two thirds of the bytes per pass and half the passes
-    SortResult sr;
-    sr.keys = w.keysA; sr.vals = w.valsA; sr.passes = 0;
-    const uint32_t *sorted32 = nullptr;               // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
     int rc;
-    // value of pair i = i: not stored by k_build_keys, the first sort pass takes the index (saves 8 B / suffix)
-    const bool iota = n >= 2 && key_bits > 0;
-    uint32_t *vals0 = iota ? (uint32_t *)nullptr : w.valsA;
-    // alphabets of 2, 4 or 16 symbols: k_build_keys also writes the text as bit-packed codes, which every later random
-    // read of the text uses instead (a key becomes a bit field of two words; DNA shrinks to a quarter: cache-resident)
-    uint8_t *packed_out = nullptr;
-    if ((P.bits == 1 || P.bits == 2 || P.bits == 4) && n >= 64 && !tn.no_packed_text) {
-        packed_out = w.packed;
-        HIP_TRY(hipMemsetAsync(packed_out + (size_t)(n >> 3) * P.bits, 0, 64, st));     // the padding behind the last whole group
-    }
-    if (top_shift) {
-        uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
-        // the first radix pass's digit histogram comes out of k_build_keys (keys in registers there): one read of every key less
-        const FirstCounts fc = sort_first_counts(w.ss, tn, n, true);
-        const bool counted = n > 1;
-        if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
-        PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
-                                                      (uint64_t *)nullptr, vals0, k32a, top_shift, packed_out,
-                                                      counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, 0xffu));
-        SortResult32 s32;
-        rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.ss, SA, st, &s32, tn, iota, counted);
-        if (rc) return rc;
-        local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
-        sorted32 = s32.keys;
-        sr.vals = s32.vals; sr.passes = s32.passes;
-        sr.keys = (s32.keys == k32a) ? w.keysA : w.keysB;      // the 8n-byte buffer that now holds the sorted 32-bit keys
-    } else {
-        const FirstCounts fc = sort_first_counts(w.ss, tn, n, false);
-        const bool counted = n > 1 && key_bits > 0;
-        const int nb0 = key_bits < RADIX_BITS ? key_bits : RADIX_BITS;
-        if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
-        if (P.gram > 0)
-            PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false, true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
-                                                          w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
-                                                          counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, (1u << nb0) - 1u));
-        else
-            PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
-                                                          w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out,
-                                                          counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, (1u << nb0) - 1u));
-        // (a text of ONE byte value -- a zero-filled file -- has the same key everywhere but at its end: its passes are the identity
-        // and are looked for; any other text does not pay the read-backs)
-        rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.ss, SA, st, &sr, tn, iota, sigma == 1, counted);
-        if (rc) return rc;
-        local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
-    }
-    P.packed = packed_out;
-    if (sr.vals != SA) {   // n == 1: no pass ran, the values are still in the input buffer
-        PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_copy_u32), dim3(1), dim3(256), 0, st, sr.vals, SA, n));
-    }
-
-    // 4. group heads of the initial order; how many suffixes are still tied with a neighbour
-    uint32_t *Ucur = w.U0, *Unext = w.U1, *Gcur = w.G0, *Gnext = w.G1;
-    uint32_t *Vcur = w.valsA;
-    int64_t tiles = ceil_div(n, RR_TILE);
-    uint32_t m32 = 0;
-    int64_t m = 0;
-    uint64_t *rkA = w.keysA, *rkB = w.keysB;          // key buffers of the refinement rounds
-    uint64_t *sorted0 = sr.keys;                      // the initial keys in SA order (kept for the rank look-ups)
-    bool lists_ready = false;                         // (Ucur, Gcur, Vcur) already hold the tied suffixes
-    int64_t depth = P.k;                               // symbols the current order is sorted by
-    // Text-keyed rounds pack their symbols as bit fields of ceil(log2 sigma) bits whatever the alphabet: a secondary key only
-    // has to preserve the order inside one round, and the base-sigma form costs a 64-bit multiply per symbol in kernels
-    // that are instruction-bound (k_group_sort: 26 ps per suffix however small the text).  English-like sigma = 56: six
-    // symbols in 36 bits either way.
-    KeyParams Ptext = P;
-    if (P.bits == 0) Ptext.bits = bit_length(P.sigma - 1);
-    Ptext.gram = 0;                                    // (gram ranks are the initial keys' business only)
-    int s_sym = 0, tkb = 0;                            // symbols per round, bits of their packed key
-    {
-        const int room = 64 - g_bits;                   // bits left below the group head
-        s_sym = room / Ptext.bits;
-        if (s_sym > 64) s_sym = 64;
-        tkb = s_sym * Ptext.bits;
-    }
-    bool finished32 = false, fused64 = false;
-#ifdef SA_AMD_DIAG
-    const bool timing_only = tn.timing_only_initial_sort;       // diag library only: stop after the initial sort (array NOT finished)
-#else
-    constexpr bool timing_only = false;
-#endif
-    if (top_shift && local_ok && !tn.no_fused_finish && !timing_only) {
-        // fast finish of the 32-bit first stage: one pass orders every small group by its low key bits in place
-        // (k_finish_sorted); only if some group is too large for it does the general path below run instead
-        const int cap = tn.group_cap;
-        uint32_t *surv_bits = w.surv_bits, *surv_head = w.isa;  // (the ISA is not in use before the doubling rounds)
-        HIP_TRY(hipMemsetAsync(surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
-        HIP_TRY(hipMemsetAsync(w.tcnt, 0, (size_t)tiles * 4, st));
-        HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
-        HIP_TRY(hipMemsetAsync(w.total, 0, 16, st));
-        HIP_TRY(hipMemsetAsync(w.chg, 0, (size_t)RR_CHG_COUNTERS * 32 * 4, st));
-        KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
-        PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint32_t, KS_LOWKEY, false>), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS),
-                                                 0, st, sorted32, SA, dT, P, n, K, cap, surv_bits, surv_head, w.tcnt, w.total, (uint32_t *)nullptr,
-                                                 (uint32_t *)nullptr, (uint32_t *)nullptr));
-        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-        uint32_t cnt3[3] = { 0, 0, 0 };                       // still tied on 64 bits, members of groups nobody owned, tied on 32 bits
-        {
-            uint32_t words[64 + RR_CHG_COUNTERS * 32];         // (the tied-slot counts are spread over w.chg, directly behind w.total)
-            const int rcw = read_words(words, w.total, sizeof(words), st); if (rcw) return rcw;
-            cnt3[0] = words[0]; cnt3[1] = words[1];
-            for (int c = 0; c < RR_CHG_COUNTERS; ++c) cnt3[2] += words[64 + c * 32];
-        }
-        if (cnt3[1] == 0) {
-            finished32 = true;
-            m = cnt3[0];
-            local.locally_sorted += cnt3[2];
-            local.unresolved_after_initial = m;
-            if (m > 0) {
-                PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_surv_compact), dim3((unsigned)tiles), dim3(256), 0, st, (const uint32_t *)surv_bits,
-                                                            (const uint32_t *)surv_head, (const uint32_t *)SA, n, (const uint32_t *)w.tcnt,
-                                                            (const uint32_t *)w.total, Ucur, Gcur, Vcur));
-                rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
-                rkB = w.keysC;
-                lists_ready = true;
-            }
-        }
-    }
-    // (SA_AMD_SPARSE_DIV moves the text-round / doubling boundary for the tests: then the general route decides, as before)
-    // Opt-in (SA_AMD_FUSED64=1): measured on C3 the one-pass round costs 8.2 ms against the 4.3 ms of k_group_sort on the tied
-    // list -- with 68 % of the slots tied the work list is six entries per thread -- and the whole build 31.0 instead of 28.8 ms.
-    if (!top_shift && text_ok && local_ok && s_sym > 0 && tn.fused64 && !tn.no_fused_finish && !tn.sparse_div_set && !timing_only) {
-        // the first text-keyed round straight from the sorted keys (k_finish_sorted): groups of up to `cap` members are
-        // ordered in place by the next s_sym symbols, their still-tied members recorded by slot; the members of larger
-        // groups are listed (k_todo_compact) and take the general route (refine_list + re-rank), joining the same record;
-        // k_surv_compact then lists everything that is still tied, in slot order, for the second round
-        const int cap = tn.group_cap;
-        const int64_t ft_tiles = ceil_div(n, FT_TILE);
-        uint32_t *surv_head = w.isa;
-        HIP_TRY(hipMemsetAsync(w.surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
-        HIP_TRY(hipMemsetAsync(w.todo_bits, 0, ((size_t)n + 31) / 32 * 4, st));
-        HIP_TRY(hipMemsetAsync(w.ft_cnt, 0, (size_t)(ft_tiles + 1) * 4, st));
-        HIP_TRY(hipMemsetAsync(w.ft_head, 0, (size_t)(ft_tiles + 1) * 4, st));
-        HIP_TRY(hipMemsetAsync(w.surv_cnt, 0, (size_t)tiles * 4, st));
-        HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
-        HIP_TRY(hipMemsetAsync(w.total, 0, 32, st));
-        HIP_TRY(hipMemsetAsync(w.chg, 0, (size_t)RR_CHG_COUNTERS * 32 * 4, st));
-        KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
-        PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint64_t, KS_TEXT, true>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
-                                                 (const uint64_t *)sorted0, SA, dT, Ptext, n, K, cap, w.surv_bits, surv_head, w.surv_cnt, w.total,
-                                                 w.todo_bits, w.ft_cnt, w.ft_head));
-        PROF(KC_RR_SCAN, ft_tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, ft_tiles, w.total + 3));
-        uint32_t cnt4[4] = { 0, 0, 0, 0 };                    // [2] tied after the initial sort, [3] members left to the general route
-        {
-            uint32_t words[64 + RR_CHG_COUNTERS * 32];
-            const int rcw = read_words(words, w.total, sizeof(words), st); if (rcw) return rcw;
-            cnt4[0] = words[0]; cnt4[1] = words[1]; cnt4[3] = words[3];
-            for (int c = 0; c < RR_CHG_COUNTERS; ++c) cnt4[2] += words[64 + c * 32];
-        }
-        local.unresolved_after_initial = cnt4[2];
-        const int64_t m_todo = cnt4[3];
-        local.locally_sorted += (int64_t)cnt4[2] - m_todo;
-        rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
-        rkB = w.keysC;
-        if (m_todo > 0) {
-            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_todo_compact<uint64_t>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
-                                                        (const uint64_t *)sorted0, (const uint32_t *)SA, n, (const uint32_t *)w.todo_bits,
-                                                        (const uint32_t *)w.ft_cnt, (const uint32_t *)w.ft_head, (const uint32_t *)(w.total + 3),
-                                                        Ucur, Gcur, Vcur));
-            uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
-            Refined rf;
-            bool big_local = true;                             // (large groups: the global sort does the work either way)
-            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m_todo, n, dT, Ptext, K, g_bits, &big_local, w, st, &local, &rf, tn);
-            if (rc) return rc;
-            const int64_t tt = ceil_div(m_todo, RR_TILE);
-            PROF(KC_RR_COUNT, m_todo, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st, rf.keys,
-                                                        (const uint32_t *)Ucur, m_todo, w.ft_cnt, w.ft_head, 0, (uint32_t *)nullptr, 0));
-            PROF(KC_RR_SCAN, tt, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, tt, w.total + 4));
-            PROF(KC_RR_APPLY, m_todo, st, hipLaunchKernelGGL((k_rr_apply<false, true, 4>), dim3((unsigned)tt), dim3(RR_THREADS), 0, st,
-                                                        rf.keys, rf.vals, (const uint32_t *)Ucur, m_todo, (const uint32_t *)w.ft_cnt,
-                                                        (const uint32_t *)w.ft_head, SA, surv_head, Unext, Gnext, rf.vnext, (uint32_t)n,
-                                                        w.surv_bits, 0, (uint64_t *)nullptr, w.surv_cnt, (const uint32_t *)(w.total + 4), 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
-        }
-        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.surv_cnt, w.thead, tiles, w.total));
-        { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
-        m = m32;
-        Ucur = w.U0; Gcur = w.G0; Vcur = w.valsA; Unext = w.U1; Gnext = w.G1;
-        if (m > 0)
-            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_surv_compact), dim3((unsigned)tiles), dim3(256), 0, st, (const uint32_t *)w.surv_bits,
-                                                        (const uint32_t *)surv_head, (const uint32_t *)SA, n, (const uint32_t *)w.surv_cnt,
-                                                        (const uint32_t *)w.total, Ucur, Gcur, Vcur));
-        fused64 = true;
-        lists_ready = true;
-        depth += s_sym;
-        local.text_rounds++;
-        local.rounds++;
-    }
-    if (!finished32 && !fused64) {
-    if (top_shift)
-        PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sorted32,
-                                                    (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
-    else
-        PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)sr.keys,
-                                                    (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
-    PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-    { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
-    m = m32;
-    local.unresolved_after_initial = m;
-    if (timing_only) m = 0;   // diag library: ablation kernels produce wrong orders; stop here
-    }
-    if (!finished32 && top_shift && m > 0) {
-        // finish the initial sort: the suffixes tied on the top 32 bits are ordered by their low key bits
-        rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
-        rkB = w.keysC;
-        PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                    sorted32, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
-                                                    (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
-                                                    w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
-        uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
-        Refined rf;
-        KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
-        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn);
-        if (rc) return rc;
-        tiles = ceil_div(m, RR_TILE);
-        PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rf.keys,
-                                                    (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
-        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-        PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                    rf.keys, rf.vals, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
-                                                    (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, rf.vnext, (uint32_t)n,
-                                                    (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
-                                                    (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
-        { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
-        m = m32;
-        uint32_t *t;
-        t = Ucur; Ucur = Unext; Unext = t;
-        t = Gcur; Gcur = Gnext; Gnext = t;
-        Vcur = rf.vnext;
-        lists_ready = true;
-        local.unresolved_after_initial = m;           // now: tied on the whole 64-bit key, as after a full sort
-    }
-    // 5. refinement of the tied suffixes.  Three regimes:
-    //   text rounds  while more than n / SPARSE_DIV suffixes are tied: secondary key = the next symbols of
-    //                the text itself (no rank array needed yet), depth grows by s symbols per round;
-    //   sparse       few tied suffixes: prefix doubling, ranks looked up without an ISA (sparse_key2);
-    //   dense        prefix doubling with a full ISA (repetitive texts, or forced for A/B measurements).
-    const int key2_bits = bit_length((uint64_t)(2 * n));
-    const int64_t sparse_div = tn.sparse_div;      // (SA_AMD_SPARSE_DIV moves the boundary for tests / A-B)
-    const int64_t sparse_limit = n / sparse_div;
-    bool sparse = false;
-    const bool dense_first = m > 0 && !lists_ready && (force_dense || (!text_ok && m > sparse_limit) || (probe_dense && m > sparse_limit));
-    if (m > 0 && dense_first) {
-        // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
-        if (binned(n, n, tn)) {
-            uint64_t *pk = (sr.keys == w.keysA) ? w.keysB : w.keysA;
-            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                        sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
-            rc = scatter_binned((uint32_t *)pk, w.U1, (uint32_t *)sr.keys, w.G1, n, n, w, st, &local, tn);
-            if (rc) return rc;
-        } else {
-            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                        sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
-                                                        SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0,
-                                                        (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
-        }
-    } else if (m > 0) {
-        // compaction only; the sorted initial keys stay intact for the rank look-ups
-        HIP_TRY(hipMemsetAsync(w.has_isa, 0, ((size_t)n + 31) / 32 * 4, st));
-        if (!lists_ready) {
-            rkA = (sr.keys == w.keysA) ? w.keysB : w.keysA;
-            rkB = w.keysC;
-            PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                        (const uint64_t *)sorted0, (const uint32_t *)SA, (const uint32_t *)nullptr, n,
-                                                        (const uint32_t *)w.tcnt, (const uint32_t *)w.thead, SA, w.isa, Ucur, Gcur, Vcur, 0u,
-                                                        w.has_isa, 0, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
-        }
-        // ---- text-keyed rounds ----
-        bool progressing = true;     // a text round that resolves little (runs, long repeats) is the last one
-
-        while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < tn.max_text_rounds && progressing) {
-            const int64_t m_before = m;
-            uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
-            Refined rf;
-            KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
-            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, Ptext, K, g_bits, &local_ok, w, st, &local, &rf, tn);
-            if (rc) return rc;
-            const uint64_t *keysS = rf.keys;                  // (group, text key) pairs ordered inside every group
-            const uint32_t *valsS = rf.vals;
-            uint32_t *Vnext = rf.vnext;
-            tiles = ceil_div(m, RR_TILE);
-            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS,
-                                                        (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
-            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                        keysS, valsS, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
-                                                        (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
-                                                        (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
-            { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
-            m = m32;
-            uint32_t *t;
-            t = Ucur; Ucur = Unext; Unext = t;
-            t = Gcur; Gcur = Gnext; Gnext = t;
-            Vcur = Vnext;
-            depth += s_sym;
-            local.text_rounds++;
-            local.rounds++;
-            progressing = m * 4 <= m_before * 3;
-            if (trace) fprintf(stderr, "suffix_array_amd: text round %d depth %lld: tied %lld -> %lld  (%.2f ms)\n", local.text_rounds, (long long)depth, (long long)m_before, (long long)m, lap());
-        }
-        if (m > sparse_limit) {
-            // still many ties (repetitive text): build the ISA of the current order and double densely
-            int64_t blocks = ceil_div(n, 256);
-            if (blocks > 16384) blocks = 16384;
-            if (binned(n, n, tn) && (((uintptr_t)dSA) & 15) == 0) {
-                // inverse permutation without n random 4-byte stores: dSA[0 .. n] itself is the key array (dSA[0] = n, the
-                // sentinel, is skipped by the scatter), the value is the index = rank; one 32-bit radix pass bins the pairs by
-                // the top 8 bits of the suffix position, the scatter then works window by window (10.0 -> ~2.5 ms at 256 MiB)
-                hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);
-                LAUNCH_CHECK(st);
-                const size_t H = ((size_t)n + 1 + 3) & ~(size_t)3;      // keys in the first half of an 8(n + 64)-byte buffer, values in the second
-                rc = scatter_binned(dSA, nullptr, (uint32_t *)rkB, (uint32_t *)rkB + H, n + 1, n, w, st, &local, tn, true,
-                                    (uint32_t *)rkA, (uint32_t *)rkA + H);
-                if (rc) return rc;
-            } else
-                PROF(KC_SCATTER, n, st, hipLaunchKernelGGL((k_isa_from_sa), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)SA, w.isa, n));
-            blocks = ceil_div(m, 256);
-            if (blocks > 16384) blocks = 16384;
-            PROF(KC_SCATTER, m, st, hipLaunchKernelGGL((k_isa_tied), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)Vcur,
-                                                       (const uint32_t *)Gcur, w.isa, m, n));
-        } else {
-            sparse = m > 0;
-        }
-    }
-    local.sparse_mode = sparse ? 1 : 0;
-    if (trace) fprintf(stderr, "suffix_array_amd: initial sort + text rounds + rank set-up done, %lld tied (%.2f ms since the last line)\n", (long long)m, lap());
-
-    // prefix doubling on what is still tied; `depth` symbols are sorted, so the first offset is `depth`
-    const int64_t depth_text = depth;
-    int64_t h = depth;
-    bool chase_ok = false;
-    int split_rest = 0;                               // rounds the three-way split sits out (refine_list)
-    bool parent_tail = false;                         // the ranks in the ISA are tail ranks (set by the first dense round)
-    int64_t changed_prev = 0;                         // ranks the last dense round wrote
-    int64_t m_local_off = m;                          // size of the tied list when the local pass was last in use
-    int rounds_local_off = 0;
-    while (m > 0) {
-        if (local.rounds >= 48) return SA_AMD_EINTERNAL;
-        uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
-        // the same refinement machinery as the text rounds, keyed by ranks -- small groups (a long repeat gives millions of
-        // pairs) are ordered in LDS, only large groups go through the global sort.  Dense: ranks from the ISA; sparse:
-        // looked up without one (sparse_key2)
-        KeySrc K = KeySrc();
-        K.mode = sparse ? KS_SPARSE : KS_RANK; K.h = h; K.kb = key2_bits; K.isa = w.isa;
-        // dense rounds chase (up to `chase` rank look-ups per member inside one launch) once a round has had no group left
-        // for the global sort: from then on every surviving group is known to share (iters + 1) * h symbols
-        // the local pass was given up because (nearly) every member sat in a group no tile can own: it is tried again when the
-        // list has halved, and every third round -- if refine_list then finds the average group small enough for a tile (large
-        // lists count their groups anyway; a Fibonacci word's groups shrink while the list does not, a periodic text's never do)
-        if (!local_ok && !tn.no_local_sort && m * 2 < m_local_off) local_ok = true;
-        const bool retry_local = !local_ok && ++rounds_local_off >= 3;
-        K.iters = (!sparse && local_ok && chase_ok) ? (m >= tn.chase_big_min ? tn.chase_big : tn.chase) : 1;
-        if (K.iters > 1) K.mode = KS_CHASE;
-        K.has_isa = w.has_isa; K.sorted_keys = sorted0; K.sorted_top32 = sorted32; K.sa = SA; K.depth = depth_text; K.top_shift = top_shift;
-        Refined rf;
-        if (local_ok) { m_local_off = m; rounds_local_off = 0; }
-        rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn, retry_local, &split_rest);
-        if (rc) return rc;
-        if (retry_local && rf.m_global < m) { m_local_off = m; rounds_local_off = 0; }      // (the local pass ran again)
-        const uint64_t *keysS = rf.keys; const uint32_t *valsS = rf.vals; uint32_t *Vnext = rf.vnext;
-        tiles = ceil_div(m, RR_TILE);
-        // dense rounds: a group's rank is its last slot + 1 and a parent's last subgroup keeps it (k_rr_apply, TAIL); the tiles
-        // then also need the first group start BEHIND them (k_rr_scan_next)
-        if (sparse)
-            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m, w.tcnt,
-                               w.thead, 0, (uint32_t *)nullptr, 0));
-        else
-            PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false, uint64_t, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m,
-                               w.tcnt, w.thead, 0, w.tnext, key2_bits));
-        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-        if (!sparse)
-            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan_next), dim3(1), dim3(SPINE_THREADS), 0, st, w.tnext, tiles, w.chg));
-        // binned or direct ISA stores: by the number of ranks this round is expected to write -- all of them when the parents'
-        // ranks are not tail ranks yet, otherwise about as many as the round before wrote
-        const int64_t expect = (!parent_tail || m < changed_prev) ? m : changed_prev;
-        if (sparse) {
-            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                        keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
-        } else if (binned(n, expect, tn)) {
-            // Gcur has been consumed by the gather, the other key buffer by nothing: they take the pairs
-            uint64_t *pk = (keysS == rkA) ? rkB : rkA;
-            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                        keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total, 0,
-                                                        (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg));
-            // (only the ranks that change became pairs; their number is in the counters)
-            uint32_t chg[RR_CHG_COUNTERS * 32];
-            { const int rcw = read_words(chg, w.chg, sizeof(chg), st); if (rcw) return rcw; }
-            int64_t pairs = 0;
-            for (int c = 0; c < RR_CHG_COUNTERS; ++c) pairs += chg[c * 32];
-            if (pairs > 0) {
-                rc = scatter_binned((uint32_t *)pk, Gcur, (uint32_t *)keysS, (uint32_t *)valsS, pairs, n, w, st, &local, tn);
-                if (rc) return rc;
-            }
-        } else {
-            PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                        keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                        (uint32_t)n, (uint32_t *)nullptr, key2_bits, (uint64_t *)nullptr,
-                                                        (uint32_t *)nullptr, (const uint32_t *)w.total, 0,
-                                                        (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg));
-        }
-        {
-            // w.total (64 words) and the changed-rank counters behind it (w.chg) in one read-back
-            uint32_t words[64 + RR_CHG_COUNTERS * 32];
-            const int rcw = read_words(words, w.total, sparse ? 4 : sizeof(words), st); if (rcw) return rcw;
-            m32 = words[0];
-            if (!sparse) {
-                changed_prev = 0;
-                for (int c = 0; c < RR_CHG_COUNTERS; ++c) changed_prev += words[64 + c * 32];
-                parent_tail = true;
-            }
-        }
-        if (trace) fprintf(stderr, "suffix_array_amd: doubling round %d h %lld (%s, %d look-ups, %lld through the global sort): tied %lld -> %u, %lld ranks written\n", local.rounds + 1, (long long)h, sparse ? "sparse" : "dense", K.iters, (long long)rf.m_global, (long long)m, m32, sparse ? -1ll : (long long)changed_prev), fprintf(stderr, "    (%.2f ms)\n", lap());
-        m = m32;
-        uint32_t *t;
-        t = Ucur; Ucur = Unext; Unext = t;
-        t = Gcur; Gcur = Gnext; Gnext = t;
-        Vcur = Vnext;
-        // every group that is still tied went through K.iters look-ups -- unless some went through the global sort (one look-up)
-        h *= (K.iters > 1 && rf.m_global == 0) ? (int64_t)(K.iters + 1) : 2;
-        chase_ok = rf.m_global == 0;
-        local.rounds++;
-    }
+    if ((rc = B.geometry_and_probes())) return rc;
+    if ((rc = B.initial_sort())) return rc;
+    if ((rc = B.first_round_from_sorted_keys())) return rc;
+    if ((rc = B.group_heads())) return rc;
+    if ((rc = B.finish_top32_ties())) return rc;
+    if ((rc = B.rank_setup_and_text_rounds())) return rc;
+    if ((rc = B.doubling_rounds())) return rc;
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);   // reference src/saca.rs:13
     LAUNCH_CHECK(st);
     {

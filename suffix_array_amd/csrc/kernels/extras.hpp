@@ -244,6 +244,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_batch(
         lo = bkt[(int)pat[0] * 257]; hi = bkt[(int)pat[0] * 257 + 257];
     }
     const int64_t bucket_hi = hi;
+    const bool empty_bucket = bkt != nullptr && plen > 0 && lo == hi;      // (search_lcp below: reference src/sa.rs:211-222)
     // search_all, first loop (reference src/sa.rs:182-190): first i with !(pat > s[sa[i]..])
     while (lo < hi) {
         const int64_t m = lo + (hi - lo) / 2;
@@ -259,7 +260,13 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_batch(
     const int64_t j = lo2;
     // search_lcp without buckets (src/sa.rs:207-253): i is also the insertion point of pat
     uint32_t ls = (uint32_t)n, ll = 0;
-    {
+    if (empty_bucket) {
+        // With a bucket table the reference searches the pattern's (c0, c1) bucket only; when that is empty no suffix shares
+        // two bytes with the pattern and it answers with the FIRST suffix of the top-level bucket of c0 (one common byte),
+        // or s.len()..s.len() when that is empty too (src/sa.rs:211-222) -- not with the neighbour of the insertion point.
+        const int64_t tlo = bkt[(int)pat[0] * 257], thi = bkt[(int)pat[0] * 257 + 257];
+        if (thi > tlo) { ls = SA[tlo]; ll = 1; }
+    } else {
         SuffixCmp cb; cb.ord = 1; cb.lcp = 0;
         if (i < len) cb = wave_compare(T, n, (int64_t)SA[i], pat, plen);
         if (i < len && cb.ord == 0) { ls = SA[i]; ll = (uint32_t)(n - (int64_t)SA[i]); }            // Ok(i): start..s.len()

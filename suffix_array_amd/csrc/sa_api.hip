@@ -108,11 +108,13 @@ SA_EXPORT int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n
 
 SA_EXPORT int32_t sa_amd_bucket_table_device(const uint8_t *dT, const uint32_t *dSA, int32_t n, uint32_t *dBkt, void *stream)
 {
+    SA_ABI_GUARD_BEGIN
     if (n < 0 || !dSA || !dBkt || (n > 0 && !dT)) return SA_AMD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sa::k_bucket_table, dim3((sa::BKT_LEN + 255) / 256), dim3(256), 0, st, dT, dSA, (int64_t)n, dBkt);
     if (hipGetLastError() != hipSuccess) return SA_AMD_EHIP;
     return hipStreamSynchronize(st) == hipSuccess ? SA_AMD_OK : SA_AMD_EHIP;
+    SA_ABI_GUARD_END(0)
 }
 
 // layout of the larger work block (fast form): flags | rank | four pair buffers | spine + digit totals | granules + error word
@@ -314,7 +316,7 @@ SA_EXPORT int32_t sa_amd_index_create(const uint8_t *T, int32_t n, const uint32_
     SA_ABI_GUARD_END(0)
 }
 
-SA_EXPORT void sa_amd_index_destroy(sa_amd_index *ix)
+SA_EXPORT void sa_amd_index_destroy(sa_amd_index *ix)      // (frees and deletes: nothing that throws)
 {
     if (!ix) return;
     if (ix->dT) (void)hipFree(ix->dT);
@@ -333,6 +335,7 @@ SA_EXPORT int32_t sa_amd_index_sa(const sa_amd_index *ix, uint32_t *SA_out)
 
 SA_EXPORT int32_t sa_amd_index_buckets(sa_amd_index *ix, uint32_t *bkt)
 {
+    SA_ABI_GUARD_BEGIN
     if (!ix || !bkt) return SA_AMD_EINVAL;
     sa::DeviceGuard guard(ix->device);
     if (guard.rc != SA_AMD_OK) return guard.rc;
@@ -344,10 +347,12 @@ SA_EXPORT int32_t sa_amd_index_buckets(sa_amd_index *ix, uint32_t *bkt)
         ix->dBkt = dB;                                           // kept: later searches start from the pattern's bucket
     }
     return hipMemcpy(bkt, ix->dBkt, (size_t)sa::BKT_LEN * 4, hipMemcpyDeviceToHost) == hipSuccess ? SA_AMD_OK : SA_AMD_EHIP;
+    SA_ABI_GUARD_END(0)
 }
 
 SA_EXPORT int32_t sa_amd_index_check_integrity(const sa_amd_index *ix)
 {
+    SA_ABI_GUARD_BEGIN
     if (!ix) return SA_AMD_EINVAL;
     sa::DeviceGuard guard(ix->device);
     if (guard.rc != SA_AMD_OK) return guard.rc;
@@ -363,12 +368,14 @@ SA_EXPORT int32_t sa_amd_index_check_integrity(const sa_amd_index *ix)
     rc = sa_amd_check_integrity_device(ix->dT, ix->n, ix->dSA, blk.p, wb, nullptr);
     sa::pool().release(blk);
     return rc;
+    SA_ABI_GUARD_END(0)
 }
 
 SA_EXPORT int32_t sa_amd_index_search(const sa_amd_index *ix, const uint8_t *pat_data, const int64_t *pat_off, int32_t count,
                                       uint8_t *contains, uint32_t *range_lo, uint32_t *range_hi, uint32_t *lcp_start,
                                       uint32_t *lcp_len)
 {
+    SA_ABI_GUARD_BEGIN
     using namespace sa;
     if (!ix || count < 0 || (count > 0 && !pat_off)) return SA_AMD_EINVAL;
     if (count == 0) return SA_AMD_OK;
@@ -399,6 +406,7 @@ SA_EXPORT int32_t sa_amd_index_search(const sa_amd_index *ix, const uint8_t *pat
     if (lcp_start) HIP_TRY(hipMemcpy(lcp_start, R + 2 * C, C * 4, hipMemcpyDeviceToHost));
     if (lcp_len) HIP_TRY(hipMemcpy(lcp_len, R + 3 * C, C * 4, hipMemcpyDeviceToHost));
     return SA_AMD_OK;
+    SA_ABI_GUARD_END(0)
 }
 
 // ---- packed format (reference src/packed_sa.rs); byte layout: u32 magic "SA4x" LE, u32 length, u64 data length
@@ -419,6 +427,7 @@ SA_EXPORT int64_t sa_amd_pack_bound(int64_t length)
 
 SA_EXPORT int32_t sa_amd_pack(const uint32_t *SA, int64_t length, uint8_t *out, int64_t capacity, int64_t *out_len)
 {
+    SA_ABI_GUARD_BEGIN
     using namespace sa;
     if (!SA || !out || !out_len || length < 1 || length > 0xffffffffLL) return SA_AMD_EINVAL;
     if (capacity < sa_amd_pack_bound(length)) return SA_AMD_EINVAL;
@@ -450,10 +459,12 @@ SA_EXPORT int32_t sa_amd_pack(const uint32_t *SA, int64_t length, uint8_t *out, 
     memcpy(out, &magic, 4); memcpy(out + 4, &len32, 4); memcpy(out + 8, &dl, 8);
     *out_len = 16 + data_len;
     return SA_AMD_OK;
+    SA_ABI_GUARD_END(0)
 }
 
 SA_EXPORT int32_t sa_amd_unpack(const uint8_t *bytes, int64_t nbytes, uint32_t *SA, int64_t capacity, int64_t *length)
 {
+    SA_ABI_GUARD_BEGIN
     using namespace sa;
     if (!bytes || !length || nbytes < 16) return SA_AMD_EINVAL;
     uint32_t magic, len32; uint64_t dl;
@@ -485,9 +496,13 @@ SA_EXPORT int32_t sa_amd_unpack(const uint8_t *bytes, int64_t nbytes, uint32_t *
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(SA, dS.p, (size_t)len32 * 4, hipMemcpyDeviceToHost));
     return SA_AMD_OK;
+    SA_ABI_GUARD_END(0)
 }
 
-SA_EXPORT void sa_amd_release_cache(void) { sa::pool().clear(); }
+SA_EXPORT void sa_amd_release_cache(void)
+{
+    try { sa::pool().clear(); } catch (...) { }
+}
 
 SA_EXPORT void sa_amd_last_stats(sa_amd_stats *out)
 {

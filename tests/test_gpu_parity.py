@@ -1053,6 +1053,33 @@ def test_batched_search_on_device_resident_index(oracle):
         assert s[st:st + ln] == p[:ln]
         if q < 40:
             assert ln == len(naive_search_lcp(s, p))
+    # With the bucket table built (enable_buckets) the searches start from the pattern's (c0, c1) bucket like the
+    # reference's get_bucket (src/sa.rs:123-144); search_lcp then has the reference's empty-bucket branch (src/sa.rs:211-222):
+    # first suffix of the top-level bucket of c0 with length 1, or s.len()..s.len() -- the RANGE, not only the substring
+    bkt = oracle.bucket_table(text)
+
+    def ref_search_lcp_with_buckets(p):
+        if len(p) > 1:
+            idx = p[0] * 257 + p[1] + 2
+            blo, bhi = int(bkt[idx - 1]), int(bkt[idx])
+        elif len(p) == 1:
+            blo, bhi = int(bkt[p[0] * 257]), int(bkt[p[0] * 257 + 257])
+        else:
+            blo, bhi = 0, 1
+        if blo == bhi:
+            tlo, thi = int(bkt[p[0] * 257]), int(bkt[p[0] * 257 + 257])
+            return (int(arr[tlo]), 1) if thi > tlo else (len(s), 0)
+        return None                                             # (non-empty bucket: the substring is checked above)
+    pats2 = [b"e\x00", b"e\xff", b"t\x01x", b"\xff", b"\xffa", b"\x00\x00", b"q!", b"e"]
+    res2 = ix.search(pats2)
+    hit = 0
+    for q, p in enumerate(pats2):
+        exp = ref_search_lcp_with_buckets(p)
+        if exp is not None:
+            assert (int(res2["lcp_start"][q]), int(res2["lcp_len"][q])) == exp, p
+            assert not res2["contains"][q] and res2["lo"][q] == res2["hi"][q]
+            hit += 1
+    assert hit >= 5
     ix.close()
 
 
