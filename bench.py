@@ -58,7 +58,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3_english_256m",
-                    help="c2_uniform_64m | c2_uniform_256m | c3_english_256m | c3_iid_256m | c4_dna_1g | c5_uniform_512m")
+                    help="c2_uniform_64m | c2_uniform_256m | c3_english_256m | c3_iid_256m | c4_dna_1g | c4_dna_repeats_1g | c5_uniform_512m")
     ap.add_argument("--text-bytes", "--n", dest="n", type=int, default=None, help="override the text length (bytes)")
     ap.add_argument("--verify-cpu", action="store_true", help="additionally check the last SA with the oracle's linear verifier")
     ap.add_argument("--no-cpu-baseline", action="store_true")

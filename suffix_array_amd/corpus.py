@@ -89,6 +89,7 @@ WORKLOADS = {
     "c3_iid_256m": (english_iid, 256 << 20, 3),
     "c2_uniform_256m": (uniform, 256 << 20, 2),          # north_star's literal "256 MiB random-byte text"
     "c4_dna_1g": (dna, 1 << 30, 4),
+    "c4_dna_repeats_1g": (lambda n, seed: dna_repeats(n, seed, 0.2), 1 << 30, 4),   # the harder C4 variant (planted repeats of 1-100 KiB, 1 % mutations)
     "c5_uniform_512m": (uniform, 512 << 20, 50),
 }
 

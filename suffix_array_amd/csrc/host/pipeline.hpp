@@ -913,8 +913,31 @@ struct DeviceBuild {
                 { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
                 // c - 1 per value seen c times under-counts pairs only when values repeat often, which is the
                 // "do not" case anyway; expected number of other suffixes sharing the top bits with a given one:
-                const double q = 2.0 * (double)dups / ((double)S * (double)S);
-                use = (double)n * q < 0.5;
+                const double p32 = (double)n * 2.0 * (double)dups / ((double)S * (double)S);
+                use = p32 < (double)tn.top32_partners_x100 / 100.0;
+                double p64 = -1.0;
+                if (!use && p32 < 4.0 * (double)tn.top32_collisions_x100 / 100.0) {
+                    // Not "almost all separated" -- but WHY do suffixes share their top 32 bits?  Chance collisions (a small or
+                    // skewed alphabet: few partners each, told apart by the low key bits in one pass over the sorted keys) or
+                    // repeats (they share the low bits too and go to the refinement rounds either way).  The same sample,
+                    // whole keys: the partners a suffix has on all key bits.  Measured (tools/top32_threshold.py, 1 GiB): sigma 16
+                    // skewed, 2.5 partners on 32 bits and none on 64: 42 ms against 74 ms with full keys; DNA with 20 % in
+                    // repeats (0.72 / 0.35): 118 against 137 ms; 40 % in repeats (0.82 / 0.45): 154 against 143 ms -- hence 0.8 x the threshold for those.
+                    PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_keys), dim3((unsigned)ceil_div(S, GK_THREADS)), dim3(GK_THREADS), 0, st, dT, P, n, S,
+                                                            -1, w.keysA));
+                    HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
+                    HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
+                    PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
+                                                            (unsigned long long *)w.keysB, H - 1u, w.total));
+                    uint32_t dups64 = 0;
+                    { const int rcw = read_words(&dups64, w.total, 4, st); if (rcw) return rcw; }
+                    const double chance = (double)S * (double)S / 8589934592.0;           // 32-bit hash collisions among S samples
+                    const double d64 = (double)dups64 > chance ? (double)dups64 - chance : 0.0;
+                    p64 = (double)n * 2.0 * d64 / ((double)S * (double)S);
+                    use = p64 < 0.8 * (double)tn.top32_partners_x100 / 100.0 && p32 - p64 < (double)tn.top32_collisions_x100 / 100.0;
+                }
+                if (trace) fprintf(stderr, "suffix_array_amd: entropy probe: %u duplicates of the top 32 key bits among %lld samples -> %.3f expected partners per suffix "
+                                           "(on all key bits: %.3f) -> %s\n", dups, (long long)S, p32, p64, use ? "32-bit first stage" : "full keys");
             }
             if (use) top_shift = key_bits - 32;
         }

@@ -414,7 +414,11 @@ __global__ __launch_bounds__(GK_THREADS) void k_sample_keys(const uint8_t *__res
     const uint64_t r = ((uint64_t)i + 1u) * 0x9E3779B97F4A7C15ull;
     const int64_t p = (int64_t)((r >> 11) % (uint64_t)n);
     const uint64_t kq = text_key(T, lcode, P, n, p, P.k, (((uintptr_t)T) & 7) == 0);
-    out[i] = ((kq >> top_shift) << 32) | (uint64_t)(uint32_t)p;      // position in the low half: equal positions are not collisions
+    uint64_t part = kq >> (top_shift < 0 ? 0 : top_shift);
+    if (top_shift < 0) {                                              // the WHOLE key, hashed to 32 bits (the host subtracts the chance collisions)
+        part ^= part >> 33; part *= 0xff51afd7ed558ccdull; part ^= part >> 33; part *= 0xc4ceb9fe1a85ec53ull; part ^= part >> 33;
+    }
+    out[i] = (part << 32) | (uint64_t)(uint32_t)p;                    // position in the low half: equal positions are not collisions
 }
 
 // Repeat probe: how much of the text lies in repeats longer than a few words?  The first 2k symbols of SAMPLE pseudo-random
