@@ -119,7 +119,7 @@ static Workspace carve(void *base, int64_t n)
 
 // ------------------------------------------------------------------------------------------
 // Single-pass tile scatter (kernels/onesweep.hpp): host side of one LSD sort.
-// Scratch inside the spine slab: two ZONES of OS_ZONE words, zone = [16 tickets | RADIX * OS_NSEG segment counts].
+// Scratch inside the spine slab: two ZONES of OS_ZONE words, zone = [OS_TICKETS ticket words | RADIX * OS_NSEG segment counts].
 // Pass p reads its digit's counts from zone z and writes the next digit's counts -- and takes its tickets -- in zone z ^ 1,
 // which the host zeroes right before the launch.
 // ------------------------------------------------------------------------------------------
@@ -132,7 +132,9 @@ static const OsShape os_shapes32[] = { { 1024, 12, false, 1 }, { 512, 16, true, 
 // 1024-thread workgroup --, 512 x 24 likewise; two workgroups per CU bought nothing at equal tile size)
 constexpr int N_OS_SHAPES64 = (int)(sizeof(os_shapes64) / sizeof(os_shapes64[0]));
 constexpr int N_OS_SHAPES32 = (int)(sizeof(os_shapes32) / sizeof(os_shapes32[0]));
-constexpr int OS_ZONE = 16 + RADIX * OS_NSEG;  // words
+constexpr int OS_TICKETS = 64;                 // words in front of a zone's counts: one ticket counter per segment
+constexpr int OS_ZONE = OS_TICKETS + RADIX * OS_NSEG;  // words
+static_assert(OS_NSEG <= OS_TICKETS, "one ticket word per segment");
 static_assert(2 * OS_ZONE <= RADIX * SORT_MAX_WG, "both zones live in the spine slab");
 
 static bool onesweep_on(const SortScratch &ss, const Tuning &tn) { return ss.status != nullptr && !tn.no_onesweep; }
@@ -209,14 +211,14 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
             const int64_t sub = K64 ? ((ceil_div(g.seg_elems, split) + 1) & ~(int64_t)1) : ((ceil_div(g.seg_elems, split) + 3) & ~(int64_t)3);
             if (K64)
                 PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.nseg * split), dim3(SORT_THREADS), 0, st, (const uint64_t *)kin,
-                                                               zone[z] + 16, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
+                                                               zone[z] + OS_TICKETS, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
             else
                 PROF(KC_UPSWEEP32, count, st, hipLaunchKernelGGL((k_radix_upsweep32), dim3(g.nseg * split), dim3(SORT_THREADS), 0, st, (const uint32_t *)kin,
-                                                                 zone[z] + 16, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
+                                                                 zone[z] + OS_TICKETS, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
         }
         if (may_skip && !tn.no_run_skip && count >= tn.run_skip_min && !(iota && *passes == 0) && !(last && final_vals)) {
             // a digit that is the same for EVERY element makes the pass the identity (the sort is stable): skip it
-            hipLaunchKernelGGL(k_os_digit_totals, dim3(1), dim3(RADIX), 0, st, (const uint32_t *)(zone[z] + 16), g.nseg, ss.digit_tot);
+            hipLaunchKernelGGL(k_os_digit_totals, dim3(1), dim3(RADIX), 0, st, (const uint32_t *)(zone[z] + OS_TICKETS), g.nseg, ss.digit_tot);
             LAUNCH_CHECK(st);
             uint32_t tot[RADIX];
             { const int rcw = read_words(tot, ss.digit_tot, sizeof(tot), st); if (rcw) return rcw; }
@@ -225,8 +227,8 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
             if (constant) { ++*skipped; have_counts = false; continue; }
         }
         OnesweepPass P;
-        P.hist_cur = zone[z] + 16;
-        P.hist_next = last ? nullptr : zone[z ^ 1] + 16;
+        P.hist_cur = zone[z] + OS_TICKETS;
+        P.hist_next = last ? nullptr : zone[z ^ 1] + OS_TICKETS;
         P.tickets = zone[z ^ 1];
         P.status = ss.status;
         P.err = ss.err;
@@ -427,7 +429,7 @@ static FirstCounts sort_first_counts(const SortScratch &ss, const Tuning &tn, in
         const OsShape &sh = keys32 ? os_shapes32[tn.onesweep32_shape] : os_shapes64[tn.onesweep64_shape];
         const int tile = sh.threads * sh.items;
         const OnesweepGeom g = onesweep_geom(count, tile);
-        f.counts = ss.spine + 16; f.chunk_elems = g.seg_elems; f.G = g.nseg;
+        f.counts = ss.spine + OS_TICKETS; f.chunk_elems = g.seg_elems; f.G = g.nseg;
         f.zero_ptr = ss.spine; f.zero_bytes = (size_t)OS_ZONE * 4;
         return f;
     }

@@ -326,7 +326,9 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
                 else dpack[j >> 2] |= d << (8 * (j & 3));
             }
             if (count_next) {
-                const uint32_t slot = ok ? digit_of(kx, P.shift_next, P.dmask_next) * OS_NSEG + (uint32_t)seg0[d] + (gp >= bnd[d] ? 1u : 0u) : 0u;
+                // (segment-major in LDS: neighbouring lanes carry different digits, i.e. different banks -- digit-major put the whole
+                // wave on RADIX * OS_NSEG / 32 = 4 banks)
+                const uint32_t slot = ok ? ((uint32_t)seg0[d] + (gp >= bnd[d] ? 1u : 0u)) * RADIX + digit_of(kx, P.shift_next, P.dmask_next) : 0u;
                 const uint64_t act = __ballot(ok);
                 const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
                 // one (digit, segment) for the whole wave (constant high digits, runs): one add, not 64 on one address
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
         __syncthreads();
         for (int i = tid; i < RADIX * OS_NSEG; i += THREADS) {
             const uint32_t c = hist2[i];
-            const int d = i / OS_NSEG, s = i % OS_NSEG;
+            const int s = i / RADIX, d = i % RADIX;
             if (c && s < nseg) atomicAdd(&P.hist_next[d * nseg + s], c);
         }
     }
