@@ -520,7 +520,8 @@ def run(args, backend, rank, world, dist=None, share=False):
     reported = [ln for ln in lines if device_ms > 0 and ln["ms_per_step"] >= REPORT_SHARE * device_ms]
     whole_build = None
     if tj and tj.get("builds_per_pass"):
-        pmc_bytes = sum(k.get("hbm_bytes_per_build", 0) for k in tj["kernels"].values())
+        # (the verification kernels k_ci_* run once per bench run, outside the builds)
+        pmc_bytes = sum(k.get("hbm_bytes_per_build", 0) for nm, k in tj["kernels"].items() if not nm.startswith("k_ci_"))
         whole_build = {"pmc_hbm_bytes_per_build": pmc_bytes, "device_ms_per_build": round(device_ms, 3),
                        "achieved": round(pmc_bytes / (device_ms * 1e-3) / 1e9, 1) if device_ms > 0 else None,
                        "frac": round(pmc_bytes / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms > 0 else None,

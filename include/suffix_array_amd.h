@@ -93,7 +93,7 @@ int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n, void *dW
 
 /* The host-pointer entry points take their device memory (text + SA + workspace of one build = one block), streams and
  * pinned staging buffers from a process-wide pool, so repeated calls do not pay hipMalloc / hipFree; the pool retains at
- * most SA_AMD_CACHE_MAX_BYTES of device memory (default 64 GiB of the 288 GB).  This empties the pool now. */
+ * most SA_AMD_CACHE_MAX_BYTES of device memory (default 128 GiB of the 288 GB).  This empties the pool now. */
 void sa_amd_release_cache(void);
 
 /* wall-clock phases of the calling thread's most recent host-pointer build, milliseconds:

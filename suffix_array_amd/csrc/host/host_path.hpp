@@ -3,7 +3,7 @@
 //
 // Device memory comes from a process-wide pool of blocks (one block = text + SA + workspace of one build), so neither
 // repeated calls nor the short-lived worker threads of sa_amd_saca_batch pay hipMalloc / hipFree per call; the pool
-// retains at most SA_AMD_CACHE_MAX_BYTES (default 64 GiB of the 288 GB) and sa_amd_release_cache() empties it.
+// retains at most SA_AMD_CACHE_MAX_BYTES (default 128 GiB of the 288 GB) and sa_amd_release_cache() empties it.
 // The suffix array travels back either with one hipMemcpy into the caller's pageable buffer, or -- large arrays --
 // chunk by chunk through pinned staging buffers while helper threads move finished chunks into the caller's buffer
 // (a freshly allocated Vec<u32>, as SuffixArray::new makes, is page-faulted in by several threads instead of one).

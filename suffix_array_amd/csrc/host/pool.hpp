@@ -1,7 +1,7 @@
 // host/pool.hpp -- process-wide pool of device blocks, streams and pinned host blocks (mutex-protected).
 // One device block = text + SA + workspace of one build, so neither repeated calls of the host-pointer entry points
 // (the contract of `saca()`, reference src/saca.rs:9-15) nor the worker threads of sa_amd_saca_batch pay hipMalloc /
-// hipFree per call; the pool retains at most SA_AMD_CACHE_MAX_BYTES (default 64 GiB of the 288 GB) and
+// hipFree per call; the pool retains at most SA_AMD_CACHE_MAX_BYTES (default 128 GiB of the 288 GB: one 1 GiB text is a 58 GiB block) and
 // sa_amd_release_cache() empties it.  Pinned blocks remember the NUMA node they were first touched on (helpers.hpp).
 #pragma once
 #include "helpers.hpp"
@@ -12,11 +12,11 @@ namespace sa {
 
 static size_t cache_limit()
 {
-    return (size_t)env_int("SA_AMD_CACHE_MAX_BYTES", (int64_t)64 << 30, 0, (int64_t)1 << 50);
+    return (size_t)env_int("SA_AMD_CACHE_MAX_BYTES", (int64_t)128 << 30, 0, (int64_t)1 << 50);
 }
 
 // ---- pool of device blocks, streams and pinned staging buffers (process-wide, mutex-protected) ----
-struct DevBlock { int device = -1; void *p = nullptr; size_t bytes = 0; };
+struct DevBlock { int device = -1; void *p = nullptr; size_t bytes = 0; uint64_t stamp = 0; };      // stamp: when it was last handed back
 struct PinBlock { void *p = nullptr; size_t bytes = 0; int node = -1; };      // node: NUMA node its pages were first touched on (-1: wherever)
 
 class ResourcePool {
@@ -25,6 +25,7 @@ class ResourcePool {
     std::vector<std::pair<int, hipStream_t>> streams_;
     std::vector<PinBlock> pinned_;
     size_t retained_ = 0;
+    uint64_t clock_ = 0;
 
 public:
     // a free block of `device` with at least `need` bytes (the smallest such), else a new allocation
@@ -44,8 +45,8 @@ public:
         }
         // slack: a slowly growing series of texts reuses the block -- but never so much that a block which fits the cache
         // limit is pushed over it and dropped on release (a 1 GiB text needs 57.9 GiB: with an eighth on top it was 65.1 GiB
-        // against the default 64 GiB limit, and every call of that size paid hipMalloc + hipFree)
-        size_t want = need + need / 8;
+        // against the 64 GiB limit of round 2, and every call of that size paid hipMalloc + hipFree)
+        size_t want = need + (need / 8 < ((size_t)1 << 30) ? need / 8 : ((size_t)1 << 30));      // (at most 1 GiB of slack)
         {
             const size_t limit = cache_limit();
             if (want > limit) want = need > limit ? need : limit;
@@ -71,15 +72,20 @@ public:
             std::lock_guard<std::mutex> lk(mu_);
             if (b.bytes > limit) drop.push_back(b);
             else {
-                // evict the largest blocks until the newcomer fits (it is the size the caller is working at)
+                // evict the blocks that have been idle longest until the newcomer fits (it is the size the caller is working at).
+                // Not "the largest first": two workers of a batch alternate on two large blocks next to an older small one, and
+                // dropping the large idle block made the next call pay a 30 GiB hipMalloc -- 2 s, with the other worker's
+                // copies stalled behind it (profiles/r03_host_path.txt)
                 while (retained_ + b.bytes > limit && !blocks_.empty()) {
-                    int big = 0;
-                    for (int i = 1; i < (int)blocks_.size(); ++i) if (blocks_[i].bytes > blocks_[big].bytes) big = i;
-                    retained_ -= blocks_[big].bytes;
-                    drop.push_back(blocks_[big]);
-                    blocks_.erase(blocks_.begin() + big);
+                    int old = 0;
+                    for (int i = 1; i < (int)blocks_.size(); ++i) if (blocks_[i].stamp < blocks_[old].stamp) old = i;
+                    retained_ -= blocks_[old].bytes;
+                    drop.push_back(blocks_[old]);
+                    blocks_.erase(blocks_.begin() + old);
                 }
-                blocks_.push_back(b);
+                DevBlock kept = b;
+                kept.stamp = ++clock_;
+                blocks_.push_back(kept);
                 retained_ += b.bytes;
             }
         }
