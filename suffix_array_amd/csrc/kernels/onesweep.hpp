@@ -298,6 +298,13 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
                     }
                 }
                 g = acc;                                            // (the inclusive prefix the walk ended on carries the segment's start)
+#ifdef SA_AMD_DIAG
+                if ((P.flags & 128u) != 0 && tid == 7) {            // look-back statistics of digit 7's thread: walks, tiles walked, polls
+                    atomicAdd(&g_phase_cycles[8], 1ull);
+                    atomicAdd(&g_phase_cycles[9], (unsigned long long)(t - 1 - k));
+                    atomicAdd(&g_phase_cycles[10], (unsigned long long)spins);
+                }
+#endif
             }
             __hip_atomic_store(status + (int64_t)t * RADIX + tid, tagI | (unsigned long long)(g + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             goff[tid] = g - dbase;

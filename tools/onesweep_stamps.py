@@ -38,4 +38,6 @@ tiles = passes * ((n + tile - 1) // tile)
 print(f"{kb}-bit keys, 2^{lg} pairs, {passes} passes, shape {shape}, tile {tile}; s_memtime ticks of wave 0 per tile")
 for i, nm in enumerate(names):
     print(f"{nm:44s} {buf[i] / tiles:9.1f} ticks/tile  {100.0 * buf[i] / tot:5.1f} %")
-print(f"{'total':44s} {tot / tiles:9.1f} ticks/tile = {tot / tiles / 100.0:.2f} us")
+print(f"{'total':44s} {tot / tiles:9.1f} ticks/tile")
+if buf[8]:
+    print(f"look-back of one digit's thread: {buf[8]} walks, {buf[9] / buf[8]:.2f} tiles walked (rounded up to rounds of 4), {buf[10] / buf[8]:.2f} polls of a granule that was not there yet per walk")
