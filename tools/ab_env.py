@@ -8,7 +8,17 @@ import numpy as np, torch
 import suffix_array_amd as sa
 from suffix_array_amd import corpus
 name = sys.argv[1]
-t = corpus.workload(name)
+if name.startswith("adv:"):                     # adversarial families: adv:<one|ab|fib|p1000|twice>:<n>
+    _, fam, nn = name.split(":"); nn = int(nn)
+    def _fib(k):
+        a, b = b"a", b"ab"
+        while len(b) < k: a, b = b, b + a
+        return np.frombuffer(b[:k], dtype=np.uint8).copy()
+    t = {"one": lambda: np.full(nn, 97, dtype=np.uint8), "ab": lambda: np.resize(np.frombuffer(b"ab", dtype=np.uint8), nn).copy(),
+         "fib": lambda: _fib(nn), "twice": lambda: np.concatenate([corpus.english(nn // 2, 5)] * 2),
+         "p1000": lambda: np.resize(np.random.default_rng(7).integers(0, 256, 1000, dtype=np.uint8), nn).copy()}[fam]()
+else:
+    t = corpus.workload(name)
 n = t.size
 dev = torch.device("cuda", 0)
 text = torch.from_numpy(t).to(dev)
