@@ -1078,7 +1078,7 @@ struct DeviceBuild {
             HIP_TRY(hipMemsetAsync(w.total, 0, 16, st));
             HIP_TRY(hipMemsetAsync(w.chg, 0, (size_t)RR_CHG_COUNTERS * 32 * 4, st));
             KeySrc K = KeySrc(); K.mode = KS_LOWKEY; K.kb = top_shift;
-            PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint32_t, KS_LOWKEY, false>), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS),
+            PROF(KC_FINISH, n, st, hipLaunchKernelGGL((k_finish_sorted<uint32_t, KS_LOWKEY, false>), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS),
                                                      0, st, sorted32, SA, dT, P, n, K, cap, surv_bits, surv_head, w.tcnt, w.total, (uint32_t *)nullptr,
                                                      (uint32_t *)nullptr, (uint32_t *)nullptr));
             PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
@@ -1124,7 +1124,7 @@ struct DeviceBuild {
             HIP_TRY(hipMemsetAsync(w.total, 0, 32, st));
             HIP_TRY(hipMemsetAsync(w.chg, 0, (size_t)RR_CHG_COUNTERS * 32 * 4, st));
             KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
-            PROF(KC_LOCAL, n, st, hipLaunchKernelGGL((k_finish_sorted<uint64_t, KS_TEXT, true>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
+            PROF(KC_FINISH, n, st, hipLaunchKernelGGL((k_finish_sorted<uint64_t, KS_TEXT, true>), dim3((unsigned)ft_tiles), dim3(FT_THREADS), 0, st,
                                                      (const uint64_t *)sorted0, SA, dT, Ptext, n, K, cap, w.surv_bits, surv_head, w.surv_cnt, w.total,
                                                      w.todo_bits, w.ft_cnt, w.ft_head));
             PROF(KC_RR_SCAN, ft_tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.ft_head, ft_tiles, w.total + 3));
