@@ -513,6 +513,12 @@ def run(args, backend, rank, world, dist=None, share=False):
             line["traffic"] = tj["kernels"][nm]["hbm_bytes_per_launch"]
             if ab and units:
                 line["traffic_over_algorithmic"] = round(line["traffic"] / (ab * units / max(launches, 1)), 3)
+            # the rate the kernel moves FETCHED bytes at (profiles/traffic.json is measured on the headline workload): a
+            # kernel of random 4-byte look-ups sits far below the roofline on algorithmic bytes and AT it on these --
+            # every look-up is a 128-byte request on gfx950 (tools/gather_probe.hip, profiles/r03_gather_probe.txt)
+            if ms > 0 and launches and tj.get("workload") == args.workload:
+                line["traffic_rate"] = round(line["traffic"] / (ms / launches * 1e-3) / 1e9, 1)
+                line["traffic_frac"] = round(line["traffic_rate"] / HBM_PEAK_GBS, 4)
         return line
 
     timed = sorted((i for i in range(len(prof)) if prof[i][1]), key=lambda i: -prof[i][0])
@@ -584,20 +590,23 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # rehearsal on a one-GPU box: SA_BENCH_SHARE_GPU=1 puts every rank on device 0 and uses gloo for the
-    # control plane (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank + nccl
+    # rehearsal on a one-GPU box: SA_BENCH_SHARE_GPU=1 puts every rank on device 0; the driver's real runs use one GPU per rank.
+    # Control plane: the data path has NO collective (one independent text per GPU); what the ranks exchange is a
+    # barrier, a mask and a few scalars, so they go over gloo on CPU tensors by default -- bringing RCCL up across 8 GPUs is
+    # failure surface the path never needs.  SA_BENCH_CONTROL=nccl uses RCCL (backend "nccl" on ROCm) for them instead.
     share = os.environ.get("SA_BENCH_SHARE_GPU") == "1"
+    use_nccl = os.environ.get("SA_BENCH_CONTROL", "gloo") == "nccl" and not share
     backend = HipBackend(0 if share else local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group(backend="gloo")
-        else:
+        if use_nccl:
             dist.init_process_group(backend="nccl", device_id=backend.dev)
+        else:
+            dist.init_process_group(backend="gloo")
     try:
-        result = run(args, backend, rank, world, dist, share)
+        result = run(args, backend, rank, world, dist, share or not use_nccl)        # (True: control tensors live on the CPU)
         if result is not None:
             print(json.dumps(result), flush=True)
     finally:
