@@ -11,6 +11,7 @@
 #include "pipeline.hpp"
 
 #include <chrono>
+#include <mutex>
 
 namespace sa {
 
@@ -78,6 +79,25 @@ static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipSt
     return rc;
 }
 
+// Callers that share a device (the worker threads of sa_amd_saca_batch, or an application that calls saca() from several
+// threads) take turns PER PHASE: one upload, one build and one download at a time per device.  Left alone, threads that
+// start together stay in step -- both upload, both build on half a GPU, both download on half a link (measured, two threads,
+// 8 x 512 MiB: every call h2d 18 + build 32 + d2h 85 ms, 500 ms per batch) -- with the lanes one text's download runs at
+// full link speed under the next one's upload and build.  SA_AMD_NO_LANES=1: no turns (A/B).
+struct DeviceLanes { std::mutex up, run, down; };
+static DeviceLanes &device_lanes(int device)
+{
+    static DeviceLanes lanes[64];
+    return lanes[(unsigned)device & 63u];
+}
+struct LaneTurn {
+    std::mutex *m;
+    LaneTurn(std::mutex &mx, bool on) : m(on ? &mx : nullptr) { if (m) m->lock(); }
+    ~LaneTurn() { if (m) m->unlock(); }
+    LaneTurn(const LaneTurn &) = delete;
+    LaneTurn &operator=(const LaneTurn &) = delete;
+};
+
 // host buffers in, host buffers out; with_sentinel writes SA[0] = n too (saca layout)
 static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_sentinel, int device)
 {
@@ -140,14 +160,23 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     uint8_t *dT = (uint8_t *)blk.p;
     uint32_t *dSA = (uint32_t *)((char *)blk.p + tb);
     void *dW = (char *)blk.p + tb + sb;
-    rc = hip_status(hipMemcpyAsync(dT, T, (size_t)n, hipMemcpyHostToDevice, st));
-    if (rc == SA_AMD_OK) rc = hip_status(hipStreamSynchronize(st));
+    DeviceLanes &lanes = device_lanes(cur);
+    const bool turns = env_int("SA_AMD_NO_LANES", 0, 0, 1) == 0;
+    {
+        LaneTurn turn(lanes.up, turns);
+        rc = hip_status(hipMemcpyAsync(dT, T, (size_t)n, hipMemcpyHostToDevice, st));
+        if (rc == SA_AMD_OK) rc = hip_status(hipStreamSynchronize(st));
+    }
     double t1 = wall_ms();
     tm.h2d = t1 - t0;
-    if (rc == SA_AMD_OK) rc = build_device(dT, dSA, n, dW, (int64_t)wb, st, nullptr);
+    if (rc == SA_AMD_OK) {
+        LaneTurn turn(lanes.run, turns);
+        rc = build_device(dT, dSA, n, dW, (int64_t)wb, st, nullptr);
+    }
     t0 = wall_ms();
     tm.build = t0 - t1;
     if (rc == SA_AMD_OK) {
+        LaneTurn turn(lanes.down, turns);
         const uint32_t *src = with_sentinel ? dSA : dSA + 1;
         const size_t out_bytes = ((size_t)n + (with_sentinel ? 1 : 0)) * 4;
         const int copy_threads = (int)env_int("SA_AMD_COPY_THREADS", 8, 0, 32);      // 0: plain hipMemcpy into the caller's buffer
@@ -157,6 +186,7 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
             rc = staged_download(SA_host, src, out_bytes, st, copy_threads, cur, node);
         } else {
             rc = hip_status(hipMemcpyAsync(SA_host, src, out_bytes, hipMemcpyDeviceToHost, st));
+            if (rc == SA_AMD_OK) rc = hip_status(hipStreamSynchronize(st));      // (the turn ends when the copy has)
         }
     }
     const int rs = hip_status(hipStreamSynchronize(st));       // also drains the stream after a failure
