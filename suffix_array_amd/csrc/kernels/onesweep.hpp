@@ -20,7 +20,7 @@
 //   * Look-back: per tile and digit one 8-byte granule {epoch << 2 | flag, value} written by ONE agent-scope store and
 //     polled with agent-scope loads (no fences: the data is its own flag, MI355X guide R2).  flag 1 = the tile's own count
 //     (published right after the ranking), flag 2 = the inclusive prefix of the segment up to and including the tile.
-//     A tile sums its predecessors' counts backwards until it meets an inclusive prefix, four predecessors per round trip;
+//     A tile sums its predecessors' counts backwards until it meets an inclusive prefix, three predecessors per round trip;
 //     the first look comes after the tile has been staged in LDS, when its neighbours' counts have had time to become visible.
 //     A tile only ever waits for tiles with smaller tickets, which are held by running workgroups: no co-residency
 //     assumption, no deadlock when another stream shares the device.
@@ -32,7 +32,8 @@
 namespace sa {
 
 constexpr int OS_NSEG = 8;           // segments per pass (one per XCD; fewer when there are fewer tiles)
-constexpr int OS_LB = 4;             // predecessors read speculatively per look-back round
+constexpr int OS_LB = 3;             // predecessors read speculatively per look-back round (measured: 1 slower, 2 and 3 equal, 4 and 8
+                                     // slower on 32-bit keys -- rows of granules nobody needs are L2 traffic too; profiles/r03_onesweep_experiments.txt)
 constexpr int OS_MIN_TILE = 4096;    // smallest tile of any shape in use (the granule slab is sized by it)
 
 __device__ __forceinline__ unsigned os_xcc_id()
