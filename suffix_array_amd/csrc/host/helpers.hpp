@@ -158,6 +158,46 @@ public:
             }
         }
     }
+    // The same in two halves: start() hands fn(0) .. fn(count-1) to the helpers and returns; finish() takes what is left
+    // on the calling thread and returns when all have run.  The handle (and what fn refers to) must outlive finish().
+    struct Async { Job job; bool queued = false; };
+    void start(Async &a, int count, const std::function<void(int)> &fn)
+    {
+        a.job.fn = fn; a.job.count = count; a.job.next = 0; a.job.done = 0; a.queued = false;
+        if (count <= 0) return;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while ((int)threads_.size() < want_) {
+                try { threads_.emplace_back([this] { worker(); }); threads_.back().detach(); }
+                catch (...) { want_ = (int)threads_.size(); break; }
+            }
+            jobs_.push_back(&a.job);
+            a.queued = true;
+        }
+        cv_work_.notify_all();
+    }
+    void finish(Async &a)
+    {
+        if (!a.queued) return;
+        Job &job = a.job;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            if (job.next < job.count) {
+                const int t = job.next++;
+                if (job.next >= job.count) {
+                    for (auto it = jobs_.begin(); it != jobs_.end(); ++it) if (*it == &job) { jobs_.erase(it); break; }
+                }
+                lk.unlock();
+                job.fn(t);
+                lk.lock();
+                ++job.done;
+            } else {
+                cv_done_.wait(lk, [&] { return job.done == job.count; });
+                break;
+            }
+        }
+        a.queued = false;
+    }
     // runs fn once on a helper thread of this pool (its CPU affinity decides where first-touched pages land);
     // on the calling thread when the pool has no helpers
     void run_on_helper(const std::function<void()> &fn)

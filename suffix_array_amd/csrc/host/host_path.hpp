@@ -162,6 +162,19 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     void *dW = (char *)blk.p + tb + sb;
     DeviceLanes &lanes = device_lanes(cur);
     const bool turns = env_int("SA_AMD_NO_LANES", 0, 0, 1) == 0;
+    // The caller's array is usually FRESH memory (`vec![0; n + 1]`, reference src/sa.rs:24: zero pages that are mapped on first
+    // write): the helpers touch its pages -- read a byte, write it back: the contents stay whatever they were -- while the GPU
+    // builds, so the download later copies into mapped memory (C3, fresh buffer: d2h 26-31 -> 20 ms).  SA_AMD_NO_PREFAULT=1: off.
+    const size_t out_bytes_all = ((size_t)n + (with_sentinel ? 1 : 0)) * 4;
+    const int copy_threads = (int)env_int("SA_AMD_COPY_THREADS", 12, 0, 32);      // 0: plain hipMemcpy into the caller's buffer
+    const size_t staged_min = (size_t)env_int("SA_AMD_STAGED_MIN_BYTES", (int64_t)64 << 20, 0, (int64_t)1 << 40);
+    const bool staged = copy_threads > 0 && out_bytes_all >= staged_min;
+    HelperPool::Async prefault;
+    HelperPool &hp = helper_pool(node);
+    struct PrefaultEnd {                                         // (also when something below throws: the helpers hold a pointer to the handle)
+        HelperPool &pool_; HelperPool::Async &h_;
+        ~PrefaultEnd() { pool_.finish(h_); }
+    } prefault_end{ hp, prefault };
     {
         LaneTurn turn(lanes.up, turns);
         rc = hip_status(hipMemcpyAsync(dT, T, (size_t)n, hipMemcpyHostToDevice, st));
@@ -169,19 +182,35 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     }
     double t1 = wall_ms();
     tm.h2d = t1 - t0;
+    // (started behind the upload: the runtime's staging of the pageable text and the page touching would share the same cores)
+    if (staged && env_int("SA_AMD_NO_PREFAULT", 0, 0, 1) == 0) {
+        char *dst = (char *)SA_host;
+        const size_t per = (((out_bytes_all + copy_threads - 1) / copy_threads) + 4095) & ~(size_t)4095;
+        hp.start(prefault, copy_threads, [=](int t) {
+            const size_t b = (size_t)t * per, e = b + per < out_bytes_all ? b + per : out_bytes_all;
+            if (b >= e) return;
+            uintptr_t a = (uintptr_t)(dst + b);
+            const uintptr_t end = (uintptr_t)(dst + e);
+            while (a < end) {
+                volatile char *q = (volatile char *)a;
+                const char c = *q;
+                *q = c;
+                a = (a + 4096) & ~(uintptr_t)4095;                // first byte of the next page
+            }
+        });
+    }
     if (rc == SA_AMD_OK) {
         LaneTurn turn(lanes.run, turns);
         rc = build_device(dT, dSA, n, dW, (int64_t)wb, st, nullptr);
     }
+    hp.finish(prefault);                                         // (usually done by now; otherwise the caller takes what is left -- also after a failed build)
     t0 = wall_ms();
     tm.build = t0 - t1;
     if (rc == SA_AMD_OK) {
         LaneTurn turn(lanes.down, turns);
         const uint32_t *src = with_sentinel ? dSA : dSA + 1;
-        const size_t out_bytes = ((size_t)n + (with_sentinel ? 1 : 0)) * 4;
-        const int copy_threads = (int)env_int("SA_AMD_COPY_THREADS", 8, 0, 32);      // 0: plain hipMemcpy into the caller's buffer
-        const size_t staged_min = (size_t)env_int("SA_AMD_STAGED_MIN_BYTES", (int64_t)64 << 20, 0, (int64_t)1 << 40);
-        if (copy_threads > 0 && out_bytes >= staged_min) {
+        const size_t out_bytes = out_bytes_all;
+        if (staged) {
             tm.staged = copy_threads;
             rc = staged_download(SA_host, src, out_bytes, st, copy_threads, cur, node);
         } else {
