@@ -118,7 +118,7 @@ public:
             snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
             if (read_small_file(path, buf, sizeof(buf)) && parse_cpulist(buf, &cpus_)) { have_cpus_ = true; cpus = CPU_COUNT(&cpus_); }
         }
-        // enough for two concurrent downloads of eight slices each; never more than the node has CPUs
+        // enough for one download of twelve slices (callers of one device download one at a time) plus a page-touching job; never more than the node has CPUs
         want_ = (int)env_int("SA_AMD_HELPER_THREADS", 16, 0, 256);
         if (cpus > 0 && want_ > cpus) want_ = cpus;
     }
