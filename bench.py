@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES = {"k_byte_hist": 1, "k_build_keys": 9, "k_radix_upsweep": 8, "k_radix_downsweep": 24,
               "k_rr_count": 8, "k_rr_apply": 24, "k_gather_key2": 20, "k_scatter_pairs": 16,
               "k_radix_upsweep32": 4, "k_radix_downsweep32": 16, "k_onesweep": 24, "k_onesweep32": 16,
-              "k_group_sort": 29, "k_finish_sorted": 8}
+              "k_group_sort": 29, "k_finish_sorted": 8, "k_bucket_sort": 16}
 EVENT_SHARE = 0.05             # classes with at least this share of a build's device time get events in the timed region
 REPORT_SHARE = 0.10            # ... and at least this share are listed in roofline.kernels
 

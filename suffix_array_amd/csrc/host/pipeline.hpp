@@ -9,6 +9,9 @@
 namespace sa {
 
 constexpr int SORT_MAX_WG = 1024;   // spine rows are scanned by one 1024-thread block
+constexpr int BK_LBITS = 16;        // bucket sort of the 32-bit first stage (kernels/bucket_sort.hpp): low key bits ordered inside a bucket
+constexpr uint32_t BK_BUCKETS = 1u << (32 - BK_LBITS);
+static_assert(BK_LBITS >= 1 && BK_LBITS <= BK_MAX_LBITS, "two 8-bit passes inside a bucket");
 constexpr size_t GRAM_MAX_ENTRIES = (size_t)1 << 24;   // gram keys: the rank table has sigma^g <= min(n, 2^24) entries
 static_assert(GROUP_CAP_MAX == GS_CAP, "Tuning clamps SA_AMD_GROUP_CAP to the kernel's cap");
 
@@ -69,6 +72,7 @@ struct Workspace {
     uint32_t *surv_bits, *surv_cnt, *todo_bits, *ft_cnt, *ft_head;   // first refinement round straight from the sorted keys (k_finish_sorted)
     unsigned long long *os_status;  // look-back granules of the single-pass tile scatter: 2 KiB per 8192-element tile
     uint32_t *os_err;
+    uint32_t *bk_start;             // bucket sort of the 32-bit first stage: 65 537 bucket starts
     SortScratch ss;
     size_t bytes;
 };
@@ -111,6 +115,7 @@ static Workspace carve(void *base, int64_t n)
     w.ft_head = (uint32_t *)take(ft_tiles * 4);
     w.os_status = (unsigned long long *)take(((size_t)ceil_div((int64_t)N, OS_MIN_TILE) + 1) * RADIX * 8);
     w.os_err = (uint32_t *)take(256);
+    w.bk_start = (uint32_t *)take(((size_t)BK_BUCKETS + 1) * 4);
     w.ss.spine = w.spine; w.ss.digit_tot = w.digit_tot; w.ss.status = w.os_status; w.ss.err = w.os_err;
     w.bytes = off;
     return w;
@@ -443,6 +448,44 @@ static FirstCounts sort_first_counts(const SortScratch &ss, const Tuning &tn, in
     }
     f.zero_bytes = (size_t)RADIX * f.G * 4;
     return f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Bucket sort of the 32-bit first stage (kernels/bucket_sort.hpp): pairs grouped by their top 16 key bits (two stable
+// global passes) -> pairs in the order of the whole 32-bit key, one workgroup per bucket, everything in LDS.
+// ------------------------------------------------------------------------------------------
+struct BkShape { int threads, items; };
+static const BkShape bk_shapes[] = { { 256, 20 }, { 512, 20 }, { 1024, 20 } };     // largest bucket: 5120, 10240, 20480 pairs
+constexpr int N_BK_SHAPES = (int)(sizeof(bk_shapes) / sizeof(bk_shapes[0]));
+static int64_t bucket_cap_max() { return (int64_t)bk_shapes[N_BK_SHAPES - 1].threads * bk_shapes[N_BK_SHAPES - 1].items; }
+
+// *done = false: some bucket is larger than every shape holds (nothing was written; the caller sorts the low bits globally).
+// words: two scratch words (largest bucket, error count); start: BK_BUCKETS + 1 words.  Read-back: the largest bucket.
+static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, int64_t count,
+                         uint32_t *start, uint32_t *words, hipStream_t st, const Tuning &tn, bool *done, uint32_t *largest)
+{
+    *done = false; *largest = 0;
+    HIP_TRY(hipMemsetAsync(words, 0, 8, st));
+    PROF(KC_MISC, BK_BUCKETS, st, hipLaunchKernelGGL((k_bucket_starts), dim3((unsigned)ceil_div((int64_t)BK_BUCKETS + 1, BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS),
+                                                       0, st, keys_in, count, BK_LBITS, BK_BUCKETS, start));
+    PROF(KC_MISC, BK_BUCKETS, st, hipLaunchKernelGGL((k_bucket_max), dim3((unsigned)ceil_div((int64_t)BK_BUCKETS, BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS), 0, st,
+                                                       (const uint32_t *)start, BK_BUCKETS, words));
+    uint32_t maxb = 0;
+    { const int rcw = read_words(&maxb, words, 4, st); if (rcw) return rcw; }
+    *largest = maxb;
+    int shape = tn.bucket_shape;
+    while (shape < N_BK_SHAPES && (int64_t)bk_shapes[shape].threads * bk_shapes[shape].items < (int64_t)maxb) ++shape;
+    if (shape >= N_BK_SHAPES) return SA_AMD_OK;
+#define BK_LAUNCH(T, I) PROF(KC_BUCKET, count, st, hipLaunchKernelGGL((k_bucket_sort<T, I>), dim3(BK_BUCKETS), dim3(T), 0, st, keys_in, vals_in, \
+                                                                       (const uint32_t *)start, BK_LBITS, keys_out, vals_out, words + 1))
+    switch (shape) {
+    case 0: BK_LAUNCH(256, 20); break;
+    case 1: BK_LAUNCH(512, 20); break;
+    default: BK_LAUNCH(1024, 20); break;
+    }
+#undef BK_LAUNCH
+    *done = true;
+    return SA_AMD_OK;
 }
 
 // symbol codes and key geometry from the sigma = 256 histogram; returns the number of key bits to sort
@@ -997,20 +1040,45 @@ struct DeviceBuild {
         }
         if (top_shift) {
             uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
+            // Two global passes over the key bits 16..31 + one pass that orders every bucket (= value of the top 16 bits) in LDS, when
+            // an average bucket fits a workgroup (n = 2^28: 4096 pairs; 2^30: 16384); a text whose LARGEST bucket does not -- known
+            // only once the two passes have run -- builds its keys again and takes the four global passes.
+            bool bucket_route = !tn.no_bucket_sort && n >= tn.bucket_min_n && n > 1 && (int64_t)(n / BK_BUCKETS) * 10 <= bucket_cap_max() * 9;
+            for (;;) {
             // the first radix pass's digit histogram comes out of k_build_keys (keys in registers there): one read of every key less
             const FirstCounts fc = sort_first_counts(w.ss, tn, n, true);
             const bool counted = n > 1;
             if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
             PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
                                                           (uint64_t *)nullptr, vals0, k32a, top_shift, packed_out,
-                                                          counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, 0xffu));
+                                                          counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, 0xffu, bucket_route ? BK_LBITS : 0));
             SortResult32 s32;
+            if (bucket_route) {
+                rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, BK_LBITS, 32, w.ss, nullptr, st, &s32, tn, iota, counted);
+                if (rc) return rc;
+                local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
+                uint32_t *kout = (s32.keys == k32a) ? k32b : k32a;
+                bool done = false;
+                uint32_t largest = 0;
+                rc = bucket_sort32(s32.keys, s32.vals, kout, SA, n, w.bk_start, w.os_err + 2, st, tn, &done, &largest);
+                if (rc) return rc;
+                if (trace) fprintf(stderr, "suffix_array_amd: 32-bit first stage: %d global passes, largest bucket %u -> %s\n", s32.passes, largest,
+                                   done ? "low 16 bits ordered bucket by bucket in LDS" : "too large: keys rebuilt, four global passes");
+                if (!done) { bucket_route = false; continue; }
+                local.sort_passes += 1; local.sorted_elements += n;
+                sorted32 = kout;
+                sr.vals = SA; sr.passes = s32.passes + 1;
+                sr.keys = (kout == k32a) ? w.keysA : w.keysB;
+                break;
+            }
             rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 0, 32, w.ss, SA, st, &s32, tn, iota, counted);
             if (rc) return rc;
             local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
             sorted32 = s32.keys;
             sr.vals = s32.vals; sr.passes = s32.passes;
             sr.keys = (s32.keys == k32a) ? w.keysA : w.keysB;      // the 8n-byte buffer that now holds the sorted 32-bit keys
+            break;
+            }
         } else {
             const FirstCounts fc = sort_first_counts(w.ss, tn, n, false);
             const bool counted = n > 1 && key_bits > 0;
@@ -1489,9 +1557,10 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     LAUNCH_CHECK(st);
     {
         // (synchronises the stream) a look-back that gave up means a tile scatter wrote nothing useful: never a silent wrong array
-        uint32_t gave_up = 0;
-        const int rcw = read_words(&gave_up, w.os_err, 4, st); if (rcw) return rcw;
-        if (gave_up) return SA_AMD_EINTERNAL;
+        // (word 3: a bucket larger than the shape the host picked for k_bucket_sort)
+        uint32_t gave_up[4] = { 0, 0, 0, 0 };
+        const int rcw = read_words(gave_up, w.os_err, 16, st); if (rcw) return rcw;
+        if (gave_up[0] || gave_up[3]) return SA_AMD_EINTERNAL;
     }
     g_prof.resolve();
     g_last_stats = local;

@@ -4,6 +4,7 @@
 #include "../kernels/keys.hpp"
 #include "../kernels/radix_sort.hpp"
 #include "../kernels/onesweep.hpp"
+#include "../kernels/bucket_sort.hpp"
 #include "../kernels/rerank.hpp"
 #include "../kernels/refine.hpp"
 #include "../kernels/isa.hpp"
@@ -96,13 +97,14 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
 enum KClass { KC_BYTE_HIST = 0, KC_BUILD_KEYS, KC_UPSWEEP, KC_SPINE, KC_DOWNSWEEP, KC_RR_COUNT, KC_RR_SCAN, KC_RR_APPLY,
-              KC_GATHER, KC_SCATTER, KC_LOCAL, KC_MISC, KC_UPSWEEP32, KC_DOWNSWEEP32, KC_ONESWEEP, KC_ONESWEEP32, KC_FINISH, KC_COUNT };
+              KC_GATHER, KC_SCATTER, KC_LOCAL, KC_MISC, KC_UPSWEEP32, KC_DOWNSWEEP32, KC_ONESWEEP, KC_ONESWEEP32, KC_FINISH, KC_BUCKET, KC_COUNT };
 static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys", "k_radix_upsweep", "k_spine_rows",
                                                     "k_radix_downsweep", "k_rr_count", "k_rr_scan", "k_rr_apply",
                                                     "k_gather_key2", "k_scatter_pairs", "k_group_sort", "misc",   // (k_gather_key2: the plain gathers; k_group_sort: all fused gather + sort kernels)
                                                     "k_radix_upsweep32", "k_radix_downsweep32",
                                                     "k_onesweep", "k_onesweep32",      // single-pass tile scatter, 64- / 32-bit keys (kernels/onesweep.hpp)
-                                                    "k_finish_sorted" };               // one pass over the sorted keys that orders the small groups in place
+                                                    "k_finish_sorted",                 // one pass over the sorted keys that orders the small groups in place
+                                                    "k_bucket_sort" };                 // the low 16 bits of the 32-bit first stage, bucket by bucket in LDS (kernels/bucket_sort.hpp)
 struct Profiler {
     bool on = false;
     uint64_t mask = ~0ull;      // kernel classes that get events (each pair costs a few microseconds of host time)

@@ -1,0 +1,181 @@
+// kernels/bucket_sort.hpp -- the low 16 bits of the 32-bit first stage, ordered bucket by bucket in LDS.
+// Part of the MI355X-native suffix-array engine (gfx950 / CDNA4, wave64); see DESIGN.md section 3.
+// Replaces two of the four global tile-scatter passes of the 32-bit initial sort, i.e. part of the arithmetic behind
+// `cdivsufsort::sort_in_place` (reference src/saca.rs:14).
+//
+// A stable LSD sort may stop early: after the passes over the key bits 16..31 the pairs are grouped by their top 16 bits
+// (a BUCKET, contiguous, its members in text order), and what the two passes over the bits 0..15 would have done --
+// 2 x 16 bytes per pair through a 256-way scatter -- is a sort INSIDE every bucket.  With n = 2^28 suffixes of random
+// bytes a bucket holds 4096 +- 64 pairs: it fits in LDS, so one workgroup per bucket reads its pairs once (coalesced),
+// orders them by two 8-bit counting passes in LDS (the ranking of the tile scatter: 8 ballots + mbcnt per key, per-wave
+// digit counts in LDS) and writes them back in order (coalesced, sequential): 16 bytes per pair at streaming speed
+// instead of 32 at scatter speed.
+//   k_bucket_starts  start[b] = first pair whose key >> lbits is >= b, by binary search in the grouped keys
+//                    (65 537 searches; the first levels are shared and cache-resident), and the largest bucket
+//   k_bucket_sort    one workgroup per bucket; THREADS x ITEMS = the largest bucket the shape can hold; the host reads
+//                    the largest bucket back and picks the shape -- a text whose buckets are too large for every shape
+//                    (a skewed alphabet that the entropy probe nevertheless sent to the 32-bit stage) takes the four
+//                    global passes as before
+// Only the low 16 key bits are staged (the top 16 are the bucket's number): 6 bytes of LDS per pair.
+// Algorithmic traffic: 8 B read + 8 B written per pair.
+#pragma once
+#include "common.hpp"
+#include "radix_sort.hpp"
+
+namespace sa {
+
+constexpr int BK_MAX_LBITS = 16;             // at most two 8-bit passes inside a bucket
+constexpr int BK_STARTS_THREADS = 256;
+
+// start[0 .. nb]: first index whose key >> lbits is >= b (start[nb] = n: nb is past the last bucket in use)
+__global__ __launch_bounds__(BK_STARTS_THREADS) void k_bucket_starts(const uint32_t *__restrict__ keys, int64_t n, int lbits, uint32_t nb,
+                                                                     uint32_t *__restrict__ start)
+{
+    const uint32_t b = blockIdx.x * BK_STARTS_THREADS + threadIdx.x;
+    if (b > nb) return;
+    int64_t lo = 0, hi = n;                    // first index in [0, n] with (keys[i] >> lbits) >= b
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((keys[mid] >> lbits) >= b) hi = mid; else lo = mid + 1;
+    }
+    start[b] = (uint32_t)lo;
+}
+
+// words[0] = the largest bucket (zeroed by the host)
+__global__ __launch_bounds__(BK_STARTS_THREADS) void k_bucket_max(const uint32_t *__restrict__ start, uint32_t nb, uint32_t *__restrict__ words)
+{
+    __shared__ uint32_t lds[BK_STARTS_THREADS / WAVE];
+    const uint32_t b = blockIdx.x * BK_STARTS_THREADS + threadIdx.x;
+    const uint32_t sz = b < nb ? start[b + 1] - start[b] : 0u;
+    uint32_t tot;
+    (void)block_incl_max<BK_STARTS_THREADS>(sz, lds, &tot);
+    if (threadIdx.x == 0 && tot) atomicMax(&words[0], tot);
+}
+
+// One workgroup per bucket.  Element e of the bucket is held by wave e / (64 J), item (e / 64) % J, lane e % 64 with
+// J = ceil(size / THREADS) items in use (wave-striped, so a stable rank inside the wave is a prefix count over lanes and items).
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_bucket_sort(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                         const uint32_t *__restrict__ start, int lbits,
+                                                         uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                         uint32_t *__restrict__ err)
+{
+    constexpr int CAP = THREADS * ITEMS;
+    constexpr int NWAVES = THREADS / WAVE;
+    static_assert(THREADS >= RADIX, "thread d owns digit d");
+    static_assert(CAP < 65536, "16-bit bucket-local positions");
+    static_assert(ITEMS % 2 == 0, "positions are packed two to a register");
+    __shared__ uint16_t lds_k[CAP];
+    __shared__ uint32_t lds_v[CAP];
+    __shared__ uint16_t wave_hist[NWAVES][RADIX];
+    __shared__ uint32_t digit_base[RADIX];
+    __shared__ uint32_t scan_lds[NWAVES + 1];
+
+    const int tid = threadIdx.x, l = lane_id(), w = wave_id();
+    const uint32_t b = blockIdx.x;
+    const uint32_t lo = start[b];
+    const int size = (int)(start[b + 1] - lo);
+    if (size <= 0) return;
+    if (size > CAP) { if (tid == 0) atomicAdd(err, 1u); return; }      // (the host picked the shape from the largest bucket: cannot happen)
+    const int J = (size + THREADS - 1) / THREADS;
+    const int e0 = w * J * WAVE + l;
+    uint16_t *my_hist = wave_hist[w];
+
+    uint32_t key[ITEMS], val[ITEMS], pp[ITEMS / 2];
+#define BK_POS(j) ((pp[(j) >> 1] >> (16 * ((j) & 1))) & 0xffffu)
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        // (register arrays are only ever assigned unconditionally, from scalars: conditional element stores make the compiler keep
+        // the arrays as 32-wide vectors that it copies and spills around every branch)
+        const int e = e0 + j * WAVE;
+        uint32_t kx = 0, vx = 0;
+        if (j < J && e < size) { kx = keys_in[lo + e]; vx = vals_in[lo + e]; }
+        key[j] = kx; val[j] = vx;
+    }
+    const uint32_t hi_bits = (keys_in[lo] >> lbits) << lbits;      // the bucket's number, as key bits (1 <= lbits <= 16, host-checked)
+    const uint32_t lo_mask = (1u << lbits) - 1u;
+
+#pragma unroll
+    for (int pass = 0; pass < BK_MAX_LBITS / RADIX_BITS; ++pass) {
+        const int shift = pass * RADIX_BITS;
+        if (shift >= lbits) break;                 // (uniform)
+        const int nbits = lbits - shift < RADIX_BITS ? lbits - shift : RADIX_BITS;
+        const uint32_t dmask = (1u << nbits) - 1u;
+        if (pass > 0) {
+            // the order of the pass before: back into registers, wave-striped
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int e = e0 + j * WAVE;
+                uint32_t kx = 0, vx = 0;
+                if (j < J && e < size) { kx = lds_k[e]; vx = lds_v[e]; }
+                key[j] = kx; val[j] = vx;
+            }
+        }
+        for (int i = tid; i < NWAVES * RADIX / 2; i += THREADS) ((uint32_t *)&wave_hist[0][0])[i] = 0;
+        __syncthreads();
+        // ---- rank inside the wave: lanes with my digit below me + earlier items (8 ballots + mbcnt) ----
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            uint32_t r = 0;
+            if (j < J) {                           // (uniform)
+                const bool ok = (e0 + j * WAVE) < size;
+                const uint32_t d = (key[j] >> shift) & dmask;
+                const uint64_t okm = __ballot(ok);
+                uint32_t xlo = ~(uint32_t)okm, xhi = ~(uint32_t)(okm >> 32);
+#pragma unroll
+                for (int bb = 0; bb < RADIX_BITS; ++bb) {
+                    const uint32_t sel = (uint32_t)((int32_t)(d << (31 - bb)) >> 31);
+                    const uint64_t bal = __ballot(sel != 0);
+                    xlo |= (uint32_t)bal ^ sel;
+                    xhi |= (uint32_t)(bal >> 32) ^ sel;
+                }
+                const uint32_t mlo = ~xlo, mhi = ~xhi;
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                const uint32_t prior = my_hist[d];
+                if (ok && below == 0) my_hist[d] = (uint16_t)(prior + (uint32_t)(__popc(mlo) + __popc(mhi)));
+                r = prior + below;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((j & 1) == 0) pp[j >> 1] = r; else pp[j >> 1] |= r << 16;
+        }
+        lds_barrier();
+        // ---- thread d: per-wave offsets of digit d, its start in the bucket ----
+        uint32_t tot = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int ww = 0; ww < NWAVES; ++ww) {
+                const uint32_t cnt = wave_hist[ww][tid];
+                wave_hist[ww][tid] = (uint16_t)tot;
+                tot += cnt;
+            }
+        }
+        uint32_t all;
+        const uint32_t dbase = block_excl_sum_b<THREADS, true>(tot, scan_lds, &all);
+        if (tid < RADIX) digit_base[tid] = dbase;
+        lds_barrier();
+        // ---- into LDS in the order of this digit (stable) ----
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (j < J && (e0 + j * WAVE) < size) {
+                const uint32_t d = (key[j] >> shift) & dmask;
+                const uint32_t ps = BK_POS(j) + digit_base[d] + my_hist[d];
+                lds_k[ps] = (uint16_t)(key[j] & lo_mask);
+                lds_v[ps] = val[j];
+            }
+        }
+    }
+#undef BK_POS
+    __syncthreads();
+    // ---- LDS -> global, in order ----
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = tid + j * THREADS;
+        if (idx < size) {
+            keys_out[lo + idx] = hi_bits | (uint32_t)lds_k[idx];
+            vals_out[lo + idx] = lds_v[idx];
+        }
+    }
+}
+
+}  // namespace sa

@@ -91,7 +91,7 @@ __device__ __forceinline__ uint32_t gram_rank(const uint4 *__restrict__ table, u
 __device__ __forceinline__ void kb_stage_codes(const uint8_t *__restrict__ T, int64_t n, int64_t base, const uint8_t *lcode, uint8_t *c, int tid);
 
 // TOP32: only the top 32 bits of every key are stored (keys32), for the two-stage initial sort
-// A workgroup takes KB_TPW consecutive tiles.  counts != nullptr: it also histograms the lowest digit (key & dmask) of the
+// A workgroup takes KB_TPW consecutive tiles.  counts != nullptr: it also histograms the digit ((key >> dshift) & dmask) of the
 // keys it writes -- the digit of the first radix pass -- and adds it to that pass's spine (counts[d * G + chunk], zeroed by
 // the host; chunk_elems is a multiple of KB_TILE), so the first k_radix_upsweep[32] launch and its read of every key go away.
 constexpr int KB_TPW = 8;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
                                                             KeyParams P, uint64_t *__restrict__ keys,
                                                             uint32_t *__restrict__ vals, uint32_t *__restrict__ keys32,
                                                             int top_shift, uint8_t *__restrict__ packed_out,
-                                                            uint32_t *__restrict__ counts, int64_t chunk_elems, int G, uint32_t dmask)
+                                                            uint32_t *__restrict__ counts, int64_t chunk_elems, int G, uint32_t dmask, int dshift = 0)
 {
     __shared__ uint8_t lcode[256];
     __shared__ __attribute__((aligned(16))) uint8_t c[KB_TILE + KB_HALO];
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
 #pragma unroll
         for (int r = 0; r < KB_ITEMS; ++r) {
             const bool in = g0 + r < n;
-            const uint32_t d = (uint32_t)(TOP32 ? (kk[r] >> top_shift) : kk[r]) & dmask;
+            const uint32_t d = (uint32_t)((TOP32 ? (kk[r] >> top_shift) : kk[r]) >> dshift) & dmask;
             const uint64_t act = __ballot(in);
             const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
             if (__all(!in || d == f)) {                       // one digit for the whole wave (runs, tiny alphabets): one add, not 64 on one address
