@@ -454,15 +454,22 @@ static FirstCounts sort_first_counts(const SortScratch &ss, const Tuning &tn, in
 // Bucket sort of the 32-bit first stage (kernels/bucket_sort.hpp): pairs grouped by their top 16 key bits (two stable
 // global passes) -> pairs in the order of the whole 32-bit key, one workgroup per bucket, everything in LDS.
 // ------------------------------------------------------------------------------------------
-struct BkShape { int threads, items; };
-static const BkShape bk_shapes[] = { { 256, 20 }, { 512, 20 }, { 1024, 20 } };     // largest bucket: 5120, 10240, 20480 pairs
+struct BkShape { int threads, items, minw; };
+// (threads, pairs per thread, waves per SIMD the registers are held to); the first three are the ones in use -- the smallest that
+// holds the largest bucket is taken --, the fourth is kept for A/B measurements (SA_AMD_BUCKET_SHAPE tries that one first)
+static const BkShape bk_shapes[] = { { 512, 10, 8 }, { 1024, 10, 8 }, { 1024, 20, 1 }, { 256, 20, 1 } };
 constexpr int N_BK_SHAPES = (int)(sizeof(bk_shapes) / sizeof(bk_shapes[0]));
-static int64_t bucket_cap_max() { return (int64_t)bk_shapes[N_BK_SHAPES - 1].threads * bk_shapes[N_BK_SHAPES - 1].items; }
+constexpr int N_BK_DEFAULT = 3;
+static int64_t bucket_cap(int shape) { return (int64_t)bk_shapes[shape].threads * bk_shapes[shape].items; }
+static int64_t bucket_cap_max() { return bucket_cap(N_BK_DEFAULT - 1); }
 
 // *done = false: some bucket is larger than every shape holds (nothing was written; the caller sorts the low bits globally).
 // words: two scratch words (largest bucket, error count); start: BK_BUCKETS + 1 words.  Read-back: the largest bucket.
+// fin != nullptr: the tied suffixes are ordered by their low key bits in the same launch (what k_finish_sorted does in a pass of
+// its own); the caller has zeroed fin's bitmap and counters.
 static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, int64_t count,
-                         uint32_t *start, uint32_t *words, hipStream_t st, const Tuning &tn, bool *done, uint32_t *largest)
+                         uint32_t *start, uint32_t *words, hipStream_t st, const Tuning &tn, bool *done, uint32_t *largest,
+                         const BucketFinish *fin = nullptr, const KeyParams *P = nullptr, const KeySrc *K = nullptr)
 {
     *done = false; *largest = 0;
     HIP_TRY(hipMemsetAsync(words, 0, 8, st));
@@ -473,15 +480,26 @@ static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint3
     uint32_t maxb = 0;
     { const int rcw = read_words(&maxb, words, 4, st); if (rcw) return rcw; }
     *largest = maxb;
-    int shape = tn.bucket_shape;
-    while (shape < N_BK_SHAPES && (int64_t)bk_shapes[shape].threads * bk_shapes[shape].items < (int64_t)maxb) ++shape;
-    if (shape >= N_BK_SHAPES) return SA_AMD_OK;
-#define BK_LAUNCH(T, I) PROF(KC_BUCKET, count, st, hipLaunchKernelGGL((k_bucket_sort<T, I>), dim3(BK_BUCKETS), dim3(T), 0, st, keys_in, vals_in, \
-                                                                       (const uint32_t *)start, BK_LBITS, keys_out, vals_out, words + 1))
+    int shape = -1;
+    if (tn.bucket_shape >= 0 && tn.bucket_shape < N_BK_SHAPES && bucket_cap(tn.bucket_shape) >= (int64_t)maxb) shape = tn.bucket_shape;
+    for (int c = 0; shape < 0 && c < N_BK_DEFAULT; ++c)
+        if (bucket_cap(c) >= (int64_t)maxb) shape = c;
+    if (shape < 0) return SA_AMD_OK;
+    const BucketFinish F0 = BucketFinish();
+    const KeyParams P0 = KeyParams();
+    const KeySrc K0 = KeySrc();
+#define BK_LAUNCH(T, I, W)                                                                                                               \
+    do {                                                                                                                                 \
+        if (fin) PROF(KC_BUCKET, count, st, hipLaunchKernelGGL((k_bucket_sort<T, I, W, true>), dim3(BK_BUCKETS), dim3(T), 0, st, keys_in, vals_in, \
+                                                               (const uint32_t *)start, BK_LBITS, keys_out, vals_out, words + 1, *fin, *P, *K));     \
+        else PROF(KC_BUCKET, count, st, hipLaunchKernelGGL((k_bucket_sort<T, I, W, false>), dim3(BK_BUCKETS), dim3(T), 0, st, keys_in, vals_in,    \
+                                                            (const uint32_t *)start, BK_LBITS, keys_out, vals_out, words + 1, F0, P0, K0));          \
+    } while (0)
     switch (shape) {
-    case 0: BK_LAUNCH(256, 20); break;
-    case 1: BK_LAUNCH(512, 20); break;
-    default: BK_LAUNCH(1024, 20); break;
+    case 0: BK_LAUNCH(512, 10, 8); break;
+    case 1: BK_LAUNCH(1024, 10, 8); break;
+    case 2: BK_LAUNCH(1024, 20, 1); break;
+    default: BK_LAUNCH(256, 20, 1); break;
     }
 #undef BK_LAUNCH
     *done = true;
@@ -907,6 +925,7 @@ struct DeviceBuild {
     // ---- initial order (initial_sort) ----
     SortResult sr;
     const uint32_t *sorted32 = nullptr; // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
+    bool bucket_finished = false;       // ... and k_bucket_sort has already ordered the suffixes tied on those 32 bits by their low key bits
     uint64_t *sorted0 = nullptr;        // the initial keys in SA order (kept for the rank look-ups)
     // ---- the tied list and its buffers (from first_round_from_sorted_keys on) ----
     uint32_t *Ucur = nullptr, *Unext = nullptr, *Gcur = nullptr, *Gnext = nullptr, *Vcur = nullptr;
@@ -1028,6 +1047,7 @@ struct DeviceBuild {
         //    (u32, u32) pairs in 12 Ki-element tiles -- two thirds of the bytes per pass and half the passes
         sr.keys = w.keysA; sr.vals = w.valsA; sr.passes = 0;
         sorted32 = nullptr;               // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
+        bucket_finished = false;
         // value of pair i = i: not stored by k_build_keys, the first sort pass takes the index (saves 8 B / suffix)
         const bool iota = n >= 2 && key_bits > 0;
         uint32_t *vals0 = iota ? (uint32_t *)nullptr : w.valsA;
@@ -1060,11 +1080,27 @@ struct DeviceBuild {
                 uint32_t *kout = (s32.keys == k32a) ? k32b : k32a;
                 bool done = false;
                 uint32_t largest = 0;
-                rc = bucket_sort32(s32.keys, s32.vals, kout, SA, n, w.bk_start, w.os_err + 2, st, tn, &done, &largest);
+                // the round on the low key bits of the suffixes tied on all 32 (first_round_from_sorted_keys) in the same launch
+                const bool fuse = local_ok && !tn.no_fused_finish && !tn.no_bucket_finish && !timing_only();
+                BucketFinish F = BucketFinish();
+                KeySrc K = KeySrc();
+                if (fuse) {
+                    const int64_t rr_tiles = ceil_div(n, RR_TILE);
+                    HIP_TRY(hipMemsetAsync(w.surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
+                    HIP_TRY(hipMemsetAsync(w.tcnt, 0, (size_t)rr_tiles * 4, st));
+                    HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)rr_tiles * 4, st));
+                    HIP_TRY(hipMemsetAsync(w.total, 0, 16, st));
+                    HIP_TRY(hipMemsetAsync(w.chg, 0, (size_t)RR_CHG_COUNTERS * 32 * 4, st));
+                    F.T = dT; F.n = n; F.cap = tn.group_cap; F.surv_bits = w.surv_bits; F.surv_head = w.isa; F.tile_cnt = w.tcnt; F.counters = w.total;
+                    K.mode = KS_LOWKEY; K.kb = top_shift;
+                }
+                rc = bucket_sort32(s32.keys, s32.vals, kout, SA, n, w.bk_start, w.os_err + 2, st, tn, &done, &largest,
+                                   fuse ? &F : nullptr, &P, &K);
                 if (rc) return rc;
+                bucket_finished = done && fuse;
                 if (trace) fprintf(stderr, "suffix_array_amd: 32-bit first stage: %d global passes, largest bucket %u -> %s\n", s32.passes, largest,
                                    done ? "low 16 bits ordered bucket by bucket in LDS" : "too large: keys rebuilt, four global passes");
-                if (!done) { bucket_route = false; continue; }
+                if (!done) { bucket_route = false; continue; }      // (nothing was launched: the finish buffers are zeroed again by whoever uses them)
                 local.sort_passes += 1; local.sorted_elements += n;
                 sorted32 = kout;
                 sr.vals = SA; sr.passes = s32.passes + 1;
@@ -1140,6 +1176,7 @@ struct DeviceBuild {
             // (k_finish_sorted); only if some group is too large for it does the general path below run instead
             const int cap = tn.group_cap;
             uint32_t *surv_bits = w.surv_bits, *surv_head = w.isa;  // (the ISA is not in use before the doubling rounds)
+            if (!bucket_finished) {      // (else k_bucket_sort has done this round while it had the buckets in LDS, into the same records)
             HIP_TRY(hipMemsetAsync(surv_bits, 0, ((size_t)n + 31) / 32 * 4, st));
             HIP_TRY(hipMemsetAsync(w.tcnt, 0, (size_t)tiles * 4, st));
             HIP_TRY(hipMemsetAsync(w.thead, 0, (size_t)tiles * 4, st));
@@ -1149,6 +1186,7 @@ struct DeviceBuild {
             PROF(KC_FINISH, n, st, hipLaunchKernelGGL((k_finish_sorted<uint32_t, KS_LOWKEY, false>), dim3((unsigned)ceil_div(n, FT_TILE)), dim3(FT_THREADS),
                                                      0, st, sorted32, SA, dT, P, n, K, cap, surv_bits, surv_head, w.tcnt, w.total, (uint32_t *)nullptr,
                                                      (uint32_t *)nullptr, (uint32_t *)nullptr));
+            }
             PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
             uint32_t cnt3[3] = { 0, 0, 0 };                       // still tied on 64 bits, members of groups nobody owned, tied on 32 bits
             {

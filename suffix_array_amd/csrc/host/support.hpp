@@ -4,9 +4,9 @@
 #include "../kernels/keys.hpp"
 #include "../kernels/radix_sort.hpp"
 #include "../kernels/onesweep.hpp"
-#include "../kernels/bucket_sort.hpp"
 #include "../kernels/rerank.hpp"
 #include "../kernels/refine.hpp"
+#include "../kernels/bucket_sort.hpp"
 #include "../kernels/isa.hpp"
 #include "../kernels/extras.hpp"
 #include "../kernels/small.hpp"

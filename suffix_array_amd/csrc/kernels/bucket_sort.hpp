@@ -17,10 +17,17 @@
 //                    (a skewed alphabet that the entropy probe nevertheless sent to the 32-bit stage) takes the four
 //                    global passes as before
 // Only the low 16 key bits are staged (the top 16 are the bucket's number): 6 bytes of LDS per pair.
-// Algorithmic traffic: 8 B read + 8 B written per pair.
+// FINISH = true: the round that k_finish_sorted (kernels/refine.hpp) runs over the sorted keys happens here, while the bucket
+// is still in LDS -- suffixes tied on all 32 bits (a run of equal staged keys; never across buckets) fetch their low key bits
+// from the text, are ranked inside their group and change places; the ones that are still tied are recorded for the later
+// rounds exactly as k_finish_sorted records them (bitmap, slot of the subgroup's first member, count per re-rank tile).  The
+// low keys travel through the values' LDS words, so the stage stays at 6 bytes per pair.
+// Algorithmic traffic: 8 B read + 8 B written per pair (+ the text look-ups of the tied suffixes).
 #pragma once
 #include "common.hpp"
 #include "radix_sort.hpp"
+#include "rerank.hpp"
+#include "refine.hpp"
 
 namespace sa {
 
@@ -54,11 +61,19 @@ __global__ __launch_bounds__(BK_STARTS_THREADS) void k_bucket_max(const uint32_t
 
 // One workgroup per bucket.  Element e of the bucket is held by wave e / (64 J), item (e / 64) % J, lane e % 64 with
 // J = ceil(size / THREADS) items in use (wave-striped, so a stable rank inside the wave is a prefix count over lanes and items).
-template <int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS) void k_bucket_sort(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+// what the fused finish needs (FINISH = true): the text and its key geometry come as separate kernel arguments
+struct BucketFinish {
+    const uint8_t *T;
+    int64_t n;
+    int cap;                        // largest group ordered here (a larger one only bumps counters[1]: the host runs the general path)
+    uint32_t *surv_bits, *surv_head, *tile_cnt, *counters;    // as k_finish_sorted's
+};
+
+template <int THREADS, int ITEMS, int MINW = 1, bool FINISH = false>
+__global__ __launch_bounds__(THREADS, MINW) void k_bucket_sort(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                          const uint32_t *__restrict__ start, int lbits,
                                                          uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                                                         uint32_t *__restrict__ err)
+                                                         uint32_t *__restrict__ err, BucketFinish F, KeyParams P, KeySrc K)
 {
     constexpr int CAP = THREADS * ITEMS;
     constexpr int NWAVES = THREADS / WAVE;
@@ -70,8 +85,24 @@ __global__ __launch_bounds__(THREADS) void k_bucket_sort(const uint32_t *__restr
     __shared__ uint16_t wave_hist[NWAVES][RADIX];
     __shared__ uint32_t digit_base[RADIX];
     __shared__ uint32_t scan_lds[NWAVES + 1];
+    constexpr int SURV_WORDS = FINISH ? CAP / 32 + 2 : 1;
+    __shared__ uint8_t lcode[FINISH ? 256 : 1];
+    __shared__ uint32_t s_surv[SURV_WORDS];        // survivor bits of this bucket's slots, word-aligned to the global bitmap
+    __shared__ uint32_t s_cnt[2];
+    // work list of the tied slots: in the per-wave digit counts (free once the bucket is ordered) when a thread stages at most
+    // 10 pairs -- room for 40 % of the bucket's slots --, else (20 pairs per thread) in an array of its own for half of them
+    constexpr int R_MAX = ITEMS <= 10 ? 4 : 10;
+    constexpr int LCAP = ITEMS <= 10 ? NWAVES * RADIX : CAP / 2;
+    static_assert(LCAP <= R_MAX * THREADS, "every list entry has a thread and a round");
+    __shared__ uint16_t s_list_own[FINISH && ITEMS > 10 ? LCAP : 1];
+    uint16_t *s_list = ITEMS <= 10 ? &wave_hist[0][0] : s_list_own;
 
     const int tid = threadIdx.x, l = lane_id(), w = wave_id();
+    if (FINISH) {
+        if (tid < 256) lcode[tid] = P.code[tid];
+        for (int i = tid; i < SURV_WORDS; i += THREADS) s_surv[i] = 0;
+        if (tid < 2) s_cnt[tid] = 0;
+    }
     const uint32_t b = blockIdx.x;
     const uint32_t lo = start[b];
     const int size = (int)(start[b + 1] - lo);
@@ -167,6 +198,126 @@ __global__ __launch_bounds__(THREADS) void k_bucket_sort(const uint32_t *__restr
     }
 #undef BK_POS
     __syncthreads();
+    if (FINISH) {
+        // ---- suffixes tied on all 32 key bits: ordered by their low key bits, inside the staged bucket ----
+        // Work list of the tied slots (any order), then R rounds of THREADS entries; the thread that takes an entry keeps it through
+        // all phases.  Texts the probe sends here have few ties (random bytes at n = 2^28: 6 % of the slots; DNA at 2^30: 22 %), so a
+        // thread holds one to five entries and that many text look-ups are exposed, not one per slot it staged.
+        const bool aligned8 = (((uintptr_t)F.T) & 7) == 0;
+        const int cap = F.cap;
+        uint32_t n_unowned = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int idx = tid + j * THREADS;
+            bool tied = false;
+            if (j < J && idx < size) {
+                const uint16_t k = lds_k[idx];
+                tied = (idx > 0 && lds_k[idx - 1] == k) || (idx + 1 < size && lds_k[idx + 1] == k);
+            }
+            if (j < J) {                           // (uniform)
+                const uint64_t m = __ballot(tied);
+                if (m) {
+                    uint32_t base = 0;
+                    if (l == 0) base = atomicAdd(&s_cnt[1], (uint32_t)__popcll(m));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (tied && slot < (uint32_t)LCAP) s_list[slot] = (uint16_t)idx;
+                }
+            }
+        }
+        lds_barrier();
+        // No room in the list (far more ties than this route is meant for): nothing in this bucket moves -- a group with
+        // members in the list and members outside it must not be ordered by the ones inside -- and the whole bucket is reported.
+        const int n_tied = (int)s_cnt[1];
+        const int n_list = n_tied <= LCAP ? n_tied : 0;
+        if (n_tied > LCAP && tid == 0) n_unowned += (uint32_t)n_tied;
+        uint32_t fi[R_MAX], fv[R_MAX], fk[R_MAX], fse[R_MAX], fd[R_MAX];
+        uint32_t own_mask = 0;
+#pragma unroll
+        for (int r = 0; r < R_MAX; ++r) {
+            const int q = tid + r * THREADS;
+            uint32_t ii = 0, se = 0, vv = 0, own = 0;
+            if (q < n_list) {
+                const int idx = (int)s_list[q];
+                const uint16_t k = lds_k[idx];
+                int sb = idx, eb = idx + 1;
+                while (sb > 0 && lds_k[sb - 1] == k && idx - sb <= cap) --sb;
+                while (eb < size && lds_k[eb] == k && eb - sb <= cap) ++eb;
+                if (eb - sb <= cap && !(sb > 0 && lds_k[sb - 1] == k)) {
+                    own = 1u;
+                    ii = (uint32_t)idx;
+                    se = (uint32_t)sb | ((uint32_t)eb << 16);
+                    vv = lds_v[idx];
+                } else ++n_unowned;                // too large for this round: reported, left in text order
+            }
+            fi[r] = ii; fse[r] = se; fv[r] = vv;
+            own_mask |= own << r;
+        }
+#pragma unroll
+        for (int r = 0; r < R_MAX; ++r) {
+            uint32_t k2 = 0;
+            if (r * THREADS < n_list) k2 = (uint32_t)text_key2<KS_LOWKEY>(F.T, lcode, P, F.n, K, fv[r], aligned8);      // (uniform branch)
+            fk[r] = k2;
+        }
+        lds_barrier();                             // every value of a listed slot is in a register
+#pragma unroll
+        for (int r = 0; r < R_MAX; ++r)
+            if ((own_mask >> r) & 1u) lds_v[fi[r]] = fk[r];
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < R_MAX; ++r) {
+            uint32_t d = 0;
+            if ((own_mask >> r) & 1u) {
+                const int idx = (int)fi[r], sb = (int)(fse[r] & 0xffffu), eb = (int)(fse[r] >> 16);
+                const uint32_t me = fk[r];
+                int rank = 0;
+                for (int q = sb; q < eb; ++q) {
+                    const uint32_t kq = lds_v[q];
+                    rank += (kq < me || (kq == me && q < idx)) ? 1 : 0;
+                }
+                d = (uint32_t)(sb + rank);
+            }
+            fd[r] = d;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < R_MAX; ++r)
+            if ((own_mask >> r) & 1u) lds_v[fd[r]] = fk[r];
+        lds_barrier();
+        const uint32_t lsh = lo & 31u;             // bit 0 of s_surv[0] is global slot lo - lsh
+#pragma unroll
+        for (int r = 0; r < R_MAX; ++r) {
+            if ((own_mask >> r) & 1u) {
+                const int sb = (int)(fse[r] & 0xffffu), eb = (int)(fse[r] >> 16), d = (int)fd[r];
+                const uint32_t kk = fk[r];
+                const bool tl = d > sb && lds_v[d - 1] == kk, tr = d + 1 < eb && lds_v[d + 1] == kk;
+                if (tl || tr) {                    // still tied on the whole 64-bit key
+                    int q = d;
+                    while (q > sb && lds_v[q - 1] == kk) --q;
+                    F.surv_head[(int64_t)lo + d] = lo + (uint32_t)q;
+                    atomicOr(&s_surv[((uint32_t)d + lsh) >> 5], 1u << (((uint32_t)d + lsh) & 31u));
+                }
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < R_MAX; ++r)
+            if ((own_mask >> r) & 1u) lds_v[fd[r]] = fv[r];
+        if (n_unowned) atomicAdd(&s_cnt[0], n_unowned);
+        __syncthreads();
+        if (tid == 0) {
+            if (s_cnt[0]) atomicAdd(&F.counters[1], s_cnt[0]);
+            if (n_tied) atomicAdd(&F.counters[64 + (blockIdx.x % RR_CHG_COUNTERS) * 32], (uint32_t)n_tied);
+        }
+        for (int i = tid; i < SURV_WORDS; i += THREADS) {
+            const uint32_t sw = s_surv[i];
+            if (sw) {
+                const int64_t j0 = (int64_t)(lo - lsh) + 32 * (int64_t)i;
+                atomicOr(&F.surv_bits[j0 >> 5], sw);
+                atomicAdd(&F.tile_cnt[j0 / RR_TILE], (uint32_t)__popc(sw));
+            }
+        }
+    }
     // ---- LDS -> global, in order ----
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {

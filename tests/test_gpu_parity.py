@@ -78,10 +78,10 @@ def test_radix_sort_pairs_32bit_keys(count, bits, engine, monkeypatch):
     assert np.array_equal(v2, vals[order]) and np.array_equal(k2, keys[order])
 
 
-@pytest.mark.parametrize("count,tops,shape", [(1, 1, "0"), (2, 1, "0"), (255, 3, "0"), (5_000, 1, "0"), (5_120, 1, "0"), (5_121, 1, "0"),
-                                              (100_003, 0, "0"), (3_000_001, 0, "1"), (200_000, 64, "0"), (600_000, 64, "0"),
-                                              (1_200_000, 64, "0"), (20_480, 1, "0"), (20_481, 1, "0"), (2_000_000, 64, "2"),
-                                              (400_000, 70_000, "2"), (8_000_000, 0, "0")])
+@pytest.mark.parametrize("count,tops,shape", [(1, 1, "0"), (2, 1, "3"), (255, 3, "4"), (5_000, 1, "0"), (5_120, 1, "0"), (5_121, 1, "0"),
+                                              (100_003, 0, "-1"), (3_000_001, 0, "1"), (200_000, 64, "3"), (200_000, 64, "1"), (200_000, 64, "2"),
+                                              (600_000, 64, "0"), (600_000, 64, "2"), (1_200_000, 64, "0"), (20_480, 1, "0"), (20_481, 1, "0"),
+                                              (2_000_000, 64, "2"), (400_000, 70_000, "2"), (8_000_000, 0, "-1")])
 def test_bucket_sort_32bit_keys(count, tops, shape, monkeypatch):
     """kernels/bucket_sort.hpp: two global passes over the key bits 16..31, then every bucket (= value of the top 16 bits)
     ordered by its low 16 bits in LDS -- the same stable order as four global passes.  tops = distinct values of the top 16
@@ -537,7 +537,7 @@ def test_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed):
 
 @pytest.mark.parametrize("gen,n,seed", [("uniform", 500_000, 2), ("uniform", 3_000_001, 3), ("dna", 1 << 20, 4), ("english", 300_000, 3),
                                         ("dna_repeats", 400_000, 5), ("periodic", 100_001, 1), ("sigma2", 250_000, 7), ("sigma200", 900_000, 9)])
-@pytest.mark.parametrize("shape", ["0", "2"])
+@pytest.mark.parametrize("shape", ["-1", "2", "3"])
 def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed, shape):
     """the 32-bit first stage as two global passes + the in-LDS bucket sort (taken from 32 Mi suffixes on; here from 1), on texts
     whose buckets fit a workgroup and on texts where they do not (a period, two symbols: the keys are rebuilt and the four
@@ -559,6 +559,11 @@ def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n,
     assert st["top32_first"] == 1
     if gen in ("uniform", "dna", "sigma200"):
         assert st["sort_passes"] == 3, st                 # two global passes + the bucket pass
+    monkeypatch.setenv("SA_AMD_GROUP_CAP", "3")           # larger tied groups are left to the general path
+    assert np.array_equal(build(text), exp)
+    monkeypatch.delenv("SA_AMD_GROUP_CAP")
+    monkeypatch.setenv("SA_AMD_NO_BUCKET_FINISH", "1")    # the round on the low key bits as a pass of its own (k_finish_sorted)
+    assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")         # the global passes by the three-kernel engine
     assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_FUSED_FINISH", "1")     # ties on the top 32 bits through the general path
@@ -700,7 +705,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_NO_PREFAULT",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_NO_PREFAULT",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
