@@ -9,9 +9,11 @@
 namespace sa {
 
 constexpr int SORT_MAX_WG = 1024;   // spine rows are scanned by one 1024-thread block
-constexpr int BK_LBITS = 16;        // bucket sort of the 32-bit first stage (kernels/bucket_sort.hpp): low key bits ordered inside a bucket
-constexpr uint32_t BK_BUCKETS = 1u << (32 - BK_LBITS);
-static_assert(BK_LBITS >= 1 && BK_LBITS <= BK_MAX_LBITS, "two 8-bit passes inside a bucket");
+// bucket sort of the 32-bit first stage (kernels/bucket_sort.hpp): the top 16 key bits by two global passes of 8 bits (the low 16
+// inside the buckets), or the top 18 by two passes of 9 bits (the low 14 inside) for texts whose 16-bit buckets outgrow a workgroup
+constexpr int BK_TOP_BITS_MAX = 18;
+constexpr uint32_t BK_BUCKETS_MAX = 1u << BK_TOP_BITS_MAX;
+static_assert(32 - 16 <= BK_MAX_LBITS, "two 8-bit passes inside a bucket");
 constexpr size_t GRAM_MAX_ENTRIES = (size_t)1 << 24;   // gram keys: the rank table has sigma^g <= min(n, 2^24) entries
 static_assert(GROUP_CAP_MAX == GS_CAP, "Tuning clamps SA_AMD_GROUP_CAP to the kernel's cap");
 
@@ -72,7 +74,7 @@ struct Workspace {
     uint32_t *surv_bits, *surv_cnt, *todo_bits, *ft_cnt, *ft_head;   // first refinement round straight from the sorted keys (k_finish_sorted)
     unsigned long long *os_status;  // look-back granules of the single-pass tile scatter: 2 KiB per 8192-element tile
     uint32_t *os_err;
-    uint32_t *bk_start;             // bucket sort of the 32-bit first stage: 65 537 bucket starts
+    uint32_t *bk_start;             // bucket sort of the 32-bit first stage: 2^16 + 1 or 2^18 + 1 bucket starts
     SortScratch ss;
     size_t bytes;
 };
@@ -115,7 +117,7 @@ static Workspace carve(void *base, int64_t n)
     w.ft_head = (uint32_t *)take(ft_tiles * 4);
     w.os_status = (unsigned long long *)take(((size_t)ceil_div((int64_t)N, OS_MIN_TILE) + 1) * RADIX * 8);
     w.os_err = (uint32_t *)take(256);
-    w.bk_start = (uint32_t *)take(((size_t)BK_BUCKETS + 1) * 4);
+    w.bk_start = (uint32_t *)take(((size_t)BK_BUCKETS_MAX + 1) * 4);
     w.ss.spine = w.spine; w.ss.digit_tot = w.digit_tot; w.ss.status = w.os_status; w.ss.err = w.os_err;
     w.bytes = off;
     return w;
@@ -138,7 +140,8 @@ static const OsShape os_shapes32[] = { { 1024, 12, false, 1 }, { 512, 16, true, 
 constexpr int N_OS_SHAPES64 = (int)(sizeof(os_shapes64) / sizeof(os_shapes64[0]));
 constexpr int N_OS_SHAPES32 = (int)(sizeof(os_shapes32) / sizeof(os_shapes32[0]));
 constexpr int OS_TICKETS = 64;                 // words in front of a zone's counts: one ticket counter per segment
-constexpr int OS_ZONE = OS_TICKETS + RADIX * OS_NSEG;  // words
+constexpr int OS_MAX_RADIX = 512;              // widest digit of the single-pass scatter (9 bits: the two passes in front of the bucket sort of large texts)
+constexpr int OS_ZONE = OS_TICKETS + OS_MAX_RADIX * OS_NSEG;  // words
 static_assert(OS_NSEG <= OS_TICKETS, "one ticket word per segment");
 static_assert(2 * OS_ZONE <= RADIX * SORT_MAX_WG, "both zones live in the spine slab");
 
@@ -183,31 +186,34 @@ __global__ __launch_bounds__(RADIX) void k_os_digit_totals(const uint32_t *__res
     digit_tot[threadIdx.x] = s;
 }
 
-template <typename KeyT, int THREADS, int ITEMS, bool SEQ>
+template <typename KeyT, int THREADS, int ITEMS, bool SEQ, int RBITS = RADIX_BITS>
 static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit, int end_bit,
                                const SortScratch &ss, uint32_t *final_vals, hipStream_t st, KeyT **keys_res, uint32_t **vals_res, int *passes,
                                int *skipped, const Tuning &tn, bool iota, bool may_skip, bool first_counted)
 {
     constexpr int TILE = THREADS * ITEMS;
+    constexpr int R = 1 << RBITS;
+    static_assert(R <= OS_MAX_RADIX && (RBITS == RADIX_BITS || TILE >= 2 * OS_MIN_TILE), "zones and granule slab are sized for 8-bit digits of 4 Ki-element tiles");
     static_assert(TILE >= OS_MIN_TILE, "the granule slab is sized for tiles of at least OS_MIN_TILE elements");
     constexpr bool K64 = sizeof(KeyT) == 8;
     const OnesweepGeom g = onesweep_geom(count, TILE);
     uint32_t *zone[2] = { ss.spine, ss.spine + OS_ZONE };
     int z = 0;                                    // zone that holds (or will hold) the counts of the coming pass's digit
     bool have_counts = first_counted;
-    HIP_TRY(hipMemsetAsync(ss.status, 0, (size_t)g.tiles * RADIX * 8, st));
+    HIP_TRY(hipMemsetAsync(ss.status, 0, (size_t)g.tiles * R * 8, st));
     KeyT *kin = keys_in, *kout = keys_alt;
     uint32_t *vin = vals_in, *vout = vals_alt;
     constexpr int WG_PER_CU = THREADS <= 512 ? 2 : 1;
     int grid = cu_count() * WG_PER_CU;
     if (grid > g.tiles) grid = g.tiles;
     uint32_t epoch = 0;
-    for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
-        const int nb = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
+    for (int shift = begin_bit; shift < end_bit; shift += RBITS) {
+        const int nb = (end_bit - shift) < RBITS ? (end_bit - shift) : RBITS;
         const uint32_t dmask = (1u << nb) - 1u;
-        const bool last = shift + RADIX_BITS >= end_bit;
+        const bool last = shift + RBITS >= end_bit;
         uint32_t *vdst = (last && final_vals) ? final_vals : vout;
         if (!have_counts) {
+            if (RBITS != RADIX_BITS) return SA_AMD_EINTERNAL;     // (the counting kernels have 256 bins: a wide-digit sort gets its first counts from the producer of the keys)
             // one read of the keys for the counts of this digit (first pass of a sort whose producer did not count, or the
             // pass after a skipped one)
             HIP_TRY(hipMemsetAsync(zone[z], 0, (size_t)OS_ZONE * 4, st));
@@ -221,7 +227,7 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
                 PROF(KC_UPSWEEP32, count, st, hipLaunchKernelGGL((k_radix_upsweep32), dim3(g.nseg * split), dim3(SORT_THREADS), 0, st, (const uint32_t *)kin,
                                                                  zone[z] + OS_TICKETS, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
         }
-        if (may_skip && !tn.no_run_skip && count >= tn.run_skip_min && !(iota && *passes == 0) && !(last && final_vals)) {
+        if (RBITS == RADIX_BITS && may_skip && !tn.no_run_skip && count >= tn.run_skip_min && !(iota && *passes == 0) && !(last && final_vals)) {
             // a digit that is the same for EVERY element makes the pass the identity (the sort is stable): skip it
             hipLaunchKernelGGL(k_os_digit_totals, dim3(1), dim3(RADIX), 0, st, (const uint32_t *)(zone[z] + OS_TICKETS), g.nseg, ss.digit_tot);
             LAUNCH_CHECK(st);
@@ -239,14 +245,14 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         P.err = ss.err;
         P.n = count;
         P.shift = shift; P.dmask = dmask;
-        P.shift_next = shift + RADIX_BITS;
-        { const int nbn = (end_bit - P.shift_next) < RADIX_BITS ? (end_bit - P.shift_next) : RADIX_BITS; P.dmask_next = last ? 0u : (1u << nbn) - 1u; }
+        P.shift_next = shift + RBITS;
+        { const int nbn = (end_bit - P.shift_next) < RBITS ? (end_bit - P.shift_next) : RBITS; P.dmask_next = last ? 0u : (1u << nbn) - 1u; }
         P.nseg = g.nseg; P.tiles_per_seg = g.tiles_per_seg; P.tiles = g.tiles;
         P.epoch = ++epoch;
         P.flags = (uint32_t)tn.onesweep_flags;
         HIP_TRY(hipMemsetAsync(zone[z ^ 1], 0, (size_t)OS_ZONE * 4, st));
         PROF(K64 ? KC_ONESWEEP : KC_ONESWEEP32, count, st,
-             hipLaunchKernelGGL((k_onesweep<THREADS, ITEMS, KeyT, SEQ, WG_PER_CU>), dim3(grid), dim3(THREADS), 0, st, (const KeyT *)kin,
+             hipLaunchKernelGGL((k_onesweep<THREADS, ITEMS, KeyT, SEQ, WG_PER_CU, RBITS>), dim3(grid), dim3(THREADS), 0, st, (const KeyT *)kin,
                                 (const uint32_t *)((iota && *passes == 0) ? nullptr : vin), kout, vdst, P));
         KeyT *tk = kin; kin = kout; kout = tk;
         uint32_t *free_v = vin;                   // the values just consumed become the next scratch target
@@ -370,12 +376,17 @@ static SortGrid32 sort_grid32(int64_t count, const Sort32Variant &sv)
 
 static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit,
                         int end_bit, const SortScratch &ss, uint32_t *final_vals, hipStream_t st, SortResult32 *res,
-                        const Tuning &tn, bool iota = false, bool first_counted = false)
+                        const Tuning &tn, bool iota = false, bool first_counted = false,
+                        int rbits = RADIX_BITS)       // 9: nine-bit digits (single-pass engine only, first digit counted by the producer)
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
+    if (rbits != RADIX_BITS && (rbits != 9 || !onesweep_on(ss, tn) || !first_counted)) return SA_AMD_EINTERNAL;
     if (onesweep_on(ss, tn)) {
         int skipped = 0;
+        if (rbits == 9)
+            return sort_pairs_onesweep<uint32_t, 1024, 12, false, 9>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
+                                                                     &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted);
 #define OS_CALL32(T, I, S) sort_pairs_onesweep<uint32_t, T, I, S>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st, \
                                                                  &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted)
         switch (tn.onesweep32_shape) {
@@ -463,20 +474,25 @@ constexpr int N_BK_DEFAULT = 3;
 static int64_t bucket_cap(int shape) { return (int64_t)bk_shapes[shape].threads * bk_shapes[shape].items; }
 static int64_t bucket_cap_max() { return bucket_cap(N_BK_DEFAULT - 1); }
 
-// *done = false: some bucket is larger than every shape holds (nothing was written; the caller sorts the low bits globally).
-// words: two scratch words (largest bucket, error count); start: BK_BUCKETS + 1 words.  Read-back: the largest bucket.
+// top_bits: 16 or 18 key bits that the global passes have ordered.  *done = false: some bucket is larger than every shape holds
+// (nothing was written; the caller sorts the low bits globally).  words: two scratch words (largest bucket, error count);
+// start: 2^top_bits + 1 words.  Read-back: the largest bucket.
 // fin != nullptr: the tied suffixes are ordered by their low key bits in the same launch (what k_finish_sorted does in a pass of
-// its own); the caller has zeroed fin's bitmap and counters.
-static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, int64_t count,
+// its own) when the shape has room to do it well (*fused); the caller has zeroed fin's bitmap and counters.
+static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, int64_t count, int top_bits,
                          uint32_t *start, uint32_t *words, hipStream_t st, const Tuning &tn, bool *done, uint32_t *largest,
-                         const BucketFinish *fin = nullptr, const KeyParams *P = nullptr, const KeySrc *K = nullptr)
+                         const BucketFinish *fin = nullptr, const KeyParams *P = nullptr, const KeySrc *K = nullptr, bool *fused = nullptr)
 {
     *done = false; *largest = 0;
+    if (fused) *fused = false;
+    if (top_bits < 32 - BK_MAX_LBITS || top_bits > BK_TOP_BITS_MAX) return SA_AMD_EINTERNAL;
+    const int lbits = 32 - top_bits;
+    const uint32_t nb = 1u << top_bits;
     HIP_TRY(hipMemsetAsync(words, 0, 8, st));
-    PROF(KC_MISC, BK_BUCKETS, st, hipLaunchKernelGGL((k_bucket_starts), dim3((unsigned)ceil_div((int64_t)BK_BUCKETS + 1, BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS),
-                                                       0, st, keys_in, count, BK_LBITS, BK_BUCKETS, start));
-    PROF(KC_MISC, BK_BUCKETS, st, hipLaunchKernelGGL((k_bucket_max), dim3((unsigned)ceil_div((int64_t)BK_BUCKETS, BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS), 0, st,
-                                                       (const uint32_t *)start, BK_BUCKETS, words));
+    PROF(KC_MISC, nb, st, hipLaunchKernelGGL((k_bucket_starts), dim3((unsigned)ceil_div((int64_t)nb + 1, BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS),
+                                              0, st, keys_in, count, lbits, nb, start));
+    PROF(KC_MISC, nb, st, hipLaunchKernelGGL((k_bucket_max), dim3((unsigned)ceil_div((int64_t)nb, BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS), 0, st,
+                                              (const uint32_t *)start, nb, words));
     uint32_t maxb = 0;
     { const int rcw = read_words(&maxb, words, 4, st); if (rcw) return rcw; }
     *largest = maxb;
@@ -485,15 +501,18 @@ static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint3
     for (int c = 0; shape < 0 && c < N_BK_DEFAULT; ++c)
         if (bucket_cap(c) >= (int64_t)maxb) shape = c;
     if (shape < 0) return SA_AMD_OK;
+    // the 20-pairs-per-thread shapes leave one workgroup per CU (or three waves per SIMD): the tied suffixes' text look-ups have
+    // nothing to hide behind there (1 GiB DNA: 7.7 + 7.5 ms as two kernels, 16.9 ms fused) -- k_finish_sorted follows instead
+    const bool fuse = fin != nullptr && (bk_shapes[shape].items <= 10 || tn.bucket_finish_always);
     const BucketFinish F0 = BucketFinish();
     const KeyParams P0 = KeyParams();
     const KeySrc K0 = KeySrc();
 #define BK_LAUNCH(T, I, W)                                                                                                               \
     do {                                                                                                                                 \
-        if (fin) PROF(KC_BUCKET, count, st, hipLaunchKernelGGL((k_bucket_sort<T, I, W, true>), dim3(BK_BUCKETS), dim3(T), 0, st, keys_in, vals_in, \
-                                                               (const uint32_t *)start, BK_LBITS, keys_out, vals_out, words + 1, *fin, *P, *K));     \
-        else PROF(KC_BUCKET, count, st, hipLaunchKernelGGL((k_bucket_sort<T, I, W, false>), dim3(BK_BUCKETS), dim3(T), 0, st, keys_in, vals_in,    \
-                                                            (const uint32_t *)start, BK_LBITS, keys_out, vals_out, words + 1, F0, P0, K0));          \
+        if (fuse) PROF(KC_BUCKET, count, st, hipLaunchKernelGGL((k_bucket_sort<T, I, W, true>), dim3(nb), dim3(T), 0, st, keys_in, vals_in,         \
+                                                                (const uint32_t *)start, lbits, keys_out, vals_out, words + 1, *fin, *P, *K));      \
+        else PROF(KC_BUCKET, count, st, hipLaunchKernelGGL((k_bucket_sort<T, I, W, false>), dim3(nb), dim3(T), 0, st, keys_in, vals_in,             \
+                                                            (const uint32_t *)start, lbits, keys_out, vals_out, words + 1, F0, P0, K0));            \
     } while (0)
     switch (shape) {
     case 0: BK_LAUNCH(512, 10, 8); break;
@@ -503,6 +522,7 @@ static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint3
     }
 #undef BK_LAUNCH
     *done = true;
+    if (fused) *fused = fuse;
     return SA_AMD_OK;
 }
 
@@ -1060,25 +1080,35 @@ struct DeviceBuild {
         }
         if (top_shift) {
             uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
-            // Two global passes over the key bits 16..31 + one pass that orders every bucket (= value of the top 16 bits) in LDS, when
-            // an average bucket fits a workgroup (n = 2^28: 4096 pairs; 2^30: 16384); a text whose LARGEST bucket does not -- known
-            // only once the two passes have run -- builds its keys again and takes the four global passes.
-            bool bucket_route = !tn.no_bucket_sort && n >= tn.bucket_min_n && n > 1 && (int64_t)(n / BK_BUCKETS) * 10 <= bucket_cap_max() * 9;
+            // Two global passes over the top 16 key bits + one pass that orders every bucket (= value of those bits) in LDS, when an
+            // average bucket fits a workgroup well (n = 2^28: 4096 pairs, 2^29: 8192); larger texts take two passes of NINE bits
+            // (2^30: 2^18 buckets of 4096).  A text whose LARGEST bucket fits no workgroup -- known only once the two passes have
+            // run -- builds its keys again and takes the four global passes.
+            int top_bits = 0;                    // 0: four global passes
+            if (!tn.no_bucket_sort && n >= tn.bucket_min_n && n > 1) {
+                const bool wide_ok = onesweep_on(w.ss, tn) && tn.onesweep32_shape == 0;      // (nine-bit digits: single-pass engine, default tile)
+                if (tn.bucket_bits == 18 && wide_ok) top_bits = 18;
+                else if (tn.bucket_bits == 16) top_bits = 16;
+                else if ((n >> 16) * 10 <= bucket_cap(1) * 9) top_bits = 16;
+                else if (wide_ok && (n >> 18) * 10 <= bucket_cap_max() * 9) top_bits = 18;
+                else if ((n >> 16) * 10 <= bucket_cap_max() * 9) top_bits = 16;
+            }
             for (;;) {
             // the first radix pass's digit histogram comes out of k_build_keys (keys in registers there): one read of every key less
             const FirstCounts fc = sort_first_counts(w.ss, tn, n, true);
             const bool counted = n > 1;
+            const int rbits = top_bits == 18 ? 9 : RADIX_BITS;
             if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
             PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
                                                           (uint64_t *)nullptr, vals0, k32a, top_shift, packed_out,
-                                                          counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, 0xffu, bucket_route ? BK_LBITS : 0));
+                                                          counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, (1u << rbits) - 1u, top_bits ? 32 - top_bits : 0));
             SortResult32 s32;
-            if (bucket_route) {
-                rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, BK_LBITS, 32, w.ss, nullptr, st, &s32, tn, iota, counted);
+            if (top_bits) {
+                rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 32 - top_bits, 32, w.ss, nullptr, st, &s32, tn, iota, counted, rbits);
                 if (rc) return rc;
                 local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
                 uint32_t *kout = (s32.keys == k32a) ? k32b : k32a;
-                bool done = false;
+                bool done = false, fused = false;
                 uint32_t largest = 0;
                 // the round on the low key bits of the suffixes tied on all 32 (first_round_from_sorted_keys) in the same launch
                 const bool fuse = local_ok && !tn.no_fused_finish && !tn.no_bucket_finish && !timing_only();
@@ -1094,13 +1124,14 @@ struct DeviceBuild {
                     F.T = dT; F.n = n; F.cap = tn.group_cap; F.surv_bits = w.surv_bits; F.surv_head = w.isa; F.tile_cnt = w.tcnt; F.counters = w.total;
                     K.mode = KS_LOWKEY; K.kb = top_shift;
                 }
-                rc = bucket_sort32(s32.keys, s32.vals, kout, SA, n, w.bk_start, w.os_err + 2, st, tn, &done, &largest,
-                                   fuse ? &F : nullptr, &P, &K);
+                rc = bucket_sort32(s32.keys, s32.vals, kout, SA, n, top_bits, w.bk_start, w.os_err + 2, st, tn, &done, &largest,
+                                   fuse ? &F : nullptr, &P, &K, &fused);
                 if (rc) return rc;
-                bucket_finished = done && fuse;
-                if (trace) fprintf(stderr, "suffix_array_amd: 32-bit first stage: %d global passes, largest bucket %u -> %s\n", s32.passes, largest,
-                                   done ? "low 16 bits ordered bucket by bucket in LDS" : "too large: keys rebuilt, four global passes");
-                if (!done) { bucket_route = false; continue; }      // (nothing was launched: the finish buffers are zeroed again by whoever uses them)
+                bucket_finished = done && fused;
+                if (trace) fprintf(stderr, "suffix_array_amd: 32-bit first stage: %d global passes over the top %d key bits, largest bucket %u -> %s\n", s32.passes, top_bits, largest,
+                                   done ? (fused ? "low bits and ties on all 32 ordered bucket by bucket in LDS" : "low bits ordered bucket by bucket in LDS")
+                                        : "too large: keys rebuilt, four global passes");
+                if (!done) { top_bits = 0; continue; }      // (nothing was launched: the finish buffers are zeroed again by whoever uses them)
                 local.sort_passes += 1; local.sorted_elements += n;
                 sorted32 = kout;
                 sr.vals = SA; sr.passes = s32.passes + 1;

@@ -75,6 +75,8 @@ struct Tuning {
     bool no_bucket_sort = false;     // SA_AMD_NO_BUCKET_SORT: the 32-bit first stage always takes four global passes (never two + the in-LDS bucket sort)
     int64_t bucket_min_n = (int64_t)1 << 25;   // SA_AMD_BUCKET_MIN_N: smallest text whose 32-bit first stage sorts the low 16 key bits bucket by bucket in LDS
     bool no_bucket_finish = false;   // SA_AMD_NO_BUCKET_FINISH: the suffixes tied on the top 32 key bits are ordered by k_finish_sorted in a pass of its own, not inside k_bucket_sort
+    bool bucket_finish_always = false;   // SA_AMD_BUCKET_FINISH_ALWAYS: ... inside k_bucket_sort even with the 20-pairs-per-thread shapes (measured slower)
+    int bucket_bits = 0;             // SA_AMD_BUCKET_BITS: key bits ordered by the two global passes in front of the bucket sort (0 = by text size, 16, 18)
     int bucket_shape = -1;           // SA_AMD_BUCKET_SHAPE: workgroup shape of that sort tried first (host/pipeline.hpp, bk_shapes; -1 = the smallest default one that holds the largest bucket)
 #ifdef SA_AMD_DIAG
     bool timing_only_initial_sort = false;     // SA_AMD_TIMING_ONLY_INITIAL_SORT (diag library only: the array is NOT finished)
@@ -129,6 +131,9 @@ struct Tuning {
         t.no_bucket_sort = env_flag("SA_AMD_NO_BUCKET_SORT");
         t.bucket_min_n = env_int("SA_AMD_BUCKET_MIN_N", (int64_t)1 << 25, 1, (int64_t)1 << 40);
         t.no_bucket_finish = env_flag("SA_AMD_NO_BUCKET_FINISH");
+        t.bucket_finish_always = env_flag("SA_AMD_BUCKET_FINISH_ALWAYS");
+        t.bucket_bits = (int)env_int("SA_AMD_BUCKET_BITS", 0, 0, 18);
+        if (t.bucket_bits != 16 && t.bucket_bits != 18) t.bucket_bits = 0;
         t.bucket_shape = (int)env_int("SA_AMD_BUCKET_SHAPE", -1, -1, 64);
 #ifdef SA_AMD_DIAG
         t.timing_only_initial_sort = env_flag("SA_AMD_TIMING_ONLY_INITIAL_SORT");

@@ -111,11 +111,11 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
 {
     __shared__ uint8_t lcode[256];
     __shared__ __attribute__((aligned(16))) uint8_t c[KB_TILE + KB_HALO];
-    __shared__ uint32_t dhist[256];
+    __shared__ uint32_t dhist[512];            // (dmask <= 511: eight- or nine-bit first digit)
     __shared__ uint32_t gc[GRAM ? KB_TILE + KB_HALO : 1];
     const int tid = threadIdx.x;
     lcode[tid] = P.code[tid];
-    dhist[tid] = 0;
+    for (int d = tid; d < 512; d += KB_THREADS) dhist[d] = 0;
 
     __syncthreads();
     const int64_t tiles = (n + KB_TILE - 1) / KB_TILE;
@@ -218,9 +218,11 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
         const int64_t chunk = base / chunk_elems;
         const bool flush = tile + 1 == tile1 || (base + KB_TILE) / chunk_elems != chunk;     // (uniform)
         if (flush) {
-            const uint32_t cnt = dhist[tid];
-            if (cnt) atomicAdd(&counts[(int64_t)tid * G + chunk], cnt);
-            dhist[tid] = 0;
+            for (int d = tid; d <= (int)dmask; d += KB_THREADS) {
+                const uint32_t cnt = dhist[d];
+                if (cnt) atomicAdd(&counts[(int64_t)d * G + chunk], cnt);
+                dhist[d] = 0;
+            }
             __syncthreads();
         }
     }

@@ -61,11 +61,15 @@ struct OnesweepPass {
 // THREADS x ITEMS elements per tile.  SEQ = false: keys and values are staged in LDS side by side (one workgroup per CU at the
 // sizes in use); SEQ = true: the values go through the keys' buffer once the keys are out, which leaves room for TWO
 // workgroups per CU -- while one waits (look-back, barriers, the ranking's ALU work) the other one's loads and stores flow.
-template <int THREADS, int ITEMS, typename KeyT, bool SEQ, int WG_PER_CU>
+// RBITS: digit width (8, or 9 for the two global passes in front of the bucket sort of a text of more than 2^29 suffixes)
+template <int THREADS, int ITEMS, typename KeyT, bool SEQ, int WG_PER_CU, int RBITS = RADIX_BITS>
 __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep(
     const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
     OnesweepPass P)
 {
+    constexpr int RADIX = 1 << RBITS;              // (shadows sa::RADIX inside this kernel)
+    constexpr int RADIX_BITS = RBITS;
+    static_assert(RBITS == 8 || !SEQ, "the digits of the sequential shapes travel as bytes");
     constexpr int TILE = THREADS * ITEMS;
     constexpr int NWAVES = THREADS / WAVE;
     constexpr int WAVE_ELEMS = WAVE * ITEMS;

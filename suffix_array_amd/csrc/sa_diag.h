@@ -21,9 +21,9 @@ const char *sa_amd_debug_sort_variant_name(int32_t index);
 int32_t sa_amd_test_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit, int32_t end_bit);
 /* the 32-bit-key form of the same sort (first stage of the two-stage initial sort) */
 int32_t sa_amd_test_sort_pairs32(uint32_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit, int32_t end_bit);
-/* the same order through two global passes over the key bits 16..31 + the in-LDS bucket sort of the low 16 bits
- * (kernels/bucket_sort.hpp); *largest = the largest bucket; returns 1 (buffers untouched) when no workgroup shape holds it */
-int32_t sa_amd_test_bucket_sort32(uint32_t *keys, uint32_t *vals, int64_t count, uint32_t *largest);
+/* the same order through two global passes over the top 16 (or 18: nine-bit digits) key bits + the in-LDS bucket sort of the
+ * rest (kernels/bucket_sort.hpp); *largest = the largest bucket; returns 1 (buffers untouched) when no workgroup shape holds it */
+int32_t sa_amd_test_bucket_sort32(uint32_t *keys, uint32_t *vals, int64_t count, int32_t top_bits, uint32_t *largest);
 /* initial packed keys of a text (host buffers; keys has n entries); returns bits in *bits, symbols in *k */
 int32_t sa_amd_test_build_keys(const uint8_t *T, int32_t n, uint64_t *keys, int32_t *bits, int32_t *k);
 /* micro-prototype for DESIGN.md section 2 / VERDICT r1 row (g): one exact level-0 L-type induce sweep of SA-IS executed by a

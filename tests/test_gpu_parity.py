@@ -82,10 +82,12 @@ def test_radix_sort_pairs_32bit_keys(count, bits, engine, monkeypatch):
                                               (100_003, 0, "-1"), (3_000_001, 0, "1"), (200_000, 64, "3"), (200_000, 64, "1"), (200_000, 64, "2"),
                                               (600_000, 64, "0"), (600_000, 64, "2"), (1_200_000, 64, "0"), (20_480, 1, "0"), (20_481, 1, "0"),
                                               (2_000_000, 64, "2"), (400_000, 70_000, "2"), (8_000_000, 0, "-1")])
-def test_bucket_sort_32bit_keys(count, tops, shape, monkeypatch):
-    """kernels/bucket_sort.hpp: two global passes over the key bits 16..31, then every bucket (= value of the top 16 bits)
-    ordered by its low 16 bits in LDS -- the same stable order as four global passes.  tops = distinct values of the top 16
-    bits (0: all 65 536), i.e. buckets of count / tops pairs; a bucket of more than 20 480 pairs is reported, not sorted."""
+@pytest.mark.parametrize("top_bits", [16, 18])
+def test_bucket_sort_32bit_keys(count, tops, shape, top_bits, monkeypatch):
+    """kernels/bucket_sort.hpp: two global passes over the top 16 key bits (18: nine-bit digits), then every bucket (= value of
+    those bits) ordered by its low bits in LDS -- the same stable order as four global passes.  tops = distinct values of the
+    top 16 bits (0: all 65 536), i.e. 16-bit buckets of count / tops pairs; a bucket of more than 20 480 pairs is reported,
+    not sorted."""
     monkeypatch.setenv("SA_AMD_BUCKET_SHAPE", shape)
     rng = np.random.default_rng(count + tops)
     keys = rng.integers(0, 2**32, count, dtype=np.uint32)
@@ -100,8 +102,8 @@ def test_bucket_sort_32bit_keys(count, tops, shape, monkeypatch):
     order = np.argsort(keys, kind="stable")
     k2, v2 = keys.copy(), vals.copy()
     largest = ctypes.c_uint32(0)
-    rc = sa.diag_lib().sa_amd_test_bucket_sort32(k2.ctypes.data, v2.ctypes.data, count, ctypes.byref(largest))
-    true_largest = int(np.bincount(keys >> np.uint32(16), minlength=65536).max())
+    rc = sa.diag_lib().sa_amd_test_bucket_sort32(k2.ctypes.data, v2.ctypes.data, count, top_bits, ctypes.byref(largest))
+    true_largest = int(np.bincount(keys >> np.uint32(32 - top_bits), minlength=1 << top_bits).max())
     assert largest.value == true_largest
     if true_largest > 20_480:
         assert rc == 1 and np.array_equal(k2, keys) and np.array_equal(v2, vals)
@@ -537,8 +539,8 @@ def test_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed):
 
 @pytest.mark.parametrize("gen,n,seed", [("uniform", 500_000, 2), ("uniform", 3_000_001, 3), ("dna", 1 << 20, 4), ("english", 300_000, 3),
                                         ("dna_repeats", 400_000, 5), ("periodic", 100_001, 1), ("sigma2", 250_000, 7), ("sigma200", 900_000, 9)])
-@pytest.mark.parametrize("shape", ["-1", "2", "3"])
-def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed, shape):
+@pytest.mark.parametrize("shape,bits", [("-1", "0"), ("2", "16"), ("3", "0"), ("-1", "18"), ("2", "18")])
+def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed, shape, bits):
     """the 32-bit first stage as two global passes + the in-LDS bucket sort (taken from 32 Mi suffixes on; here from 1), on texts
     whose buckets fit a workgroup and on texts where they do not (a period, two symbols: the keys are rebuilt and the four
     global passes run) -- the same array either way"""
@@ -554,6 +556,7 @@ def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n,
     monkeypatch.setenv("SA_AMD_FORCE_TOP32", "1")
     monkeypatch.setenv("SA_AMD_BUCKET_MIN_N", "1")
     monkeypatch.setenv("SA_AMD_BUCKET_SHAPE", shape)
+    monkeypatch.setenv("SA_AMD_BUCKET_BITS", bits)        # 18: two global passes of nine bits, the low 14 inside the buckets
     assert np.array_equal(build(text), exp)
     st = sa.last_stats()
     assert st["top32_first"] == 1
@@ -562,6 +565,8 @@ def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n,
     monkeypatch.setenv("SA_AMD_GROUP_CAP", "3")           # larger tied groups are left to the general path
     assert np.array_equal(build(text), exp)
     monkeypatch.delenv("SA_AMD_GROUP_CAP")
+    monkeypatch.setenv("SA_AMD_BUCKET_FINISH_ALWAYS", "1")   # the fused round with the 20-pairs-per-thread shapes too
+    assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_BUCKET_FINISH", "1")    # the round on the low key bits as a pass of its own (k_finish_sorted)
     assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")         # the global passes by the three-kernel engine
@@ -705,7 +710,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_NO_PREFAULT",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_NO_PREFAULT",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
