@@ -7,9 +7,12 @@
 // (a BUCKET, contiguous, its members in text order), and what the two passes over the bits 0..15 would have done --
 // 2 x 16 bytes per pair through a 256-way scatter -- is a sort INSIDE every bucket.  With n = 2^28 suffixes of random
 // bytes a bucket holds 4096 +- 64 pairs: it fits in LDS, so one workgroup per bucket reads its pairs once (coalesced),
-// orders them by two 8-bit counting passes in LDS (the ranking of the tile scatter: 8 ballots + mbcnt per key, per-wave
-// digit counts in LDS) and writes them back in order (coalesced, sequential): 16 bytes per pair at streaming speed
-// instead of 32 at scatter speed.
+// orders them by two counting passes in LDS and writes them back in order (coalesced, sequential): 16 bytes per pair at
+// streaming speed instead of 32 at scatter speed.  The first pass (the low 10 of the 16 bits) takes its places from one LDS
+// counter per digit (one atomic per pair; the order among equal digits is whatever the atomics give, which is enough: the
+// second pass is stable and pairs equal in ALL low bits are equal keys); the second (the top 6 bits) is the stable ranking of
+// the tile scatter (6 ballots + mbcnt per key, per-wave digit counts in LDS).  The kernel is instruction-bound, not
+// memory-bound -- with two 8-bit ballot passes it took 1.40 ms for 2^28 pairs.
 //   k_bucket_starts  start[b] = first pair whose key >> lbits is >= b, by binary search in the grouped keys
 //                    (65 537 searches; the first levels are shared and cache-resident), and the largest bucket
 //   k_bucket_sort    one workgroup per bucket; THREADS x ITEMS = the largest bucket the shape can hold; the host reads
@@ -31,7 +34,8 @@
 
 namespace sa {
 
-constexpr int BK_MAX_LBITS = 16;             // at most two 8-bit passes inside a bucket
+constexpr int BK_MAX_LBITS = 16;             // low key bits ordered inside a bucket, at most: a first pass on up to 10 of them, ...
+constexpr int BK_BBITS = 6;                  // ... and a stable one on the top 6 (NB_B = 64 = one wave: lane d owns digit d)
 constexpr int BK_STARTS_THREADS = 256;
 
 // start[0 .. nb]: first index whose key >> lbits is >= b (start[nb] = n: nb is past the last bucket in use)
@@ -77,25 +81,30 @@ __global__ __launch_bounds__(THREADS, MINW) void k_bucket_sort(const uint32_t *_
 {
     constexpr int CAP = THREADS * ITEMS;
     constexpr int NWAVES = THREADS / WAVE;
-    static_assert(THREADS >= RADIX, "thread d owns digit d");
+    constexpr int NB_A = 1 << (BK_MAX_LBITS - BK_BBITS);        // bins of the first pass at most
+    constexpr int NB_B = 1 << BK_BBITS;
     static_assert(CAP < 65536, "16-bit bucket-local positions");
     static_assert(ITEMS % 2 == 0, "positions are packed two to a register");
+    static_assert(NB_A % THREADS == 0 || THREADS % NB_A == 0, "the bins of the first pass are scanned by the whole workgroup");
+    static_assert(NB_B == WAVE, "lane d of wave 0 owns digit d of the second pass");
+    // work list of the tied slots (FINISH): in the first pass's counters (free once the bucket is ordered) when a thread stages at
+    // most 10 pairs -- room for 40 % of the bucket's slots --, else (20 pairs per thread) in an array of its own for half of them
+    constexpr int R_MAX = ITEMS <= 10 ? 4 : 10;
+    constexpr int LCAP = ITEMS <= 10 ? 4 * THREADS : CAP / 2;
+    static_assert(LCAP <= R_MAX * THREADS, "every list entry has a thread and a round");
+    constexpr int CNT_WORDS = (FINISH && ITEMS <= 10 && LCAP / 2 > NB_A) ? LCAP / 2 : NB_A;
     __shared__ uint16_t lds_k[CAP];
     __shared__ uint32_t lds_v[CAP];
-    __shared__ uint16_t wave_hist[NWAVES][RADIX];
-    __shared__ uint32_t digit_base[RADIX];
+    __shared__ uint32_t cnt_a[CNT_WORDS];          // first pass: elements per digit, then where the digit's run starts
+    __shared__ uint16_t wave_hist[NWAVES][NB_B];   // second pass: per-wave digit counts, then offsets
+    __shared__ uint32_t digit_base[NB_B];
     __shared__ uint32_t scan_lds[NWAVES + 1];
     constexpr int SURV_WORDS = FINISH ? CAP / 32 + 2 : 1;
     __shared__ uint8_t lcode[FINISH ? 256 : 1];
     __shared__ uint32_t s_surv[SURV_WORDS];        // survivor bits of this bucket's slots, word-aligned to the global bitmap
     __shared__ uint32_t s_cnt[2];
-    // work list of the tied slots: in the per-wave digit counts (free once the bucket is ordered) when a thread stages at most
-    // 10 pairs -- room for 40 % of the bucket's slots --, else (20 pairs per thread) in an array of its own for half of them
-    constexpr int R_MAX = ITEMS <= 10 ? 4 : 10;
-    constexpr int LCAP = ITEMS <= 10 ? NWAVES * RADIX : CAP / 2;
-    static_assert(LCAP <= R_MAX * THREADS, "every list entry has a thread and a round");
     __shared__ uint16_t s_list_own[FINISH && ITEMS > 10 ? LCAP : 1];
-    uint16_t *s_list = ITEMS <= 10 ? &wave_hist[0][0] : s_list_own;
+    uint16_t *s_list = ITEMS <= 10 ? (uint16_t *)cnt_a : s_list_own;
 
     const int tid = threadIdx.x, l = lane_id(), w = wave_id();
     if (FINISH) {
@@ -125,37 +134,70 @@ __global__ __launch_bounds__(THREADS, MINW) void k_bucket_sort(const uint32_t *_
     }
     const uint32_t hi_bits = (keys_in[lo] >> lbits) << lbits;      // the bucket's number, as key bits (1 <= lbits <= 16, host-checked)
     const uint32_t lo_mask = (1u << lbits) - 1u;
+    const int bbits = lbits < BK_BBITS ? lbits : BK_BBITS;        // second pass: the top bits of the low key, stable
+    const int abits = lbits - bbits;                               // first pass: the bits below them
 
+    if (abits > 0) {
+        // ---- first pass: a counter per digit hands out the places.  Which of two pairs with the same digit comes first is left
+        // to the order the atomics arrive in: the second pass keeps whatever order this one leaves (it is stable), and pairs
+        // that agree in all low bits have the same 32-bit key -- their order is the later rounds' business, not the sort's ----
+        const uint32_t amask = (1u << abits) - 1u;
+        for (int i = tid; i < NB_A; i += THREADS) cnt_a[i] = 0;
+        __syncthreads();                           // (also: the keys have arrived)
 #pragma unroll
-    for (int pass = 0; pass < BK_MAX_LBITS / RADIX_BITS; ++pass) {
-        const int shift = pass * RADIX_BITS;
-        if (shift >= lbits) break;                 // (uniform)
-        const int nbits = lbits - shift < RADIX_BITS ? lbits - shift : RADIX_BITS;
-        const uint32_t dmask = (1u << nbits) - 1u;
-        if (pass > 0) {
-            // the order of the pass before: back into registers, wave-striped
-            lds_barrier();
+        for (int j = 0; j < ITEMS; ++j) {
+            uint32_t r = 0;
+            if (j < J && (e0 + j * WAVE) < size) r = atomicAdd(&cnt_a[key[j] & amask], 1u);
+            if ((j & 1) == 0) pp[j >> 1] = r; else pp[j >> 1] |= r << 16;
+        }
+        lds_barrier();
+        {
+            // exclusive sums over the NB_A counters, in place
+            constexpr int BPT = NB_A >= THREADS ? NB_A / THREADS : 1;
+            const bool scans = tid * BPT < NB_A;
+            uint32_t c[BPT], sum = 0;
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const int e = e0 + j * WAVE;
-                uint32_t kx = 0, vx = 0;
-                if (j < J && e < size) { kx = lds_k[e]; vx = lds_v[e]; }
-                key[j] = kx; val[j] = vx;
+            for (int i = 0; i < BPT; ++i) { c[i] = scans ? cnt_a[tid * BPT + i] : 0u; sum += c[i]; }
+            uint32_t all;
+            uint32_t run = block_excl_sum_b<THREADS, true>(sum, scan_lds, &all);
+#pragma unroll
+            for (int i = 0; i < BPT; ++i) { if (scans) cnt_a[tid * BPT + i] = run; run += c[i]; }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (j < J && (e0 + j * WAVE) < size) {
+                const uint32_t ps = BK_POS(j) + cnt_a[key[j] & amask];
+                lds_k[ps] = (uint16_t)(key[j] & lo_mask);
+                lds_v[ps] = val[j];
             }
         }
-        for (int i = tid; i < NWAVES * RADIX / 2; i += THREADS) ((uint32_t *)&wave_hist[0][0])[i] = 0;
+        lds_barrier();
+        // the order of the first pass: back into registers, wave-striped
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int e = e0 + j * WAVE;
+            uint32_t kx = 0, vx = 0;
+            if (j < J && e < size) { kx = lds_k[e]; vx = lds_v[e]; }
+            key[j] = kx; val[j] = vx;
+        }
+    }
+    {
+        // ---- second pass, stable: rank inside the wave (lanes with my digit below me + earlier items: ballots + mbcnt), per-wave
+        // digit counts in LDS ----
+        const uint32_t dmask = (1u << bbits) - 1u;
+        for (int i = tid; i < NWAVES * NB_B / 2; i += THREADS) ((uint32_t *)&wave_hist[0][0])[i] = 0;
         __syncthreads();
-        // ---- rank inside the wave: lanes with my digit below me + earlier items (8 ballots + mbcnt) ----
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             uint32_t r = 0;
             if (j < J) {                           // (uniform)
                 const bool ok = (e0 + j * WAVE) < size;
-                const uint32_t d = (key[j] >> shift) & dmask;
+                const uint32_t d = (key[j] >> abits) & dmask;
                 const uint64_t okm = __ballot(ok);
                 uint32_t xlo = ~(uint32_t)okm, xhi = ~(uint32_t)(okm >> 32);
 #pragma unroll
-                for (int bb = 0; bb < RADIX_BITS; ++bb) {
+                for (int bb = 0; bb < BK_BBITS; ++bb) {
                     const uint32_t sel = (uint32_t)((int32_t)(d << (31 - bb)) >> 31);
                     const uint64_t bal = __ballot(sel != 0);
                     xlo |= (uint32_t)bal ^ sel;
@@ -171,25 +213,23 @@ __global__ __launch_bounds__(THREADS, MINW) void k_bucket_sort(const uint32_t *_
             if ((j & 1) == 0) pp[j >> 1] = r; else pp[j >> 1] |= r << 16;
         }
         lds_barrier();
-        // ---- thread d: per-wave offsets of digit d, its start in the bucket ----
-        uint32_t tot = 0;
-        if (tid < RADIX) {
+        // ---- wave 0, lane d: per-wave offsets of digit d, its start in the bucket ----
+        if (w == 0) {
+            uint32_t tot = 0;
 #pragma unroll
             for (int ww = 0; ww < NWAVES; ++ww) {
-                const uint32_t cnt = wave_hist[ww][tid];
-                wave_hist[ww][tid] = (uint16_t)tot;
+                const uint32_t cnt = wave_hist[ww][l];
+                wave_hist[ww][l] = (uint16_t)tot;
                 tot += cnt;
             }
+            digit_base[l] = wave_incl_sum(tot) - tot;
         }
-        uint32_t all;
-        const uint32_t dbase = block_excl_sum_b<THREADS, true>(tot, scan_lds, &all);
-        if (tid < RADIX) digit_base[tid] = dbase;
         lds_barrier();
         // ---- into LDS in the order of this digit (stable) ----
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             if (j < J && (e0 + j * WAVE) < size) {
-                const uint32_t d = (key[j] >> shift) & dmask;
+                const uint32_t d = (key[j] >> abits) & dmask;
                 const uint32_t ps = BK_POS(j) + digit_base[d] + my_hist[d];
                 lds_k[ps] = (uint16_t)(key[j] & lo_mask);
                 lds_v[ps] = val[j];

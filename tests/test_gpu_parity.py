@@ -101,6 +101,8 @@ def test_bucket_sort_32bit_keys(count, tops, shape, top_bits, monkeypatch):
     rng.shuffle(vals)
     order = np.argsort(keys, kind="stable")
     k2, v2 = keys.copy(), vals.copy()
+    pair_of = np.empty(count, dtype=np.uint32)
+    pair_of[vals] = keys                               # every value still travels with its own key
     largest = ctypes.c_uint32(0)
     rc = sa.diag_lib().sa_amd_test_bucket_sort32(k2.ctypes.data, v2.ctypes.data, count, top_bits, ctypes.byref(largest))
     true_largest = int(np.bincount(keys >> np.uint32(32 - top_bits), minlength=1 << top_bits).max())
@@ -109,7 +111,10 @@ def test_bucket_sort_32bit_keys(count, tops, shape, top_bits, monkeypatch):
         assert rc == 1 and np.array_equal(k2, keys) and np.array_equal(v2, vals)
     else:
         assert rc == 0
-        assert np.array_equal(k2, keys[order]) and np.array_equal(v2, vals[order])
+        # equal keys may come in any order (only the second in-LDS pass is stable): the keys are sorted, the pairs are the same
+        assert np.array_equal(k2, keys[order])
+        assert np.array_equal(v2[np.lexsort((v2, k2))], vals[np.lexsort((vals, keys))])
+        assert np.array_equal(pair_of[v2], k2)
 
 
 @pytest.mark.parametrize("engine", ["single-pass", "three-kernel"])
