@@ -945,6 +945,7 @@ struct DeviceBuild {
     // ---- initial order (initial_sort) ----
     SortResult sr;
     const uint32_t *sorted32 = nullptr; // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
+    int bucket_top_bits = 0;            // key bits the two global passes in front of the bucket sort order (0: four global passes)
     bool bucket_finished = false;       // ... and k_bucket_sort has already ordered the suffixes tied on those 32 bits by their low key bits
     uint64_t *sorted0 = nullptr;        // the initial keys in SA order (kept for the rank look-ups)
     // ---- the tied list and its buffers (from first_round_from_sorted_keys on) ----
@@ -955,6 +956,21 @@ struct DeviceBuild {
     bool lists_ready = false, finished32 = false, fused64 = false, sparse = false;
     int s_sym = 0, tkb = 0, key2_bits = 0;
 
+
+    // Bucket sort of the 32-bit first stage: which key bits do the global passes order?  16 (two passes of 8 bits) when an average
+    // bucket fits the 10-pairs-per-thread shapes (n = 2^28: 4096 pairs; 2^29: 8192), 18 (two passes of NINE bits) for larger texts
+    // (2^30: 2^18 buckets of 4096), 0 = four global passes.
+    int choose_bucket_bits() const
+    {
+        if (tn.no_bucket_sort || n < tn.bucket_min_n || n <= 1) return 0;
+        const bool wide_ok = onesweep_on(w.ss, tn) && tn.onesweep32_shape == 0;      // (nine-bit digits: single-pass engine, default tile)
+        if (tn.bucket_bits == 18 && wide_ok) return 18;
+        if (tn.bucket_bits == 16) return 16;
+        if ((n >> 16) * 10 <= bucket_cap(1) * 9) return 16;
+        if (wide_ok && (n >> 18) * 10 <= bucket_cap_max() * 9) return 18;
+        if ((n >> 16) * 10 <= bucket_cap_max() * 9) return 16;
+        return 0;
+    }
 
     // 1-2. which byte values occur -> symbol codes and key geometry; entropy probe, repeat probe, gram keys (read-backs: the 256 presence flags, two duplicate counts, the number of grams in use)
     int geometry_and_probes()
@@ -974,6 +990,7 @@ struct DeviceBuild {
         local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
 
         g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
+        bucket_top_bits = choose_bucket_bits();
         force_dense = tn.force_dense;
         text_ok = !force_dense && !tn.no_text_rounds;
         local_ok = !tn.no_local_sort;
@@ -990,11 +1007,30 @@ struct DeviceBuild {
                 // duplicates counted in a hash table (4 entries per sample, in the other key buffer) instead of sorting the sample
                 const uint32_t H = (uint32_t)S * 4u;
                 HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
-                HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
+                HIP_TRY(hipMemsetAsync(w.total, 0, 8, st));
                 PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
                                                         (unsigned long long *)w.keysB, H - 1u, w.total));
+                // the same samples, counted per bucket of the bucket sort: an estimate of its largest bucket (word 1 of the read-back)
+                const int tb = choose_bucket_bits();
+                if (tb) {
+                    HIP_TRY(hipMemsetAsync(w.keysC, 0, ((size_t)1 << tb) * 4, st));
+                    PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_bucket_hist), dim3((unsigned)ceil_div(S, BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS), 0, st,
+                                                            (const uint64_t *)w.keysA, S, tb, (uint32_t *)w.keysC));
+                    PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_u32_max), dim3((unsigned)(((size_t)1 << tb) / BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS), 0, st,
+                                                            (const uint32_t *)w.keysC, 1u << tb, w.total + 1));
+                }
                 uint32_t dups = 0;
-                { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
+                {
+                    uint32_t two[2] = { 0, 0 };
+                    const int rcw = read_words(two, w.total, 8, st); if (rcw) return rcw;
+                    dups = two[0];
+                    // (a flat text of 2^28 bytes: 16 samples per bucket on average, the fullest holds about 36 -> 9216 estimated, 4400 true)
+                    const double est = (double)two[1] * (double)n / (double)S;
+                    if (tb && est > 3.0 * (double)bucket_cap_max()) {
+                        bucket_top_bits = 0;
+                        if (trace) fprintf(stderr, "suffix_array_amd: bucket sort of the 32-bit first stage: largest bucket estimated at %.0f suffixes -> four global passes\n", est);
+                    }
+                }
                 // c - 1 per value seen c times under-counts pairs only when values repeat often, which is the
                 // "do not" case anyway; expected number of other suffixes sharing the top bits with a given one:
                 const double p32 = (double)n * 2.0 * (double)dups / ((double)S * (double)S);
@@ -1084,15 +1120,7 @@ struct DeviceBuild {
             // average bucket fits a workgroup well (n = 2^28: 4096 pairs, 2^29: 8192); larger texts take two passes of NINE bits
             // (2^30: 2^18 buckets of 4096).  A text whose LARGEST bucket fits no workgroup -- known only once the two passes have
             // run -- builds its keys again and takes the four global passes.
-            int top_bits = 0;                    // 0: four global passes
-            if (!tn.no_bucket_sort && n >= tn.bucket_min_n && n > 1) {
-                const bool wide_ok = onesweep_on(w.ss, tn) && tn.onesweep32_shape == 0;      // (nine-bit digits: single-pass engine, default tile)
-                if (tn.bucket_bits == 18 && wide_ok) top_bits = 18;
-                else if (tn.bucket_bits == 16) top_bits = 16;
-                else if ((n >> 16) * 10 <= bucket_cap(1) * 9) top_bits = 16;
-                else if (wide_ok && (n >> 18) * 10 <= bucket_cap_max() * 9) top_bits = 18;
-                else if ((n >> 16) * 10 <= bucket_cap_max() * 9) top_bits = 16;
-            }
+            int top_bits = bucket_top_bits;      // 0: four global passes (choose_bucket_bits, the probe's estimate of the largest bucket)
             for (;;) {
             // the first radix pass's digit histogram comes out of k_build_keys (keys in registers there): one read of every key less
             const FirstCounts fc = sort_first_counts(w.ss, tn, n, true);

@@ -63,6 +63,26 @@ __global__ __launch_bounds__(BK_STARTS_THREADS) void k_bucket_max(const uint32_t
     if (threadIdx.x == 0 && tot) atomicMax(&words[0], tot);
 }
 
+// Before any sorting: how large would the largest bucket be?  The entropy probe's samples (top 32 key bits in the high word,
+// kernels/keys.hpp k_sample_keys) are counted per bucket; the host scales the largest count by n / samples.  An estimate -- a
+// bucket of 4096 suffixes holds 16 of 2^20 samples -- that only has to tell a skewed alphabet (one bucket with a tenth of
+// the text) from a flat one, so that the former does not pay for two passes that the exact check afterwards throws away.
+__global__ __launch_bounds__(BK_STARTS_THREADS) void k_sample_bucket_hist(const uint64_t *__restrict__ samples, int64_t count, int top_bits,
+                                                                          uint32_t *__restrict__ hist)
+{
+    const int64_t i = (int64_t)blockIdx.x * BK_STARTS_THREADS + threadIdx.x;
+    if (i < count) atomicAdd(&hist[samples[i] >> (64 - top_bits)], 1u);
+}
+
+__global__ __launch_bounds__(BK_STARTS_THREADS) void k_u32_max(const uint32_t *__restrict__ a, uint32_t count, uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t lds[BK_STARTS_THREADS / WAVE];
+    const uint32_t i = blockIdx.x * BK_STARTS_THREADS + threadIdx.x;
+    uint32_t tot;
+    (void)block_incl_max<BK_STARTS_THREADS>(i < count ? a[i] : 0u, lds, &tot);
+    if (threadIdx.x == 0 && tot) atomicMax(out, tot);
+}
+
 // One workgroup per bucket.  Element e of the bucket is held by wave e / (64 J), item (e / 64) % J, lane e % 64 with
 // J = ceil(size / THREADS) items in use (wave-striped, so a stable rank inside the wave is a prefix count over lanes and items).
 // what the fused finish needs (FINISH = true): the text and its key geometry come as separate kernel arguments

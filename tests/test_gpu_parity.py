@@ -584,6 +584,30 @@ def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n,
         assert sa.last_stats()["sort_passes"] >= 4
 
 
+def test_bucket_route_is_not_tried_on_a_text_with_one_huge_bucket(oracle, monkeypatch):
+    """a text the entropy probe sends to the 32-bit first stage (its 4-byte prefixes are nearly unique) although one value of
+    the top 16 key bits holds 1/32 of the suffixes: the probe's samples, counted per bucket, say so and the two global passes
+    of the bucket route are not spent -- four global passes, the same array.  Without the probe (route forced) the exact check
+    after the two passes finds the bucket and the keys are built again: the same array."""
+    n = 1 << 24
+    rng = np.random.default_rng(77)
+    text = rng.integers(0, 256, n, dtype=np.uint8)
+    text[0::32] = 97
+    text[1::32] = 97
+    exp = oracle.sais(text)
+    monkeypatch.setenv("SA_AMD_BUCKET_MIN_N", "1")
+    assert np.array_equal(build(text), exp)
+    st = sa.last_stats()
+    assert st["top32_first"] == 1 and st["sort_passes"] == 4, st
+    monkeypatch.setenv("SA_AMD_FORCE_TOP32", "1")
+    assert np.array_equal(build(text), exp)
+    assert sa.last_stats()["sort_passes"] == 6, sa.last_stats()
+    text = rng.integers(0, 256, n, dtype=np.uint8)       # flat: the route is taken
+    monkeypatch.delenv("SA_AMD_FORCE_TOP32")
+    assert np.array_equal(build(text), oracle.sais(text))
+    assert sa.last_stats()["sort_passes"] == 3, sa.last_stats()
+
+
 @pytest.mark.parametrize("gen,n,seed", [("english", 700_000, 11), ("dna", 1 << 20, 12), ("sigma3", 300_000, 13),
                                         ("dna_repeats", 500_000, 14)])
 @pytest.mark.parametrize("cap", ["2", "5", "64", "1024"])
