@@ -467,10 +467,10 @@ static FirstCounts sort_first_counts(const SortScratch &ss, const Tuning &tn, in
 // ------------------------------------------------------------------------------------------
 struct BkShape { int threads, items, minw; };
 // (threads, pairs per thread, waves per SIMD the registers are held to); the first three are the ones in use -- the smallest that
-// holds the largest bucket is taken --, the fourth is kept for A/B measurements (SA_AMD_BUCKET_SHAPE tries that one first)
-static const BkShape bk_shapes[] = { { 512, 10, 8 }, { 1024, 10, 8 }, { 1024, 20, 1 }, { 256, 20, 1 } };
+// holds the largest bucket is taken --, the last is kept for A/B measurements (SA_AMD_BUCKET_SHAPE tries that one first)
+static const BkShape bk_shapes[] = { { 256, 10, 6 }, { 512, 10, 8 }, { 1024, 10, 8 }, { 1024, 20, 1 }, { 256, 20, 1 } };
 constexpr int N_BK_SHAPES = (int)(sizeof(bk_shapes) / sizeof(bk_shapes[0]));
-constexpr int N_BK_DEFAULT = 3;
+constexpr int N_BK_DEFAULT = 4;
 static int64_t bucket_cap(int shape) { return (int64_t)bk_shapes[shape].threads * bk_shapes[shape].items; }
 static int64_t bucket_cap_max() { return bucket_cap(N_BK_DEFAULT - 1); }
 
@@ -515,9 +515,10 @@ static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint3
                                                             (const uint32_t *)start, lbits, keys_out, vals_out, words + 1, F0, P0, K0));            \
     } while (0)
     switch (shape) {
-    case 0: BK_LAUNCH(512, 10, 8); break;
-    case 1: BK_LAUNCH(1024, 10, 8); break;
-    case 2: BK_LAUNCH(1024, 20, 1); break;
+    case 0: BK_LAUNCH(256, 10, 6); break;
+    case 1: BK_LAUNCH(512, 10, 8); break;
+    case 2: BK_LAUNCH(1024, 10, 8); break;
+    case 3: BK_LAUNCH(1024, 20, 1); break;
     default: BK_LAUNCH(256, 20, 1); break;
     }
 #undef BK_LAUNCH
@@ -966,7 +967,7 @@ struct DeviceBuild {
         const bool wide_ok = onesweep_on(w.ss, tn) && tn.onesweep32_shape == 0;      // (nine-bit digits: single-pass engine, default tile)
         if (tn.bucket_bits == 18 && wide_ok) return 18;
         if (tn.bucket_bits == 16) return 16;
-        if ((n >> 16) * 10 <= bucket_cap(1) * 9) return 16;
+        if ((n >> 16) * 10 <= bucket_cap(2) * 9) return 16;
         if (wide_ok && (n >> 18) * 10 <= bucket_cap_max() * 9) return 18;
         if ((n >> 16) * 10 <= bucket_cap_max() * 9) return 16;
         return 0;
