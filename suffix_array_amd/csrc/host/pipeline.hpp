@@ -745,18 +745,23 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         uint8_t *flags = (uint8_t *)scratchG;
         const unsigned gs_blocks = (unsigned)ceil_div(m, GS_TILE);
         const int cap = tn.group_cap;                    // largest group ordered in LDS (C3: 1024 beats 512 by 1%)
+        // groups of up to GB_CAP (8 192) members whose keys fit 32 bits: one workgroup each, in LDS (k_group_sort_big), on the list of
+        // their first members that k_group_sort writes (scratchU is free until k_flag_gather); the rest goes through the global sort
+        const bool big_local = !tn.no_big_group_sort && kb <= 32 && m > GS_CAP;
+        uint32_t *bheads = big_local ? scratchU : (uint32_t *)nullptr, *bcount = big_local ? w.total + 12 : (uint32_t *)nullptr;
+        HIP_TRY(hipMemsetAsync(w.total + 12, 0, 8, st));           // [12] listed first members, [13] members ordered by k_group_sort_big
         if (K.mode == KS_TEXT)
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_TEXT>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
-                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap, bheads, bcount));
         else if (K.mode == KS_LOWKEY)
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_LOWKEY>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
-                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap, bheads, bcount));
         else if (K.mode == KS_RANK)
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_RANK>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
-                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap, bheads, bcount));
         else if (K.mode == KS_CHASE)
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_CHASE>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
-                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap, bheads, bcount));
         else {
             // sparse look-up: its own kernel, one suffix per thread (a chain of ~60 dependent loads each), then the sort on those keys
             int64_t gblocks = ceil_div(m, GK_THREADS);
@@ -764,18 +769,25 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
             PROF(KC_GATHER, m, st, hipLaunchKernelGGL((k_gather_textkey<KS_SPARSE>), dim3((unsigned)gblocks), dim3(GK_THREADS), 0, st,
                                                       (const uint32_t *)Vcur, Gcur, dT, P, m, n, K, rkA));
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_PRE>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
-                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap));
+                                                     Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap, bheads, bcount));
         }
         if (gs_blocks > 1)
             PROF(KC_LOCAL, 0, st, hipLaunchKernelGGL((k_group_sort_straddle), dim3(gs_blocks - 1), dim3(GX_THREADS), 0, st, rkA, Vcur, Gcur,
                                                      Ucur, m, flags, cap, K, n));
+        if (big_local) {
+            const int lo = cap > GS_CAP ? cap : GS_CAP;
+            PROF(KC_LOCAL, 0, st, hipLaunchKernelGGL((k_group_sort_big<256>), dim3((unsigned)(8 * cu_count())), dim3(256), 0, st, rkA, Vcur, Gcur, m, kb, lo,
+                                                     (const uint32_t *)bheads, (const uint32_t *)bcount, flags, w.total + 13));
+            PROF(KC_LOCAL, 0, st, hipLaunchKernelGGL((k_group_sort_big<512>), dim3((unsigned)(4 * cu_count())), dim3(512), 0, st, rkA, Vcur, Gcur, m, kb,
+                                                     lo > GB_CAP_SMALL ? lo : GB_CAP_SMALL, (const uint32_t *)bheads, (const uint32_t *)bcount, flags, w.total + 13));
+        }
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     (const uint8_t *)flags, Ucur, Gcur, m, w.tcnt, w.ft_cnt));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.thead, tiles, w.total + 8));
-        uint32_t tot9[9] = { 0 };                             // [0] flagged members, [8] flagged groups
+        uint32_t tot9[14] = { 0 };                            // [0] flagged members, [8] flagged groups, [13] members k_group_sort_big ordered
         { const int rcw = read_words(tot9, w.total, sizeof(tot9), st); if (rcw) return rcw; }
-        const int64_t m_big = tot9[0];
+        const int64_t m_big = tot9[0], m_big_local = tot9[13];
         // the flagged members are sorted in the first `half` entries of rkB / Valt with the second half as the alternate
         // buffers: half is even (16-byte aligned 8-byte keys) and half + m_big never exceeds the n entries the slabs hold
         const size_t half = ((size_t)n / 2) & ~(size_t)1;
@@ -794,7 +806,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
                                                                (const uint64_t *)sr.keys, (const uint32_t *)sr.vals,
                                                                (const uint32_t *)scratchU, Gcur, kb, m_big, rkA, Vcur));
             }
-            out->keys = rkA; out->vals = Vcur; out->vnext = Valt; out->m_global = m_big;
+            out->keys = rkA; out->vals = Vcur; out->vnext = Valt; out->m_global = m_big + m_big_local;      // (neither kind has been chased)
             local->locally_sorted += m - m_big;
             if (m_big * 2 > m) *local_ok = false;           // mostly large groups: not worth another local pass
             return SA_AMD_OK;

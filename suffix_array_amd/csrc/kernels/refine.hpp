@@ -162,12 +162,15 @@ constexpr int GS_ITEMS = 8;
 constexpr int GS_TILE = GS_THREADS * GS_ITEMS;
 constexpr int GS_WORDS = GS_TILE / 64;
 constexpr int GS_CAP = 1024;        // upper bound of the run-time group-size cap
+constexpr int GB_LIST_MIN = 256;    // k_group_sort_big: a group that runs on beyond its tile is listed when it has this many members inside it
 
 template <int MODE>
 __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, const uint32_t *__restrict__ G,
                                                             const uint32_t *__restrict__ U, const uint8_t *__restrict__ T, KeyParams P,
                                                             int64_t m, int64_t n, KeySrc K, uint64_t *keys,
-                                                            uint32_t *Vout, uint8_t *__restrict__ bigflag, int cap)   // Vout may be Vin
+                                                            uint32_t *Vout, uint8_t *__restrict__ bigflag, int cap,   // Vout may be Vin
+                                                            uint32_t *__restrict__ big_heads = nullptr,               // list positions of the first members of groups
+                                                            uint32_t *__restrict__ n_big_heads = nullptr)             // that may be k_group_sort_big's (nullptr: not listed)
 {
     __shared__ uint64_t s_key[GS_TILE];
     __shared__ uint32_t s_val[GS_TILE];
@@ -311,6 +314,13 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
         if (owned) owned_mask |= 1u << r;
         dest[r] = owned ? start + rank : jl;
         big[r] = valid && !owned;
+        // first member of a group of more than GS_CAP members, or of one that runs on beyond the tile (its size is not known here:
+        // k_group_sort_big looks, and leaves the short ones to k_group_sort_straddle)
+        // (of the latter only those with at least GB_LIST_MIN members inside this tile: nearly every tile ends inside some small
+        // group, and a hundred thousand list entries that k_group_sort_big only looks at cost more than the few large groups
+        // that start in the last slots of a tile and so stay with the global sort)
+        if (big_heads && big[r] && u[r] == g[r] && (end < 0 ? GS_TILE - start >= GB_LIST_MIN : end - start > GS_CAP))
+            big_heads[atomicAdd(n_big_heads, 1u)] = (uint32_t)(base + jl);
         if (CHASE) { s_val[dest[r]] = v[r]; s_rng[0][dest[r]] = rng; }      // (s_val / s_rng are not read by the counts above)
     }
     stamp(3);      // group extents + rank loops
@@ -545,6 +555,203 @@ __global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__
             V[start + i] = s_v[cur][i];
             bigflag[start + i] = 0;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_group_sort_big: groups of GS_CAP + 1 .. GB_CAP (8 192) members, one workgroup per group, ordered in LDS the way k_bucket_sort
+// (kernels/bucket_sort.hpp) orders a bucket -- instead of six global radix passes over (index of the group, key2) pairs with a
+// compaction in front and a scatter behind.  The members' secondary keys (at most 32 bits) are where k_group_sort left them:
+// keys[j] = group head << kb | key2, V[j] = suffix, in list order.  First pass on the low 10 key bits by one LDS counter per
+// digit (the order among equal digits is left to the atomics: members that agree in ALL key bits stay tied, and which of them
+// takes which slot of the subgroup is nobody's business), then stable 6-bit passes (6 ballots + mbcnt) over the rest.
+// heads: the list k_group_sort wrote (first members of groups it could not own); a group of at most `cap` members is
+// k_group_sort_straddle's, one of more than GB_CAP stays flagged for the global sort.  sorted_members: members ordered here
+// (the host counts them with the members of the global sort: no chasing after a round that had such groups).
+// ------------------------------------------------------------------------------------------
+constexpr int GB_ITEMS = 16;
+constexpr int GB_CAP_SMALL = 256 * GB_ITEMS;       // 4 096 members: 256 threads, 37 KiB of LDS, four workgroups per CU
+constexpr int GB_CAP = 512 * GB_ITEMS;             // 8 192 members: 512 threads, 70 KiB of LDS, two workgroups per CU (a 1 024-thread instance
+                                                   // for 16 384 took 60 ps per member, more than the global sort's share)
+constexpr int GB_ABITS = 10, GB_BBITS = 6;
+// size_lo < members <= GB_THREADS * GB_ITEMS: the groups this instance orders (two launches over the same list: 256 threads
+// for the groups of up to 4 096 members -- a larger workgroup spends its time in barriers on them --, 512 for the rest)
+template <int GB_THREADS>
+__global__ __launch_bounds__(GB_THREADS) void k_group_sort_big(uint64_t *__restrict__ keys, uint32_t *__restrict__ V, const uint32_t *__restrict__ G,
+                                                               int64_t m, int kb, int size_lo, const uint32_t *__restrict__ heads,
+                                                               const uint32_t *__restrict__ n_heads, uint8_t *__restrict__ bigflag,
+                                                               uint32_t *__restrict__ sorted_members)
+{
+    constexpr int GB_CAP = GB_THREADS * GB_ITEMS;  // (shadows the constant of the large instance)
+    constexpr int NWAVES = GB_THREADS / WAVE;
+    constexpr int NB_A = 1 << GB_ABITS, NB_B = 1 << GB_BBITS;
+    static_assert(NB_B == WAVE && NB_A % GB_THREADS == 0, "lane d of wave 0 owns digit d of a stable pass; the counters of the first are scanned by the whole workgroup");
+    static_assert(GB_CAP < 65536 && GB_ITEMS % 2 == 0, "16-bit places, two to a register");
+    __shared__ uint32_t lds_k[GB_CAP];
+    __shared__ uint32_t lds_v[GB_CAP];
+    __shared__ uint32_t cnt_a[NB_A];
+    __shared__ uint16_t wave_hist[NWAVES][NB_B];
+    __shared__ uint32_t digit_base[NB_B];
+    __shared__ uint32_t scan_lds[NWAVES + 1];
+    __shared__ int s_size;
+    const int tid = threadIdx.x, l = lane_id(), w = wave_id();
+    uint16_t *my_hist = wave_hist[w];
+    const uint32_t count = *n_heads;
+    const int lo_size = size_lo;                                   // smaller groups are not this instance's
+    for (uint32_t ent = blockIdx.x; ent < count; ent += gridDim.x) {
+        __syncthreads();                                           // (the previous group's LDS is free)
+        const int64_t j0 = (int64_t)heads[ent];
+        const uint32_t g0 = G[j0];
+        if (tid == 0) s_size = GB_CAP + 1;
+        __syncthreads();
+        // Mine?  Two look-ups say: the member at lo_size still belongs to the group (more than lo_size members) and the one at
+        // GB_CAP does not (at most GB_CAP).  Then the size: the first list position behind j0 whose group head differs -- all
+        // positions looked at in one go (a chunk at a time costs a memory round trip per chunk).
+        {
+            const bool more = j0 + lo_size < m && G[j0 + lo_size] == g0;
+            const bool fits = j0 + GB_CAP >= m || G[j0 + GB_CAP] != g0;
+            if (!(more && fits)) continue;                         // (uniform: every thread reads the same two words)
+        }
+        {
+            int first = GB_CAP + 1;
+#pragma unroll
+            for (int i = GB_ITEMS; i >= 0; --i) {                  // (e = GB_CAP is known to differ: the scan stops there)
+                const int e = i * GB_THREADS + tid;
+                if (e > lo_size && e <= GB_CAP && (j0 + e >= m || G[j0 + e] != g0)) first = e;
+            }
+            if (first <= GB_CAP) atomicMin(&s_size, first);
+        }
+        __syncthreads();
+        const int size = s_size;
+        if (size <= lo_size || size > GB_CAP) continue;            // (cannot happen; uniform)
+        const int J = (size + GB_THREADS - 1) / GB_THREADS;
+        const int e0 = w * J * WAVE + l;
+        const uint32_t kmask = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
+        uint32_t key[GB_ITEMS], val[GB_ITEMS], pp[GB_ITEMS / 2];
+#define GB_POS(j) ((pp[(j) >> 1] >> (16 * ((j) & 1))) & 0xffffu)
+#pragma unroll
+        for (int j = 0; j < GB_ITEMS; ++j) {
+            const int e = e0 + j * WAVE;
+            uint32_t kx = 0, vx = 0;
+            if (j < J && e < size) { kx = (uint32_t)keys[j0 + e] & kmask; vx = V[j0 + e]; }
+            key[j] = kx; val[j] = vx;
+        }
+        const int abits = kb < GB_ABITS ? kb : GB_ABITS;
+        {
+            // ---- first pass: one counter per digit hands out the places ----
+            const uint32_t amask = (1u << abits) - 1u;
+            for (int i = tid; i < NB_A; i += GB_THREADS) cnt_a[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < GB_ITEMS; ++j) {
+                uint32_t r = 0;
+                if (j < J && (e0 + j * WAVE) < size) r = atomicAdd(&cnt_a[key[j] & amask], 1u);
+                if ((j & 1) == 0) pp[j >> 1] = r; else pp[j >> 1] |= r << 16;
+            }
+            lds_barrier();
+            {
+                constexpr int BPT = NB_A / GB_THREADS;
+                uint32_t c[BPT], sum = 0;
+#pragma unroll
+                for (int i = 0; i < BPT; ++i) { c[i] = cnt_a[tid * BPT + i]; sum += c[i]; }
+                uint32_t all;
+                uint32_t run = block_excl_sum_b<GB_THREADS, true>(sum, scan_lds, &all);
+#pragma unroll
+                for (int i = 0; i < BPT; ++i) { cnt_a[tid * BPT + i] = run; run += c[i]; }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < GB_ITEMS; ++j) {
+                if (j < J && (e0 + j * WAVE) < size) {
+                    const uint32_t ps = GB_POS(j) + cnt_a[key[j] & amask];
+                    lds_k[ps] = key[j];
+                    lds_v[ps] = val[j];
+                }
+            }
+        }
+        // ---- stable passes over the remaining key bits, 6 at a time ----
+#pragma unroll
+        for (int p = 0; p < (32 - 1 + GB_BBITS - 1) / GB_BBITS; ++p) {
+            const int shift = abits + p * GB_BBITS;
+            if (shift >= kb) break;                                // (uniform)
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < GB_ITEMS; ++j) {
+                const int e = e0 + j * WAVE;
+                uint32_t kx = 0, vx = 0;
+                if (j < J && e < size) { kx = lds_k[e]; vx = lds_v[e]; }
+                key[j] = kx; val[j] = vx;
+            }
+            {
+                // a digit that is the same for every member (the top bits of n + rank) makes the pass the identity: skip it
+                const uint32_t dref = (lds_k[0] >> shift) & (uint32_t)(NB_B - 1);
+                bool same = true;
+#pragma unroll
+                for (int j = 0; j < GB_ITEMS; ++j)
+                    if (j < J && (e0 + j * WAVE) < size) same = same && ((key[j] >> shift) & (uint32_t)(NB_B - 1)) == dref;
+                if (__syncthreads_and(same ? 1 : 0)) continue;     // (uniform; the bucket stays in LDS as it is)
+            }
+            for (int i = tid; i < NWAVES * NB_B / 2; i += GB_THREADS) ((uint32_t *)&wave_hist[0][0])[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < GB_ITEMS; ++j) {
+                uint32_t r = 0;
+                if (j < J) {                                       // (uniform)
+                    const bool ok = (e0 + j * WAVE) < size;
+                    const uint32_t d = (key[j] >> shift) & (uint32_t)(NB_B - 1);
+                    const uint64_t okm = __ballot(ok);
+                    uint32_t xlo = ~(uint32_t)okm, xhi = ~(uint32_t)(okm >> 32);
+#pragma unroll
+                    for (int bb = 0; bb < GB_BBITS; ++bb) {
+                        const uint32_t sel = (uint32_t)((int32_t)(d << (31 - bb)) >> 31);
+                        const uint64_t bal = __ballot(sel != 0);
+                        xlo |= (uint32_t)bal ^ sel;
+                        xhi |= (uint32_t)(bal >> 32) ^ sel;
+                    }
+                    const uint32_t mlo = ~xlo, mhi = ~xhi;
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                    const uint32_t prior = my_hist[d];
+                    if (ok && below == 0) my_hist[d] = (uint16_t)(prior + (uint32_t)(__popc(mlo) + __popc(mhi)));
+                    r = prior + below;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if ((j & 1) == 0) pp[j >> 1] = r; else pp[j >> 1] |= r << 16;
+            }
+            lds_barrier();
+            if (w == 0) {
+                uint32_t tot = 0;
+#pragma unroll
+                for (int ww = 0; ww < NWAVES; ++ww) {
+                    const uint32_t cnt = wave_hist[ww][l];
+                    wave_hist[ww][l] = (uint16_t)tot;
+                    tot += cnt;
+                }
+                digit_base[l] = wave_incl_sum(tot) - tot;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < GB_ITEMS; ++j) {
+                if (j < J && (e0 + j * WAVE) < size) {
+                    const uint32_t d = (key[j] >> shift) & (uint32_t)(NB_B - 1);
+                    const uint32_t ps = GB_POS(j) + digit_base[d] + my_hist[d];
+                    lds_k[ps] = key[j];
+                    lds_v[ps] = val[j];
+                }
+            }
+        }
+#undef GB_POS
+        __syncthreads();
+        const uint64_t ghead = (uint64_t)g0 << kb;
+#pragma unroll
+        for (int j = 0; j < GB_ITEMS; ++j) {
+            const int idx = tid + j * GB_THREADS;
+            if (idx < size) {
+                keys[j0 + idx] = ghead | (uint64_t)lds_k[idx];
+                V[j0 + idx] = lds_v[idx];
+                bigflag[j0 + idx] = 0;
+            }
+        }
+        if (tid == 0) atomicAdd(sorted_members, (uint32_t)size);
     }
 }
 

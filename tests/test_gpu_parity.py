@@ -584,6 +584,29 @@ def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n,
         assert sa.last_stats()["sort_passes"] >= 4
 
 
+@pytest.mark.parametrize("period,copies", [(300, 1025), (300, 1500), (64, 4096), (64, 4097), (64, 5000), (50, 8192), (50, 8193), (40, 20000), (700, 3000)])
+def test_groups_of_thousands_are_ordered_in_lds(oracle, monkeypatch, period, copies):
+    """k_group_sort_big: groups of 1 025 .. 8 192 members, one workgroup each, instead of the global radix sort.  A random block
+    repeated `copies` times ties every suffix with `copies` - 1 others (minus the ones cut off by the end of the text) round
+    after round; a second text mixes such groups with small ones and with a run.  With the kernel, without it, with a small cap
+    on the groups k_group_sort owns, with every rank-doubling route."""
+    rng = np.random.default_rng(period * 31 + copies)
+    block = rng.integers(0, 256, period, dtype=np.uint8)
+    text = np.tile(block, copies)
+    mixed = np.concatenate([np.tile(block, copies // 2), rng.integers(0, 4, 50_000, dtype=np.uint8), np.tile(block[: period // 2], copies),
+                            np.full(3000, 7, dtype=np.uint8), corpus.english(60_000, 5)])
+    for t in (text, mixed):
+        exp = oracle.sais(t)
+        for env in ({}, {"SA_AMD_NO_BIG_GROUP_SORT": "1"}, {"SA_AMD_GROUP_CAP": "64"}, {"SA_AMD_FORCE_DENSE": "1"},
+                    {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_CHASE": "1"}, {"SA_AMD_NO_SPLIT": "1", "SA_AMD_DENSE_REKEY_MIN": "1"},
+                    {"SA_AMD_SPARSE_DIV": "1"}, {"SA_AMD_NO_TEXT_ROUNDS": "1", "SA_AMD_NO_TOP32": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            assert np.array_equal(build(t), exp), (period, copies, env)
+            for k in env:
+                monkeypatch.delenv(k)
+
+
 def test_bucket_route_is_not_tried_on_a_text_with_one_huge_bucket(oracle, monkeypatch):
     """a text the entropy probe sends to the 32-bit first stage (its 4-byte prefixes are nearly unique) although one value of
     the top 16 key bits holds 1/32 of the suffixes: the probe's samples, counted per bucket, say so and the two global passes
@@ -739,7 +762,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_NO_PREFAULT",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_NO_PREFAULT",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 

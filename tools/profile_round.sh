@@ -45,13 +45,13 @@ cd $R
 python tools/trace_sequence.py $O/prof_seq/d_kernel_trace.csv -2 > $O/c3_dispatch_sequence.txt
 rm -rf $O/prof_seq
 timeout -k 10 900 python tools/adversarial_timing.py 268435456 > $O/adversarial_256m.txt 2>&1
-( [ -x tools/bin/pcie_probe ] && timeout -k 10 300 tools/bin/pcie_probe 1024; timeout -k 10 300 python tools/host_api_timing.py ) > $O/host_path.txt 2>&1
+( if [ -x tools/bin/pcie_probe ]; then timeout -k 10 300 tools/bin/pcie_probe 1024; fi; timeout -k 10 300 python tools/host_api_timing.py ) > $O/host_path.txt 2>&1
 timeout -k 10 300 python tools/small_latency.py > $O/small_latency.txt 2>&1
 timeout -k 10 300 python tools/extras_bench.py > $O/extras.txt 2>&1
 timeout -k 10 300 python tools/search_bench.py > $O/search_throughput.txt 2>&1
 ( timeout -k 10 120 python tools/onesweep_stamps.py 32 26 0; timeout -k 10 120 python tools/onesweep_stamps.py 64 26 0 ) > $O/onesweep_stamps.txt 2>&1
 timeout -k 10 300 python tools/group_sort_stamps.py > $O/group_sort_stamps.txt 2>&1
-( [ -x tools/bin/scatter_probe ] && timeout -k 10 60 tools/bin/scatter_probe 28 8 8 0 && timeout -k 10 60 tools/bin/scatter_probe 28 4 12 0 ) > $O/scatter_probe.txt 2>&1
+( if [ -x tools/bin/scatter_probe ]; then timeout -k 10 60 tools/bin/scatter_probe 28 8 8 0; timeout -k 10 60 tools/bin/scatter_probe 28 4 12 0; fi ) > $O/scatter_probe.txt 2>&1 || true
 timeout -k 10 300 python tools/ab_env.py c3_english_256m - SA_AMD_NO_ONESWEEP=1 SA_AMD_ONESWEEP_FLAGS=1 SA_AMD_NO_REPEAT_PROBE=1 SA_AMD_NO_REPEAT_PROBE=1,SA_AMD_MAX_TEXT_ROUNDS=1 SA_AMD_FORCE_DENSE=1 SA_AMD_CHASE=1 SA_AMD_CHASE=3 SA_AMD_CHASE=15 SA_AMD_SCATTER_LEVELS=1 SA_AMD_BINNED_MIN=4194304 SA_AMD_BINNED_MIN=268435457 SA_AMD_GROUP_CAP=512 SA_AMD_NO_GRAM_KEYS=1 > $O/ab_knobs_c3.txt 2>&1
 timeout -k 10 300 python tools/ab_env.py c2_uniform_256m - SA_AMD_NO_ONESWEEP=1 SA_AMD_ONESWEEP_FLAGS=1 SA_AMD_ONESWEEP32_SHAPE=1 SA_AMD_ONESWEEP32_SHAPE=2 SA_AMD_ONESWEEP32_SHAPE=3 >> $O/ab_knobs_c3.txt 2>&1
 tail -3 $O/adversarial_256m.txt; tail -4 $O/ab_knobs_c3.txt
