@@ -27,7 +27,7 @@ def load(counter_dir):
                 k = "k_scatter_pairs"                 # bench.py's kernel class of all binned ISA writes
             if k == "k_onesweep":                    # template arguments: <threads, items, KEY TYPE, values through the keys' buffer, workgroups per CU>
                 k = "k_onesweep32" if "unsigned int" in full else "k_onesweep"
-            if k == "k_group_sort_straddle":
+            if k in ("k_group_sort_straddle", "k_group_sort_big"):
                 k = "k_group_sort"                    # bench.py's class of all fused gather + group-sort kernels
             if k.startswith("k_radix_downsweep"):     # all tile-scatter variants are one kernel class per key width in bench.py
                 # template arguments: <threads, items, granule, min waves, stamps, KEY TYPE, prefetched items>

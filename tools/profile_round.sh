@@ -20,6 +20,13 @@ cd $R
 # builds per PMC pass: first touch + profiled build + 1 warm-up + 2 timed = 5 (bench.py run()); the verification kernels run once
 python tools/pmc_traffic.py $O/pmc $O/traffic.json c3_english_256m 268435456 5
 cp $O/traffic.json profiles/traffic.json     # bench.py quotes the figures from there: measured first, on this code
+# the same two passes on the 256 MiB random text (the 32-bit first stage: two global passes + k_bucket_sort), evidence only
+cd /tmp
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc2/pmc_FETCH_SIZE -- python3 $R/bench.py --steps 2 --warmup 1 --workload c2_uniform_256m --no-cpu-baseline --no-end-to-end > $O/pmc2_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc2/pmc_WRITE_SIZE -- python3 $R/bench.py --steps 2 --warmup 1 --workload c2_uniform_256m --no-cpu-baseline --no-end-to-end > $O/pmc2_write.log 2>&1
+cd $R
+python tools/pmc_traffic.py $O/pmc2 $O/traffic_c2_uniform_256m.json c2_uniform_256m 268435456 5
+find $O/pmc2 -name "*.csv" -delete
 for w in c3_english_256m c3_iid_256m c2_uniform_256m c2_uniform_64m c4_dna_1g c4_dna_repeats_1g c5_uniform_512m; do
   timeout -k 10 500 python bench.py --steps 5 --warmup 1 --workload $w > $O/bench_$w.json 2> $O/bench_$w.err
 done
