@@ -172,6 +172,7 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     const int copy_threads = (int)env_int("SA_AMD_COPY_THREADS", 12, 0, 32);      // 0: plain hipMemcpy into the caller's buffer
     const size_t staged_min = (size_t)env_int("SA_AMD_STAGED_MIN_BYTES", (int64_t)64 << 20, 0, (int64_t)1 << 40);
     const bool staged = copy_threads > 0 && out_bytes_all >= staged_min;
+    std::atomic<bool> prefault_stop(false);                     // (declared before the handle: the helpers read it until finish())
     HelperPool::Async prefault;
     HelperPool &hp = helper_pool(node);
     struct PrefaultEnd {                                         // (also when something below throws: the helpers hold a pointer to the handle)
@@ -187,13 +188,15 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     tm.h2d = t1 - t0;
     // (started behind the upload: the runtime's staging of the pageable text and the page touching would share the same cores)
     if (staged && env_int("SA_AMD_NO_PREFAULT", 0, 0, 1) == 0) {
+        // In the order the download will fill the array, a staging chunk's worth (16 MiB) at a time, helper t taking the units
+        // t, t + T, ...: when the build is done before the whole array is mapped (a 10 ms build of 512 MiB of random bytes against
+        // 25-70 ms for the 2 GiB of its array) the helpers stop after the unit they are in and the download starts at once --
+        // into the mapped front part at full speed, page-faulting the rest in as it goes, which costs less than waiting for it.
         char *dst = (char *)SA_host;
-        const size_t per = (((out_bytes_all + copy_threads - 1) / copy_threads) + 4095) & ~(size_t)4095;
+        const size_t units = (out_bytes_all + STAGE_BYTES - 1) / STAGE_BYTES;
+        const int T = copy_threads;
+        std::atomic<bool> *stop = &prefault_stop;
         hp.start(prefault, copy_threads, [=](int t) {
-            const size_t b = (size_t)t * per, e = b + per < out_bytes_all ? b + per : out_bytes_all;
-            if (b >= e) return;
-            uintptr_t a = (uintptr_t)(dst + b);
-            const uintptr_t end = (uintptr_t)(dst + e);
             auto touch = [](uintptr_t from, uintptr_t to) {
                 while (from < to) {
                     volatile char *q = (volatile char *)from;
@@ -202,20 +205,26 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
                     from = (from + 4096) & ~(uintptr_t)4095;      // first byte of the next page
                 }
             };
-            // whole pages: one madvise call maps them writable without a trap per page (Linux >= 5.14; contents untouched);
-            // anything it refuses, and the partial pages at the ends, are touched byte by byte
-            const uintptr_t pa = (a + 4095) & ~(uintptr_t)4095, pe = end & ~(uintptr_t)4095;
-            if (pe > pa && madvise((void *)pa, pe - pa, SA_MADV_POPULATE_WRITE) == 0) {
-                touch(a, pa < end ? pa : end);
-                touch(pe > a ? pe : a, end);
-            } else touch(a, end);
+            for (size_t u = (size_t)t; u < units && !stop->load(std::memory_order_relaxed); u += (size_t)T) {
+                const size_t b = u * STAGE_BYTES, e = b + STAGE_BYTES < out_bytes_all ? b + STAGE_BYTES : out_bytes_all;
+                const uintptr_t a = (uintptr_t)(dst + b), end = (uintptr_t)(dst + e);
+                // whole pages: one madvise call maps them writable without a trap per page (Linux >= 5.14; contents untouched);
+                // anything it refuses, and the partial pages at the ends, are touched byte by byte
+                const uintptr_t pa = (a + 4095) & ~(uintptr_t)4095, pe = end & ~(uintptr_t)4095;
+                if (pe > pa && madvise((void *)pa, pe - pa, SA_MADV_POPULATE_WRITE) == 0) {
+                    touch(a, pa < end ? pa : end);
+                    touch(pe > a ? pe : a, end);
+                } else touch(a, end);
+            }
         });
     }
     if (rc == SA_AMD_OK) {
         LaneTurn turn(lanes.run, turns);
         rc = build_device(dT, dSA, n, dW, (int64_t)wb, st, nullptr);
     }
-    hp.finish(prefault);                                         // (usually done by now; otherwise the caller takes what is left -- also after a failed build)
+    // (usually done by now; otherwise no further unit is started -- SA_AMD_PREFAULT_WAIT=1: every page is mapped first, A/B)
+    if (env_int("SA_AMD_PREFAULT_WAIT", 0, 0, 1) == 0) prefault_stop.store(true, std::memory_order_relaxed);
+    hp.finish(prefault);
     t0 = wall_ms();
     tm.build = t0 - t1;
     if (rc == SA_AMD_OK) {

@@ -14,7 +14,7 @@ for name in names:
     t = corpus.workload(name)
     out = np.zeros(t.size + 1, dtype=np.uint32)
     sa.saca(t, out)          # warm-up (context, code objects, pool)
-    for threads in ("0", "2", "4", "8"):
+    for threads in (os.environ.get("SA_HOST_TIMING_THREADS", "0,2,4,8").split(",")):
         os.environ["SA_AMD_COPY_THREADS"] = threads
         for mode in ("reused", "fresh"):
             best, bt = 1e9, None
