@@ -1108,33 +1108,18 @@ struct DeviceBuild {
         return SA_AMD_OK;
     }
 
-    // 3-4. packed keys and the initial LSD sort, the last pass writing straight into SA
-    int initial_sort()
+    // 4b. the 32-bit first stage: the top 32 key bits as (u32, u32) pairs -- two global passes + the in-LDS bucket sort, or four
+    //     global passes (read-back: the largest bucket)
+    int initial_sort_top32(uint32_t *vals0, uint8_t *packed_out, bool iota)
     {
         int rc = SA_AMD_OK; (void)rc;
-        // 3. packed keys, 4. initial sort: all key bits as (u64 key, u32 suffix) pairs, or only the top 32 bits as
-        //    (u32, u32) pairs in 12 Ki-element tiles -- two thirds of the bytes per pass and half the passes
-        sr.keys = w.keysA; sr.vals = w.valsA; sr.passes = 0;
-        sorted32 = nullptr;               // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
-        bucket_finished = false;
-        // value of pair i = i: not stored by k_build_keys, the first sort pass takes the index (saves 8 B / suffix)
-        const bool iota = n >= 2 && key_bits > 0;
-        uint32_t *vals0 = iota ? (uint32_t *)nullptr : w.valsA;
-        // alphabets of 2, 4 or 16 symbols: k_build_keys also writes the text as bit-packed codes, which every later random
-        // read of the text uses instead (a key becomes a bit field of two words; DNA shrinks to a quarter: cache-resident)
-        uint8_t *packed_out = nullptr;
-        if ((P.bits == 1 || P.bits == 2 || P.bits == 4) && n >= 64 && !tn.no_packed_text) {
-            packed_out = w.packed;
-            HIP_TRY(hipMemsetAsync(packed_out + (size_t)(n >> 3) * P.bits, 0, 64, st));     // the padding behind the last whole group
-        }
-        if (top_shift) {
-            uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
-            // Two global passes over the top 16 key bits + one pass that orders every bucket (= value of those bits) in LDS, when an
-            // average bucket fits a workgroup well (n = 2^28: 4096 pairs, 2^29: 8192); larger texts take two passes of NINE bits
-            // (2^30: 2^18 buckets of 4096).  A text whose LARGEST bucket fits no workgroup -- known only once the two passes have
-            // run -- builds its keys again and takes the four global passes.
-            int top_bits = bucket_top_bits;      // 0: four global passes (choose_bucket_bits, the probe's estimate of the largest bucket)
-            for (;;) {
+        uint32_t *k32a = (uint32_t *)w.keysA, *k32b = (uint32_t *)w.keysB;
+        // Two global passes over the top 16 key bits + one pass that orders every bucket (= value of those bits) in LDS, when an
+        // average bucket fits a workgroup well (n = 2^28: 4096 pairs, 2^29: 8192); larger texts take two passes of NINE bits
+        // (2^30: 2^18 buckets of 4096).  A text whose LARGEST bucket fits no workgroup -- known only once the two passes have
+        // run -- builds its keys again and takes the four global passes.
+        int top_bits = bucket_top_bits;      // 0: four global passes (choose_bucket_bits, the probe's estimate of the largest bucket)
+        for (;;) {
             // the first radix pass's digit histogram comes out of k_build_keys (keys in registers there): one read of every key less
             const FirstCounts fc = sort_first_counts(w.ss, tn, n, true);
             const bool counted = n > 1;
@@ -1186,7 +1171,32 @@ struct DeviceBuild {
             sr.vals = s32.vals; sr.passes = s32.passes;
             sr.keys = (s32.keys == k32a) ? w.keysA : w.keysB;      // the 8n-byte buffer that now holds the sorted 32-bit keys
             break;
-            }
+        }
+        return SA_AMD_OK;
+    }
+
+    // 3-4. packed keys and the initial LSD sort, the last pass writing straight into SA
+    int initial_sort()
+    {
+        int rc = SA_AMD_OK; (void)rc;
+        // 3. packed keys, 4. initial sort: all key bits as (u64 key, u32 suffix) pairs, or only the top 32 bits as
+        //    (u32, u32) pairs in 12 Ki-element tiles -- two thirds of the bytes per pass and half the passes
+        sr.keys = w.keysA; sr.vals = w.valsA; sr.passes = 0;
+        sorted32 = nullptr;               // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
+        bucket_finished = false;
+        // value of pair i = i: not stored by k_build_keys, the first sort pass takes the index (saves 8 B / suffix)
+        const bool iota = n >= 2 && key_bits > 0;
+        uint32_t *vals0 = iota ? (uint32_t *)nullptr : w.valsA;
+        // alphabets of 2, 4 or 16 symbols: k_build_keys also writes the text as bit-packed codes, which every later random
+        // read of the text uses instead (a key becomes a bit field of two words; DNA shrinks to a quarter: cache-resident)
+        uint8_t *packed_out = nullptr;
+        if ((P.bits == 1 || P.bits == 2 || P.bits == 4) && n >= 64 && !tn.no_packed_text) {
+            packed_out = w.packed;
+            HIP_TRY(hipMemsetAsync(packed_out + (size_t)(n >> 3) * P.bits, 0, 64, st));     // the padding behind the last whole group
+        }
+        if (top_shift) {
+            rc = initial_sort_top32(vals0, packed_out, iota);
+            if (rc) return rc;
         } else {
             const FirstCounts fc = sort_first_counts(w.ss, tn, n, false);
             const bool counted = n > 1 && key_bits > 0;
