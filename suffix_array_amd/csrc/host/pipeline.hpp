@@ -189,7 +189,8 @@ __global__ __launch_bounds__(RADIX) void k_os_digit_totals(const uint32_t *__res
 template <typename KeyT, int THREADS, int ITEMS, bool SEQ, int RBITS = RADIX_BITS>
 static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit, int end_bit,
                                const SortScratch &ss, uint32_t *final_vals, hipStream_t st, KeyT **keys_res, uint32_t **vals_res, int *passes,
-                               int *skipped, const Tuning &tn, bool iota, bool may_skip, bool first_counted)
+                               int *skipped, const Tuning &tn, bool iota, bool may_skip, bool first_counted,
+                               const uint8_t *text = nullptr, int64_t text_n = 0)      // != nullptr (32-bit keys only): the FIRST pass reads its keys from the text (k_onesweep<..., TEXT_KEYS>)
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int R = 1 << RBITS;
@@ -250,7 +251,13 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         P.nseg = g.nseg; P.tiles_per_seg = g.tiles_per_seg; P.tiles = g.tiles;
         P.epoch = ++epoch;
         P.flags = (uint32_t)tn.onesweep_flags;
+        P.text = text; P.text_n = text_n;
         HIP_TRY(hipMemsetAsync(zone[z ^ 1], 0, (size_t)OS_ZONE * 4, st));
+        if (!K64 && !SEQ && text && *passes == 0)
+            PROF(KC_ONESWEEP32, count, st,
+                 hipLaunchKernelGGL((k_onesweep<THREADS, ITEMS, KeyT, SEQ, WG_PER_CU, RBITS, !K64 && !SEQ>), dim3(grid), dim3(THREADS), 0, st, (const KeyT *)kin,
+                                    (const uint32_t *)((iota && *passes == 0) ? nullptr : vin), kout, vdst, P));
+        else
         PROF(K64 ? KC_ONESWEEP : KC_ONESWEEP32, count, st,
              hipLaunchKernelGGL((k_onesweep<THREADS, ITEMS, KeyT, SEQ, WG_PER_CU, RBITS>), dim3(grid), dim3(THREADS), 0, st, (const KeyT *)kin,
                                 (const uint32_t *)((iota && *passes == 0) ? nullptr : vin), kout, vdst, P));
@@ -377,16 +384,21 @@ static SortGrid32 sort_grid32(int64_t count, const Sort32Variant &sv)
 static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit,
                         int end_bit, const SortScratch &ss, uint32_t *final_vals, hipStream_t st, SortResult32 *res,
                         const Tuning &tn, bool iota = false, bool first_counted = false,
-                        int rbits = RADIX_BITS)       // 9: nine-bit digits (single-pass engine only, first digit counted by the producer)
+                        int rbits = RADIX_BITS,       // 9: nine-bit digits (single-pass engine only, first digit counted by the producer)
+                        const uint8_t *text = nullptr, int64_t text_n = 0)      // the first pass reads its keys from this text (single-pass engine, default tile, counted)
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
     if (rbits != RADIX_BITS && (rbits != 9 || !onesweep_on(ss, tn) || !first_counted)) return SA_AMD_EINTERNAL;
+    if (text && (!onesweep_on(ss, tn) || !first_counted || tn.onesweep32_shape != 0)) return SA_AMD_EINTERNAL;
     if (onesweep_on(ss, tn)) {
         int skipped = 0;
         if (rbits == 9)
             return sort_pairs_onesweep<uint32_t, 1024, 12, false, 9>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
-                                                                     &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted);
+                                                                     &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted, text, text_n);
+        if (text)
+            return sort_pairs_onesweep<uint32_t, 1024, 12, false, RADIX_BITS>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
+                                                                              &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted, text, text_n);
 #define OS_CALL32(T, I, S) sort_pairs_onesweep<uint32_t, T, I, S>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st, \
                                                                  &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted)
         switch (tn.onesweep32_shape) {
@@ -1124,13 +1136,25 @@ struct DeviceBuild {
             const FirstCounts fc = sort_first_counts(w.ss, tn, n, true);
             const bool counted = n > 1;
             const int rbits = top_bits == 18 ? 9 : RADIX_BITS;
+            // a text of all 256 byte values (code = byte, 8 symbols per key): the top 32 key bits are four text bytes -- the first
+            // global pass reads them from the text (a quarter of the bytes) and no key array is built in front of it
+            const bool text_keys = top_bits != 0 && counted && iota && sigma == 256 && P.bits == 8 && top_shift == 32 && packed_out == nullptr &&
+                                   onesweep_on(w.ss, tn) && tn.onesweep32_shape == 0 && !tn.no_text_keys;
             if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
+            if (text_keys) {
+                int split = 2048 / fc.G;
+                while (split > 1 && fc.chunk_elems / split < 16384) split /= 2;
+                const int64_t sub = ceil_div(fc.chunk_elems, split);
+                PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_text_upsweep32), dim3((unsigned)(fc.G * split)), dim3(SORT_THREADS), 0, st, dT, n, fc.counts,
+                                                              32 - top_bits, (1u << rbits) - 1u, fc.chunk_elems, fc.G, split, sub));
+            } else
             PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
                                                           (uint64_t *)nullptr, vals0, k32a, top_shift, packed_out,
                                                           counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, (1u << rbits) - 1u, top_bits ? 32 - top_bits : 0));
             SortResult32 s32;
             if (top_bits) {
-                rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 32 - top_bits, 32, w.ss, nullptr, st, &s32, tn, iota, counted, rbits);
+                rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 32 - top_bits, 32, w.ss, nullptr, st, &s32, tn, iota, counted, rbits,
+                                  text_keys ? dT : (const uint8_t *)nullptr, n);
                 if (rc) return rc;
                 local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
                 uint32_t *kout = (s32.keys == k32a) ? k32b : k32a;

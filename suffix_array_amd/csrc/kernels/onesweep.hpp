@@ -43,6 +43,70 @@ __device__ __forceinline__ unsigned os_xcc_id()
 
 typedef __attribute__((address_space(1))) unsigned long long os_gu64;
 
+// ---- a text of all 256 byte values: the top 32 key bits of suffix i ARE the bytes T[i .. i + 3], big-endian (symbol code =
+// byte value, 8 bits per symbol), zero past the end.  The first pass of the 32-bit stage reads them from the text -- a
+// quarter of the bytes, and no k_build_keys launch in front (0.45 ms at 256 MiB).  Two aligned words + a byte alignment
+// instead of one unaligned load; the last few positions are read bytewise (no access beyond T + n).
+__device__ __forceinline__ uint32_t text_key32(const uint8_t *__restrict__ T, int64_t n, int64_t i)
+{
+    if (i + 8 <= n) {
+        const uintptr_t a = (uintptr_t)(T + i);
+        const uint32_t *W = (const uint32_t *)(a & ~(uintptr_t)3);
+        const uint32_t lo = W[0], hi = W[1];
+        const uint32_t le = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3u));      // bytes T[i .. i + 3], little-endian
+        return __builtin_bswap32(le);
+    }
+    uint32_t k = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) k = (k << 8) | (i + b < n ? (uint32_t)T[i + b] : 0u);
+    return k;
+}
+
+// counts[d * G + g] += suffixes of chunk g whose key digit (text_key32 >> shift) & dmask is d (the counts of the first pass;
+// zeroed by the host); `split` workgroups share a chunk
+__global__ __launch_bounds__(SORT_THREADS) void k_text_upsweep32(const uint8_t *__restrict__ T, int64_t n, uint32_t *__restrict__ counts,
+                                                                 int shift, uint32_t dmask, int64_t chunk_elems, int G, int split, int64_t sub_elems)
+{
+    __shared__ uint32_t h[SORT_WAVES][512];
+    for (int i = threadIdx.x; i < SORT_WAVES * 512; i += SORT_THREADS) (&h[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t *mine = h[wave_id()];
+    const int g = (int)(blockIdx.x / split), part = (int)(blockIdx.x % split);
+    const int64_t cbegin = (int64_t)g * chunk_elems;
+    int64_t cend = cbegin + chunk_elems;
+    if (cend > n) cend = n;
+    int64_t begin = cbegin + (int64_t)part * sub_elems;
+    int64_t end = begin + sub_elems;
+    if (begin > cend) begin = cend;
+    if (end > cend || part == split - 1) end = cend;
+    // sixteen consecutive positions per thread and step out of six aligned words, while that stays inside the text; the rest one by one
+    int64_t i = begin + (int64_t)threadIdx.x * 16;
+    for (; i + 16 <= end && i + 32 <= n; i += (int64_t)SORT_THREADS * 16) {
+        const uintptr_t a = (uintptr_t)(T + i);
+        const uint32_t *W = (const uint32_t *)(a & ~(uintptr_t)3);
+        const uint32_t sh = (uint32_t)(a & 3u);
+        const uint4 q = *(const uint4 *)W;
+        const uint32_t w4 = W[4], w5 = W[5];
+        const uint32_t v[6] = { __builtin_amdgcn_alignbyte(q.y, q.x, sh), __builtin_amdgcn_alignbyte(q.z, q.y, sh), __builtin_amdgcn_alignbyte(q.w, q.z, sh),
+                                __builtin_amdgcn_alignbyte(w4, q.w, sh), __builtin_amdgcn_alignbyte(w5, w4, sh), 0u };
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t key = __builtin_bswap32(__builtin_amdgcn_alignbyte(v[(j >> 2) + 1], v[j >> 2], (uint32_t)(j & 3)));
+            atomicAdd(&mine[(key >> shift) & dmask], 1u);
+        }
+    }
+    // (what the loop above left: a thread's last, partial or too-close-to-the-end blocks of sixteen)
+    for (; i < end; i += (int64_t)SORT_THREADS * 16)
+        for (int64_t p = i; p < i + 16 && p < end; ++p) atomicAdd(&mine[(text_key32(T, n, p) >> shift) & dmask], 1u);
+    __syncthreads();
+    for (int d = threadIdx.x; d <= (int)dmask; d += SORT_THREADS) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) sum += h[w][d];
+        if (sum) atomicAdd(&counts[(int64_t)d * G + g], sum);
+    }
+}
+
 struct OnesweepPass {
     const uint32_t *hist_cur;       // [256][nseg]: elements of digit d in segment s, in this pass's input order
     uint32_t *hist_next;            // [256][nseg]: the same for the NEXT pass's digit (zeroed by the host), or nullptr
@@ -54,6 +118,8 @@ struct OnesweepPass {
     uint32_t dmask, dmask_next;
     int nseg, tiles_per_seg, tiles;
     uint32_t epoch;                 // pass number + 1
+    const uint8_t *text;            // TEXT_KEYS instances: the keys are read from here (text_key32), keys_in is not looked at
+    int64_t text_n;
     uint32_t flags;                 // bit 0: look at the predecessors' granules before the staging, not after (scheduling A/B, same
                                     // result); bit 7 (diagnostic library only): phase stamps
 };
@@ -62,7 +128,8 @@ struct OnesweepPass {
 // sizes in use); SEQ = true: the values go through the keys' buffer once the keys are out, which leaves room for TWO
 // workgroups per CU -- while one waits (look-back, barriers, the ranking's ALU work) the other one's loads and stores flow.
 // RBITS: digit width (8, or 9 for the two global passes in front of the bucket sort of a text of more than 2^29 suffixes)
-template <int THREADS, int ITEMS, typename KeyT, bool SEQ, int WG_PER_CU, int RBITS = RADIX_BITS>
+// TEXT_KEYS: the first pass of the 32-bit stage over a text of all 256 byte values -- key of element i = text_key32(P.text, i)
+template <int THREADS, int ITEMS, typename KeyT, bool SEQ, int WG_PER_CU, int RBITS = RADIX_BITS, bool TEXT_KEYS = false>
 __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep(
     const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
     OnesweepPass P)
@@ -70,6 +137,7 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
     constexpr int RADIX = 1 << RBITS;              // (shadows sa::RADIX inside this kernel)
     constexpr int RADIX_BITS = RBITS;
     static_assert(RBITS == 8 || !SEQ, "the digits of the sequential shapes travel as bytes");
+    static_assert(!TEXT_KEYS || sizeof(KeyT) == 4, "text keys are the top 32 key bits");
     constexpr int TILE = THREADS * ITEMS;
     constexpr int NWAVES = THREADS / WAVE;
     constexpr int WAVE_ELEMS = WAVE * ITEMS;
@@ -151,16 +219,38 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
         // tile loop into forty registers that then spill)
         int e0v = e0, tidv = tid;
         asm volatile("" : "+v"(e0v), "+v"(tidv));
+        // element of the tile that item j of this lane holds: wave-striped (lane l, item j -> 64 j + l inside the wave's block: the
+        // rank inside the wave is then a stable one), or -- TEXT_KEYS, the first pass of a sort, where the order among equal
+        // digits is free -- ITEMS consecutive positions per lane, whose overlapping 4-byte keys come out of ONE 20-byte read
+        int ebv = w * WAVE_ELEMS + l * ITEMS;
+        asm volatile("" : "+v"(ebv));
+#define OS_ELEM(j) (TEXT_KEYS ? ebv + (j) : e0v + (j) * WAVE)
         const int64_t base = (int64_t)t * TILE;
         const int valid = (P.n - base) >= TILE ? TILE : (int)(P.n - base);
         const bool full = valid == TILE;
         KeyT key[ITEMS];
         uint32_t val[ITEMS], pp[ITEMS / 2];    // pp: tile positions (< 65536), two to a register
 #define OS_POS(j) ((pp[(j) >> 1] >> (16 * ((j) & 1))) & 0xffffu)
+        if (TEXT_KEYS && base + TILE + 24 <= P.text_n) {          // (uniform) every read below stays inside the text
+            static_assert(!TEXT_KEYS || (ITEMS <= 13 && ITEMS % 4 == 0), "ITEMS + 3 bytes out of five aligned words; a lane's first position is word-aligned relative to the tile");
+            const uintptr_t a = (uintptr_t)(P.text + base + ebv);
+            const uint32_t *W = (const uint32_t *)(a & ~(uintptr_t)3);
+            const uint32_t sh = (uint32_t)(a & 3u);                // (the same for every lane: tile, wave block and lane stride are multiples of 4)
+            const uint4 q = *(const uint4 *)W;                     // (global_load_dwordx4 needs dword alignment only)
+            const uint32_t w4 = W[4];
+            const uint32_t v0 = __builtin_amdgcn_alignbyte(q.y, q.x, sh), v1 = __builtin_amdgcn_alignbyte(q.z, q.y, sh),
+                           v2 = __builtin_amdgcn_alignbyte(q.w, q.z, sh), v3 = __builtin_amdgcn_alignbyte(w4, q.w, sh);
+            const uint32_t v[5] = { v0, v1, v2, v3, 0u };
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                key[j] = (KeyT)__builtin_bswap32(__builtin_amdgcn_alignbyte(v[(j >> 2) + 1], v[j >> 2], (uint32_t)(j & 3)));
+        } else {
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const int e = e0v + j * WAVE;
-            key[j] = (full || e < valid) ? keys_in[base + e] : (KeyT)~(KeyT)0;
+            const int e = OS_ELEM(j);
+            if (TEXT_KEYS) key[j] = (full || e < valid) ? (KeyT)text_key32(P.text, P.text_n, base + e) : (KeyT)~(KeyT)0;
+            else key[j] = (full || e < valid) ? keys_in[base + e] : (KeyT)~(KeyT)0;
+        }
         }
         if (seg != cur_seg) {                  // (uniform) where do this segment's digit runs start?
             uint32_t tot = 0, below = 0;
@@ -182,7 +272,7 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
         // ---- rank inside the wave: lanes with my digit below me (8 ballots + mbcnt), wave totals in LDS ----
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const bool ok = full || (e0v + j * WAVE) < valid;
+            const bool ok = full || OS_ELEM(j) < valid;
             const uint32_t d = digit_of(key[j], P.shift, P.dmask);
             const uint64_t okm = __ballot(ok);
             uint32_t xlo = ~(uint32_t)okm, xhi = ~(uint32_t)(okm >> 32);
@@ -207,12 +297,12 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
         if (vals_in) {
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
-                const int e = e0v + j * WAVE;
+                const int e = OS_ELEM(j);
                 val[j] = (full || e < valid) ? vals_in[base + e] : 0u;
             }
         } else {                               // no values array: the value is the index itself
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) val[j] = (uint32_t)(base + e0v + j * WAVE);
+            for (int j = 0; j < ITEMS; ++j) val[j] = (uint32_t)(base + OS_ELEM(j));
         }
         };
         if (!SEQ) load_vals();
@@ -257,12 +347,12 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
             const uint32_t d = digit_of(key[j], P.shift, P.dmask);
             const uint32_t ps = OS_POS(j) + digit_base[d] + my_hist[d];
             if ((j & 1) == 0) pp[j >> 1] = (pp[j >> 1] & 0xffff0000u) | ps; else pp[j >> 1] = (pp[j >> 1] & 0xffffu) | (ps << 16);
-            if (full || (e0v + j * WAVE) < valid) lds_k[ps] = key[j];
+            if (full || OS_ELEM(j) < valid) lds_k[ps] = key[j];
         }
         if (!SEQ) {
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j)
-                if (full || (e0v + j * WAVE) < valid) lds_v[OS_POS(j)] = val[j];
+                if (full || OS_ELEM(j) < valid) lds_v[OS_POS(j)] = val[j];
         } else load_vals();                    // (the keys' registers are free: the values travel while the keys go out)
         if (walk && late_look) {
 #pragma unroll
@@ -356,7 +446,7 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
             lds_barrier();                     // every key has been read
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j)
-                if (full || (e0v + j * WAVE) < valid) lds_v[OS_POS(j)] = val[j];
+                if (full || OS_ELEM(j) < valid) lds_v[OS_POS(j)] = val[j];
             lds_barrier();
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
@@ -369,6 +459,7 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
         }
         stamp(7);      // values through the stage (SEQ)
 #undef OS_POS
+#undef OS_ELEM
         if (tid == 0) {                        // the ticket asked for at the top of this tile
             if (pend_s >= 0 && pend_k < seg_tiles(pend_s)) { next_t = pend_s * P.tiles_per_seg + pend_k; next_seg = pend_s; }
             else { if (pend_s >= 0) ++cand; next_t = take_ticket(&next_seg); }

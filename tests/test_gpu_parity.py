@@ -574,6 +574,8 @@ def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n,
     assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_BUCKET_FINISH", "1")    # the round on the low key bits as a pass of its own (k_finish_sorted)
     assert np.array_equal(build(text), exp)
+    monkeypatch.setenv("SA_AMD_NO_TEXT_KEYS", "1")        # (all 256 byte values: the first global pass would read its keys from the text)
+    assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")         # the global passes by the three-kernel engine
     assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_FUSED_FINISH", "1")     # ties on the top 32 bits through the general path
@@ -762,7 +764,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
@@ -861,7 +863,10 @@ def test_device_entry_point_with_unaligned_text(oracle, monkeypatch):
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     L = sa.lib()
     monkeypatch.setenv("SA_AMD_GRAM_MIN_N", "1")
-    texts = [corpus.english(150_001, 3), corpus.dna(90_000, 4), corpus.uniform(70_003, 5), np.full(33_000, 9, dtype=np.uint8)]
+    monkeypatch.setenv("SA_AMD_FORCE_TOP32", "1")          # with all 256 byte values in the text the first pass of the bucket
+    monkeypatch.setenv("SA_AMD_BUCKET_MIN_N", "1")         # route reads its keys from the text itself: two aligned words per key
+    texts = [corpus.english(150_001, 3), corpus.dna(90_000, 4), corpus.uniform(70_003, 5), np.full(33_000, 9, dtype=np.uint8),
+             corpus.uniform(300_007, 6)]
     for t in texts:
         n = int(t.size)
         exp = oracle.sais(t)
