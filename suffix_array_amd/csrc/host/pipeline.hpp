@@ -190,7 +190,8 @@ template <typename KeyT, int THREADS, int ITEMS, bool SEQ, int RBITS = RADIX_BIT
 static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit, int end_bit,
                                const SortScratch &ss, uint32_t *final_vals, hipStream_t st, KeyT **keys_res, uint32_t **vals_res, int *passes,
                                int *skipped, const Tuning &tn, bool iota, bool may_skip, bool first_counted,
-                               const uint8_t *text = nullptr, int64_t text_n = 0)      // != nullptr (32-bit keys only): the FIRST pass reads its keys from the text (k_onesweep<..., TEXT_KEYS>)
+                               const uint8_t *text = nullptr, int64_t text_n = 0,      // != nullptr (32-bit keys only): the FIRST pass reads its keys from the text (k_onesweep<..., TEXT_KEYS>)
+                               int text_bits = 8)                                      //   8: the text itself (all 256 byte values), 2: the bit-packed text of a four-symbol alphabet
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int R = 1 << RBITS;
@@ -251,7 +252,7 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         P.nseg = g.nseg; P.tiles_per_seg = g.tiles_per_seg; P.tiles = g.tiles;
         P.epoch = ++epoch;
         P.flags = (uint32_t)tn.onesweep_flags;
-        P.text = text; P.text_n = text_n;
+        P.text = text; P.text_n = text_n; P.text_bits = text_bits;
         HIP_TRY(hipMemsetAsync(zone[z ^ 1], 0, (size_t)OS_ZONE * 4, st));
         if (!K64 && !SEQ && text && *passes == 0)
             PROF(KC_ONESWEEP32, count, st,
@@ -385,7 +386,7 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
                         int end_bit, const SortScratch &ss, uint32_t *final_vals, hipStream_t st, SortResult32 *res,
                         const Tuning &tn, bool iota = false, bool first_counted = false,
                         int rbits = RADIX_BITS,       // 9: nine-bit digits (single-pass engine only, first digit counted by the producer)
-                        const uint8_t *text = nullptr, int64_t text_n = 0)      // the first pass reads its keys from this text (single-pass engine, default tile, counted)
+                        const uint8_t *text = nullptr, int64_t text_n = 0, int text_bits = 8)      // the first pass reads its keys from this text (single-pass engine, default tile, counted)
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
@@ -395,10 +396,10 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
         int skipped = 0;
         if (rbits == 9)
             return sort_pairs_onesweep<uint32_t, 1024, 12, false, 9>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
-                                                                     &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted, text, text_n);
+                                                                     &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted, text, text_n, text_bits);
         if (text)
             return sort_pairs_onesweep<uint32_t, 1024, 12, false, RADIX_BITS>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
-                                                                              &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted, text, text_n);
+                                                                              &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted, text, text_n, text_bits);
 #define OS_CALL32(T, I, S) sort_pairs_onesweep<uint32_t, T, I, S>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st, \
                                                                  &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted)
         switch (tn.onesweep32_shape) {
@@ -1138,13 +1139,23 @@ struct DeviceBuild {
             const int rbits = top_bits == 18 ? 9 : RADIX_BITS;
             // a text of all 256 byte values (code = byte, 8 symbols per key): the top 32 key bits are four text bytes -- the first
             // global pass reads them from the text (a quarter of the bytes) and no key array is built in front of it
-            const bool text_keys = top_bits != 0 && counted && iota && sigma == 256 && P.bits == 8 && top_shift == 32 && packed_out == nullptr &&
-                                   onesweep_on(w.ss, tn) && tn.onesweep32_shape == 0 && !tn.no_text_keys;
+            const bool text_route = top_bits != 0 && counted && iota && top_shift == 32 && onesweep_on(w.ss, tn) && tn.onesweep32_shape == 0 && !tn.no_text_keys;
+            const bool text_keys = text_route && sigma == 256 && P.bits == 8 && packed_out == nullptr;
+            // ... and with four symbols (DNA) the bit-packed text is the stream of keys: it is packed first (n / 4 bytes instead of a
+            // key array of 4n), and counted and read by the first pass as it stands
+            const bool packed_keys = text_route && sigma == 4 && P.bits == 2 && packed_out != nullptr;
             if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
-            if (text_keys) {
+            if (text_keys || packed_keys) {
                 int split = 2048 / fc.G;
                 while (split > 1 && fc.chunk_elems / split < 16384) split /= 2;
-                const int64_t sub = ceil_div(fc.chunk_elems, split);
+                const int64_t sub = (ceil_div(fc.chunk_elems, split) + 15) & ~(int64_t)15;
+                if (packed_keys) {
+                    int64_t pblocks = ceil_div(ceil_div(n, 16), 256);
+                    if (pblocks > 16384) pblocks = 16384;
+                    PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_pack_text2), dim3((unsigned)pblocks), dim3(256), 0, st, dT, n, P, packed_out));
+                    PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_packed2_upsweep32), dim3((unsigned)(fc.G * split)), dim3(SORT_THREADS), 0, st, (const uint8_t *)packed_out, n,
+                                                                  fc.counts, 32 - top_bits, (1u << rbits) - 1u, fc.chunk_elems, fc.G, split, sub));
+                } else
                 PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_text_upsweep32), dim3((unsigned)(fc.G * split)), dim3(SORT_THREADS), 0, st, dT, n, fc.counts,
                                                               32 - top_bits, (1u << rbits) - 1u, fc.chunk_elems, fc.G, split, sub));
             } else
@@ -1154,7 +1165,7 @@ struct DeviceBuild {
             SortResult32 s32;
             if (top_bits) {
                 rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 32 - top_bits, 32, w.ss, nullptr, st, &s32, tn, iota, counted, rbits,
-                                  text_keys ? dT : (const uint8_t *)nullptr, n);
+                                  text_keys ? dT : (packed_keys ? (const uint8_t *)packed_out : (const uint8_t *)nullptr), n, packed_keys ? 2 : 8);
                 if (rc) return rc;
                 local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
                 uint32_t *kout = (s32.keys == k32a) ? k32b : k32a;
@@ -1174,8 +1185,10 @@ struct DeviceBuild {
                     F.T = dT; F.n = n; F.cap = tn.group_cap; F.surv_bits = w.surv_bits; F.surv_head = w.isa; F.tile_cnt = w.tcnt; F.counters = w.total;
                     K.mode = KS_LOWKEY; K.kb = top_shift;
                 }
+                KeyParams Pf = P;
+                Pf.packed = packed_out;             // (written by now: the fused round's text look-ups take the bit-packed text, a quarter of the lines)
                 rc = bucket_sort32(s32.keys, s32.vals, kout, SA, n, top_bits, w.bk_start, w.os_err + 2, st, tn, &done, &largest,
-                                   fuse ? &F : nullptr, &P, &K, &fused);
+                                   fuse ? &F : nullptr, &Pf, &K, &fused);
                 if (rc) return rc;
                 bucket_finished = done && fused;
                 if (trace) fprintf(stderr, "suffix_array_amd: 32-bit first stage: %d global passes over the top %d key bits, largest bucket %u -> %s\n", s32.passes, top_bits, largest,

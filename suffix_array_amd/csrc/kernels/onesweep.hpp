@@ -107,6 +107,74 @@ __global__ __launch_bounds__(SORT_THREADS) void k_text_upsweep32(const uint8_t *
     }
 }
 
+// ---- the same for an alphabet of four symbols (DNA): the bit-packed text (2 bits per symbol, big-endian bit order, zero
+// codes behind the end; k_pack_text2) IS the stream of keys -- the top 32 key bits of suffix i are its bits [2i, 2i + 32).
+// k_pack_text2: 16 symbols per thread -> one 32-bit word (stored big-endian), instead of k_build_keys' key array (4 B per
+// suffix written and read back: 1.7 ms at 1 GiB)
+__global__ __launch_bounds__(256) void k_pack_text2(const uint8_t *__restrict__ T, int64_t n, KeyParams P, uint8_t *__restrict__ packed)
+{
+    __shared__ uint8_t lcode[256];
+    lcode[threadIdx.x] = P.code[threadIdx.x];
+    __syncthreads();
+    const int64_t words = (n + 15) / 16;
+    for (int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x; wi < words; wi += (int64_t)gridDim.x * 256) {
+        const int64_t p = wi * 16;
+        uint32_t v = 0;
+        if (p + 16 <= n && (((uintptr_t)(T + p)) & 15) == 0) {
+            const uint4 q = *(const uint4 *)(T + p);
+            const uint32_t w4[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v = (v << 2) | (uint32_t)lcode[(w4[j >> 2] >> (8 * (j & 3))) & 255u];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v = (v << 2) | (p + j < n ? (uint32_t)lcode[T[p + j]] : 0u);
+        }
+        ((uint32_t *)packed)[wi] = __builtin_bswap32(v);         // (the packed text is a byte stream: first symbol in the top bits of byte 0)
+    }
+}
+
+// 64 stream bits from byte address B on (big-endian), out of three aligned words
+__device__ __forceinline__ uint64_t packed_window64(const uint8_t *B)
+{
+    const uintptr_t a = (uintptr_t)B;
+    const uint32_t *W = (const uint32_t *)(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3u);
+    const uint32_t w0 = W[0], w1 = W[1], w2 = W[2];
+    const uint32_t v0 = __builtin_amdgcn_alignbyte(w1, w0, sh), v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    return ((uint64_t)__builtin_bswap32(v0) << 32) | (uint64_t)__builtin_bswap32(v1);
+}
+
+// the counts of the first pass's digit, from the packed text (counts[d * G + g], zeroed by the host), sixteen suffixes per thread and step
+__global__ __launch_bounds__(SORT_THREADS) void k_packed2_upsweep32(const uint8_t *__restrict__ packed, int64_t n, uint32_t *__restrict__ counts,
+                                                                    int shift, uint32_t dmask, int64_t chunk_elems, int G, int split, int64_t sub_elems)
+{
+    __shared__ uint32_t h[SORT_WAVES][512];
+    for (int i = threadIdx.x; i < SORT_WAVES * 512; i += SORT_THREADS) (&h[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t *mine = h[wave_id()];
+    const int g = (int)(blockIdx.x / split), part = (int)(blockIdx.x % split);
+    const int64_t cbegin = (int64_t)g * chunk_elems;                  // (a multiple of the tile size: of 4)
+    int64_t cend = cbegin + chunk_elems;
+    if (cend > n) cend = n;
+    int64_t begin = cbegin + (int64_t)part * sub_elems;               // (sub_elems is a multiple of 16)
+    int64_t end = begin + sub_elems;
+    if (begin > cend) begin = cend;
+    if (end > cend || part == split - 1) end = cend;
+    for (int64_t i = begin + (int64_t)threadIdx.x * 16; i < end; i += (int64_t)SORT_THREADS * 16) {
+        const uint64_t win = packed_window64(packed + (i >> 2));      // (the 64 zero bytes behind the packed text cover the last reads)
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (i + j < end) atomicAdd(&mine[((uint32_t)(win >> (32 - 2 * j)) >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d <= (int)dmask; d += SORT_THREADS) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) sum += h[w][d];
+        if (sum) atomicAdd(&counts[(int64_t)d * G + g], sum);
+    }
+}
+
 struct OnesweepPass {
     const uint32_t *hist_cur;       // [256][nseg]: elements of digit d in segment s, in this pass's input order
     uint32_t *hist_next;            // [256][nseg]: the same for the NEXT pass's digit (zeroed by the host), or nullptr
@@ -118,8 +186,9 @@ struct OnesweepPass {
     uint32_t dmask, dmask_next;
     int nseg, tiles_per_seg, tiles;
     uint32_t epoch;                 // pass number + 1
-    const uint8_t *text;            // TEXT_KEYS instances: the keys are read from here (text_key32), keys_in is not looked at
-    int64_t text_n;
+    const uint8_t *text;            // TEXT_KEYS instances: the keys are read from here (text_key32), keys_in is not looked at;
+    int64_t text_n;                 //   text_bits = 2: `text` is the bit-packed text of a four-symbol alphabet (packed_window64)
+    int text_bits;
     uint32_t flags;                 // bit 0: look at the predecessors' granules before the staging, not after (scheduling A/B, same
                                     // result); bit 7 (diagnostic library only): phase stamps
 };
@@ -231,8 +300,14 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
         KeyT key[ITEMS];
         uint32_t val[ITEMS], pp[ITEMS / 2];    // pp: tile positions (< 65536), two to a register
 #define OS_POS(j) ((pp[(j) >> 1] >> (16 * ((j) & 1))) & 0xffffu)
-        if (TEXT_KEYS && base + TILE + 24 <= P.text_n) {          // (uniform) every read below stays inside the text
-            static_assert(!TEXT_KEYS || (ITEMS <= 13 && ITEMS % 4 == 0), "ITEMS + 3 bytes out of five aligned words; a lane's first position is word-aligned relative to the tile");
+        if (TEXT_KEYS && P.text_bits == 2) {
+            // four symbols: 12 consecutive suffixes = 24 + 30 stream bits from byte (base + first position) / 4 on (the zero bytes behind
+            // the packed text and the slab's slack cover the reads of the last tile; positions behind the text are masked below)
+            const uint64_t win = packed_window64(P.text + ((base + ebv) >> 2));
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) key[j] = (full || ebv + j < valid) ? (KeyT)(uint32_t)(win >> (32 - 2 * j)) : (KeyT)~(KeyT)0;
+        } else if (TEXT_KEYS && base + TILE + 24 <= P.text_n) {   // (uniform) every read below stays inside the text
+            static_assert(!TEXT_KEYS || (ITEMS <= 13 && ITEMS % 4 == 0), "ITEMS + 3 bytes out of five aligned words (2 ITEMS + 30 bits out of 64 for the packed text); a lane's first position is word-aligned relative to the tile");
             const uintptr_t a = (uintptr_t)(P.text + base + ebv);
             const uint32_t *W = (const uint32_t *)(a & ~(uintptr_t)3);
             const uint32_t sh = (uint32_t)(a & 3u);                // (the same for every lane: tile, wave block and lane stride are multiples of 4)
