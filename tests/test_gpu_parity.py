@@ -542,7 +542,7 @@ def test_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed):
     assert np.array_equal(build(text), exp)
 
 
-@pytest.mark.parametrize("gen,n,seed", [("uniform", 500_000, 2), ("uniform", 3_000_001, 3), ("dna", 1 << 20, 4), ("english", 300_000, 3),
+@pytest.mark.parametrize("gen,n,seed", [("uniform", 500_000, 2), ("uniform", 3_000_001, 3), ("dna", 1 << 20, 4), ("dna", 1_000_003, 6), ("english", 300_000, 3),
                                         ("dna_repeats", 400_000, 5), ("periodic", 100_001, 1), ("sigma2", 250_000, 7), ("sigma200", 900_000, 9)])
 @pytest.mark.parametrize("shape,bits", [("-1", "0"), ("3", "16"), ("4", "0"), ("-1", "18"), ("2", "18")])
 def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed, shape, bits):
