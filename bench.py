@@ -561,6 +561,7 @@ def run(args, backend, rank, world, dist=None, share=False):
                      "algorithmic_bytes_per_launch": dom.get("algorithmic_bytes_per_launch"),
                      "algorithmic_bytes_per_element": dom.get("algorithmic_bytes_per_element"),
                      "avg_launch_ms": dom.get("avg_launch_ms"), "launches_per_step": dom.get("launches_per_step"),
+                     "traffic_over_algorithmic": dom.get("traffic_over_algorithmic"), "traffic_frac": dom.get("traffic_frac"),
                      "chosen": "the class with the most device time among the classes timed inside the timed region "
                                f"(every class with >= {EVENT_SHARE:.0%} of a profiled build's device time)",
                      "kernels": reported,
