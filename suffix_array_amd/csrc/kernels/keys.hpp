@@ -401,7 +401,7 @@ __device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ T, cons
 
 // ---- entropy probe + two-stage initial sort ---------------------------------------------------
 // When the top 32 bits of the packed key already separate almost all suffixes (random bytes, DNA),
-// the initial sort only needs those 4 digits; the few ties are finished by a refinement round on the
+// the initial sort only needs those 32 bits (two global passes + kernels/bucket_sort.hpp, or four global passes); the few ties are finished by a refinement round on the
 // low key bits (k_group_sort).  Whether that holds is measured, not assumed: the keys of
 // SAMPLE pseudo-random suffixes are sorted and their duplicates counted (a word-structured text looks
 // harmless under an iid model but is not).
