@@ -1040,8 +1040,9 @@ struct DeviceBuild {
                 const int tb = choose_bucket_bits();
                 if (tb) {
                     HIP_TRY(hipMemsetAsync(w.keysC, 0, ((size_t)1 << tb) * 4, st));
-                    PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_bucket_hist), dim3((unsigned)ceil_div(S, BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS), 0, st,
-                                                            (const uint64_t *)w.keysA, S, tb, (uint32_t *)w.keysC));
+                    // (a quarter of the samples is enough to tell a bucket with a tenth of the text from a flat one, and a quarter of the atomics)
+                    PROF(KC_MISC, S / 4, st, hipLaunchKernelGGL((k_sample_bucket_hist), dim3((unsigned)ceil_div(S / 4, BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS), 0, st,
+                                                            (const uint64_t *)w.keysA, S / 4, tb, (uint32_t *)w.keysC));
                     PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_u32_max), dim3((unsigned)(((size_t)1 << tb) / BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS), 0, st,
                                                             (const uint32_t *)w.keysC, 1u << tb, w.total + 1));
                 }
@@ -1050,8 +1051,8 @@ struct DeviceBuild {
                     uint32_t two[2] = { 0, 0 };
                     const int rcw = read_words(two, w.total, 8, st); if (rcw) return rcw;
                     dups = two[0];
-                    // (a flat text of 2^28 bytes: 16 samples per bucket on average, the fullest holds about 36 -> 9216 estimated, 4400 true)
-                    const double est = (double)two[1] * (double)n / (double)S;
+                    // (a flat text of 2^28 bytes: 4 samples per bucket on average, the fullest holds about 14 -> 14 336 estimated, 4400 true)
+                    const double est = (double)two[1] * (double)n / (double)(S / 4);
                     if (tb && est > 3.0 * (double)bucket_cap_max()) {
                         bucket_top_bits = 0;
                         if (trace) fprintf(stderr, "suffix_array_amd: bucket sort of the 32-bit first stage: largest bucket estimated at %.0f suffixes -> four global passes\n", est);
