@@ -1026,8 +1026,10 @@ struct DeviceBuild {
         top_shift = 0;
         if (text_ok && local_ok && key_bits > 32 && !tn.no_top32) {
             bool use = tn.force_top32;
-            if (!use && n >= ((int64_t)1 << 24)) {
-                const int64_t S = (int64_t)1 << 20;
+            if (!use && n >= tn.top32_probe_min_n) {
+                // 2^20 samples, fewer for texts below 8 Mi suffixes (a power of two: the duplicate count hashes into 4 S slots)
+                int64_t S = (int64_t)1 << 20;
+                while (S > 1024 && S * 8 > n) S >>= 1;
                 PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_sample_keys), dim3((unsigned)ceil_div(S, GK_THREADS)), dim3(GK_THREADS), 0, st, dT, P, n, S,
                                                         key_bits - 32, w.keysA));
                 // duplicates counted in a hash table (4 entries per sample, in the other key buffer) instead of sorting the sample

@@ -67,6 +67,7 @@ struct Tuning {
     int top32_partners_x100 = 50;    // SA_AMD_TOP32_PARTNERS_X100: the 32-bit first stage is taken when a suffix shares its top 32 key bits with fewer than this / 100 others (sample estimate)
     int top32_collisions_x100 = 400; // SA_AMD_TOP32_COLLISIONS_X100: ... or when fewer than this / 100 share only the top 32 bits (chance collisions) and fewer than
                                      //   top32_partners_x100 / 100 share all key bits (repeats)
+    int64_t top32_probe_min_n = (int64_t)1 << 21;   // SA_AMD_TOP32_PROBE_MIN_N: smallest text the entropy probe looks at (below: full keys; 16 Mi before the mid-size timings of round 3)
     int small_max = 8192;            // SA_AMD_SMALL_MAX: texts of up to this many bytes are built by ONE launch of one workgroup (kernels/small.hpp), 0..8192
     bool no_onesweep = false;        // SA_AMD_NO_ONESWEEP: the three-kernel radix pass (histogram, spine, chunk-owned scatter) instead of the single-pass one
     int onesweep_flags = 0;          // SA_AMD_ONESWEEP_FLAGS: scheduling switches of the single-pass scatter (kernels/onesweep.hpp, OnesweepPass::flags), same result
@@ -123,6 +124,7 @@ struct Tuning {
         t.gram_g = (int)env_int("SA_AMD_GRAM_G", 0, 0, 8);
         t.top32_partners_x100 = (int)env_int("SA_AMD_TOP32_PARTNERS_X100", 50, 0, 1000000);
         t.top32_collisions_x100 = (int)env_int("SA_AMD_TOP32_COLLISIONS_X100", 400, 0, 1000000);
+        t.top32_probe_min_n = env_int("SA_AMD_TOP32_PROBE_MIN_N", (int64_t)1 << 21, 8192, (int64_t)1 << 40);
         t.small_max = (int)env_int("SA_AMD_SMALL_MAX", 8192, 0, 8192);
         t.no_onesweep = env_flag("SA_AMD_NO_ONESWEEP");
         t.onesweep_flags = (int)env_int("SA_AMD_ONESWEEP_FLAGS", 0, 0, 255);
