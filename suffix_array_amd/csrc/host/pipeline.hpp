@@ -550,7 +550,7 @@ static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out, i
     }
     *sigma_out = sigma;
     P->packed = nullptr;
-    P->gram = 0; P->gram_m = 0; P->gram_top = 0; P->gram_D = 0; P->gram_table = nullptr;
+    P->gram = 0; P->gram_m = 0; P->gram_tail = 0; P->gram_top = 0; P->gram_D = 0; P->gram_table = nullptr;
     const uint64_t se = sigma > 2 ? (uint64_t)sigma : 2u;      // effective radix (a unary text still needs one bit)
     P->sigma = se;
     // kb_max < 64 (A/B): fewer key bits = fewer radix passes, more left to the rounds
@@ -927,16 +927,21 @@ static int choose_gram_keys(const uint8_t *dT, int64_t n, KeyParams *Pp, int *ke
     int m = 0;
     unsigned __int128 pw = 1;
     while (D >= 2 && (m + 1) * g <= 64 && pw * D <= ((unsigned __int128)1 << 64)) { pw *= D; ++m; }
+    // the bits a whole further gram does not fit into take plain symbols (base-sigma digits behind the gram ranks): C3's
+    // 3 four-grams leave 9.7 of the 64 bits idle, one symbol of 5.8 bits makes the key 13 symbols deep for one more pass
+    int tail = 0;
+    while (m > 0 && tail < tn.gram_tail_max && m * g + tail + 1 <= 64 && pw * se <= ((unsigned __int128)1 << 64)) { pw *= se; ++tail; }
     const int gram_bits = m > 0 ? bit_length((uint64_t)(pw - 1)) : 0;
     const int plain_passes = (int)ceil_div(*key_bits, RADIX_BITS), gram_passes = (int)ceil_div(gram_bits, RADIX_BITS);
-    const bool better = m > 0 && (m * g > P.k || (m * g == P.k && gram_passes < plain_passes));
-    if (trace) fprintf(stderr, "suffix_array_amd: gram keys: %u of %llu %d-grams occur -> %d symbols in %d bits (plain: %d in %d) -> %s\n",
-                       D, (unsigned long long)S, g, m * g, gram_bits, P.k, *key_bits, better ? "gram keys" : "plain keys");
+    const int syms = m * g + tail;
+    const bool better = m > 0 && (syms > P.k || (syms == P.k && gram_passes < plain_passes));
+    if (trace) fprintf(stderr, "suffix_array_amd: gram keys: %u of %llu %d-grams occur -> %d symbols (%d grams + %d plain) in %d bits (plain: %d in %d) -> %s\n",
+                       D, (unsigned long long)S, g, syms, m, tail, gram_bits, P.k, *key_bits, better ? "gram keys" : "plain keys");
     if (!better) return SA_AMD_OK;
     PROF(KC_MISC, (int64_t)S, st, hipLaunchKernelGGL((k_gram_table), dim3((unsigned)gtiles), dim3(GT_THREADS), 0, st,
                                             (const uint8_t *)w.gram_flags, (int64_t)S, (const uint32_t *)w.tcnt, w.gram_table));
-    P.gram = g; P.gram_m = m; P.gram_top = (uint32_t)top; P.gram_D = D; P.gram_table = w.gram_table;
-    P.bits = 0; P.k = m * g; P.mask = ~0ull;
+    P.gram = g; P.gram_m = m; P.gram_tail = tail; P.gram_top = (uint32_t)top; P.gram_D = D; P.gram_table = w.gram_table;
+    P.bits = 0; P.k = syms; P.mask = ~0ull;
     *key_bits = gram_bits;
     return SA_AMD_OK;
 }

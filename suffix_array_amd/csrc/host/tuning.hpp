@@ -64,6 +64,7 @@ struct Tuning {
     bool no_gram_keys = false;       // SA_AMD_NO_GRAM_KEYS: never key the initial sort by ranks of g-grams
     int64_t gram_min_n = (int64_t)1 << 22;   // SA_AMD_GRAM_MIN_N: smallest text whose g-grams are looked at (measured: -4 % at 4 MiB, +5 % at 1 MiB)
     int gram_g = 0;                  // SA_AMD_GRAM_G: gram length (0 = the longest whose table fits, else 2..8, still subject to the fit)
+    int gram_tail_max = 8;           // SA_AMD_GRAM_TAIL: most plain symbols behind the gram ranks of a gram key (as many as the 64 bits hold, 0..8; 0 = none)
     int top32_partners_x100 = 50;    // SA_AMD_TOP32_PARTNERS_X100: the 32-bit first stage is taken when a suffix shares its top 32 key bits with fewer than this / 100 others (sample estimate)
     int top32_collisions_x100 = 400; // SA_AMD_TOP32_COLLISIONS_X100: ... or when fewer than this / 100 share only the top 32 bits (chance collisions) and fewer than
                                      //   top32_partners_x100 / 100 share all key bits (repeats)
@@ -122,6 +123,7 @@ struct Tuning {
         t.no_gram_keys = env_flag("SA_AMD_NO_GRAM_KEYS");
         t.gram_min_n = env_int("SA_AMD_GRAM_MIN_N", (int64_t)1 << 22, 1, (int64_t)1 << 40);
         t.gram_g = (int)env_int("SA_AMD_GRAM_G", 0, 0, 8);
+        t.gram_tail_max = (int)env_int("SA_AMD_GRAM_TAIL", 8, 0, 8);
         t.top32_partners_x100 = (int)env_int("SA_AMD_TOP32_PARTNERS_X100", 50, 0, 1000000);
         t.top32_collisions_x100 = (int)env_int("SA_AMD_TOP32_COLLISIONS_X100", 400, 0, 1000000);
         t.top32_probe_min_n = env_int("SA_AMD_TOP32_PROBE_MIN_N", (int64_t)1 << 21, 8192, (int64_t)1 << 40);

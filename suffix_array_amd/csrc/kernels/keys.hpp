@@ -72,7 +72,10 @@ struct KeyParams {
     // number]; D = how many occur).  Order-preserving like the base-sigma form, but a word-structured text uses a small
     // part of sigma^g: English-like sigma = 57 has 2.5e5 of 1.06e7 four-grams, so three of them (12 symbols) fit in 54
     // bits -- two symbols more than 57^10 < 2^64 allows, in one radix pass less.
-    int32_t gram, gram_m;
+    // gram_tail > 0: behind the gram_m grams the key carries gram_tail further symbols as plain base-sigma digits (the bits a
+    // whole further gram does not fit into: C3, 3 four-grams in 54.3 bits + 1 symbol of 5.8 = 13 symbols in 61 bits); then
+    // k = gram * gram_m + gram_tail.
+    int32_t gram, gram_m, gram_tail;
     uint32_t gram_top;       // sigma^(gram - 1)
     uint64_t gram_D;
     const uint4 *gram_table; // one 16-byte record per 64 gram indices: {bitmap of the grams that occur (2 words), how many occur below, 0}
@@ -139,10 +142,12 @@ __global__ __launch_bounds__(KB_THREADS) void k_build_keys(const uint8_t *__rest
         }
         __syncthreads();
         const uint64_t D = P.gram_D;
+        const int tail = P.gram_tail;
 #pragma unroll
         for (int r = 0; r < KB_ITEMS; ++r) {
             uint64_t key = 0;
             for (int j = 0; j < m; ++j) key = key * D + (uint64_t)gc[p0 + r + g * j];
+            for (int t = 0; t < tail; ++t) key = key * (uint64_t)sg + (uint64_t)c[p0 + r + g * m + t];
             kk[r] = key;
         }
     } else if (bits > 0) {
@@ -363,6 +368,7 @@ __device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ T, cons
             for (int t = 0; t < P.gram; ++t) idx = idx * sg + (uint32_t)code_at(T, lcode, n, p + (int64_t)P.gram * j + t);
             tk = tk * P.gram_D + (uint64_t)gram_rank(P.gram_table, idx);
         }
+        for (int t = 0; t < P.gram_tail; ++t) tk = tk * P.sigma + code_at(T, lcode, n, p + (int64_t)P.gram * P.gram_m + t);
         return tk;
     }
     if (P.packed) {

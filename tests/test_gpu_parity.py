@@ -355,6 +355,36 @@ def test_gram_keys(oracle, monkeypatch, g):
         assert st["symbols_per_key"] > 10, st          # english-like sigma ~ 56: 10 or 11 symbols in the plain form
 
 
+@pytest.mark.parametrize("tail", ["0", "1", "2", "8"])
+def test_gram_keys_with_plain_tail(oracle, monkeypatch, tail):
+    """the key bits a whole further gram does not fit into carry plain symbols behind the gram ranks (SA_AMD_GRAM_TAIL caps
+    how many; 0 = the pure gram form): same arrays whatever the cap, keys that end past the text, the sparse route's
+    re-computation of a key from the text (text_key), and more symbols per key than the pure form when a tail is allowed"""
+    monkeypatch.setenv("SA_AMD_GRAM_MIN_N", "1")
+    monkeypatch.setenv("SA_AMD_NO_TOP32", "1")
+    monkeypatch.setenv("SA_AMD_GRAM_TAIL", tail)
+    texts = [corpus.english(300_001, 3), corpus.english_corpus(1 << 20, 4, 2000, 0.3), corpus.sigma(200_000, 7, 5, 97),
+             np.frombuffer(b"to be or not to be that is the question", dtype=np.uint8).copy(), corpus.english(37, 1),
+             _planted(400_000, 11, 3), np.resize(np.frombuffer(b"abcab", dtype=np.uint8), 50_001).copy()]
+    exp = [oracle.sais(t) for t in texts]
+    syms = {}
+    for g in ("0", "2", "3"):
+        monkeypatch.setenv("SA_AMD_GRAM_G", g)
+        for env in ({}, {"SA_AMD_FORCE_DENSE": "1"}, {"SA_AMD_NO_REPEAT_PROBE": "1", "SA_AMD_SPARSE_DIV": "4"},
+                    {"SA_AMD_NO_REPEAT_PROBE": "1", "SA_AMD_NO_TEXT_ROUNDS": "1", "SA_AMD_SPARSE_DIV": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for t, e in zip(texts, exp):
+                assert np.array_equal(build(t), e), (g, env, t.size)
+            for k in env:
+                monkeypatch.delenv(k)
+        build(texts[0]); syms[g] = sa.last_stats()["symbols_per_key"]
+    if tail == "0":
+        assert syms["3"] % 3 == 0 and syms["2"] % 2 == 0, syms      # whole grams only
+    else:
+        assert syms["0"] >= 11, syms                                  # english-like sigma ~ 56: 10 or 11 symbols in the plain form
+
+
 def test_giant_groups_are_split_around_their_majority_key(oracle, monkeypatch):
     """whole-list rounds over a few giant groups (runs, periodic texts, a block repeated): the members whose key differs from
     their group's majority are extracted, sorted on their own and merged back (k_split_*), the rest only shifts -- thresholds
