@@ -19,7 +19,7 @@ ENV = ["SA_AMD_FORCE_TOP32", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TEXT_ROUNDS", "S
 NUM = {"SA_AMD_SPARSE_DIV": [1, 4, 64, 10**9], "SA_AMD_GROUP_CAP": [2, 3, 7, 40, 300], "SA_AMD_CHASE": [1, 2, 3, 7, 15],
        "SA_AMD_SCATTER_LEVELS": [1, 2], "SA_AMD_DENSE_REKEY_MIN": [1, 1000], "SA_AMD_MAX_TEXT_ROUNDS": [0, 1, 2, 6],
        "SA_AMD_BINNED_MIN": [1, 5000], "SA_AMD_KEY_BITS": [16, 24, 40, 56], "SA_AMD_RUN_SKIP_MIN": [1, 100000],
-       "SA_AMD_GRAM_MIN_N": [1, 1, 1000], "SA_AMD_GRAM_G": [0, 2, 3, 4, 8], "SA_AMD_CHASE_BIG": [1, 2, 5], "SA_AMD_CHASE_BIG_MIN": [1, 5000],
+       "SA_AMD_GRAM_MIN_N": [1, 1, 1000], "SA_AMD_GRAM_G": [0, 2, 3, 4, 8], "SA_AMD_GRAM_TAIL": [0, 1, 2, 8], "SA_AMD_CHASE_BIG": [1, 2, 5], "SA_AMD_CHASE_BIG_MIN": [1, 5000],
        "SA_AMD_SPLIT_MIN": [1, 1, 3000], "SA_AMD_SPLIT_GROUP_MIN": [1, 2, 50, 1000],
        "SA_AMD_SMALL_MAX": [0, 0, 0, 100, 8192], "SA_AMD_ONESWEEP64_SHAPE": [0, 1, 2], "SA_AMD_ONESWEEP32_SHAPE": [0, 1, 2, 3],
        "SA_AMD_BUCKET_MIN_N": [1, 1, 1, 100000], "SA_AMD_BUCKET_BITS": [0, 16, 18], "SA_AMD_BUCKET_SHAPE": [-1, 0, 1, 2, 3, 4],
