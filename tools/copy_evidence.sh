@@ -8,7 +8,7 @@ for w in c3_english_256m c3_iid_256m c2_uniform_256m c2_uniform_64m c4_dna_1g c4
 [ -s $O/traffic_c2_uniform_256m.json ] && cp $O/traffic_c2_uniform_256m.json profiles/${TAG}_traffic_c2_uniform_256m.json
 [ -s $O/c3_dispatch_sequence.txt ] && cp $O/c3_dispatch_sequence.txt profiles/${TAG}_c3_dispatch_sequence.txt
 for f in $O/round_trace_*.txt; do [ -s $f ] && grep -v "amdgpu.ids" $f > profiles/${TAG}_$(basename $f); done
-for f in adversarial_256m host_path small_latency extras search_throughput onesweep_stamps group_sort_stamps scatter_probe ab_knobs_c3; do
+for f in adversarial_256m host_path small_latency midsize_timing midsize_d2h_probe extras search_throughput onesweep_stamps group_sort_stamps scatter_probe ab_knobs_c3; do
   [ -s $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > profiles/${TAG}_$f.txt
 done
 true

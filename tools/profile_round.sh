@@ -54,6 +54,8 @@ rm -rf $O/prof_seq
 timeout -k 10 900 python tools/adversarial_timing.py 268435456 > $O/adversarial_256m.txt 2>&1
 ( if [ -x tools/bin/pcie_probe ]; then timeout -k 10 300 tools/bin/pcie_probe 1024; fi; timeout -k 10 300 python tools/host_api_timing.py ) > $O/host_path.txt 2>&1
 timeout -k 10 300 python tools/small_latency.py > $O/small_latency.txt 2>&1
+timeout -k 10 300 python tools/midsize_timing.py > $O/midsize_timing.txt 2>&1
+timeout -k 10 300 python tools/midsize_d2h_probe.py > $O/midsize_d2h_probe.txt 2>&1
 timeout -k 10 300 python tools/extras_bench.py > $O/extras.txt 2>&1
 timeout -k 10 300 python tools/search_bench.py > $O/search_throughput.txt 2>&1
 ( timeout -k 10 120 python tools/onesweep_stamps.py 32 26 0; timeout -k 10 120 python tools/onesweep_stamps.py 64 26 0 ) > $O/onesweep_stamps.txt 2>&1
