@@ -985,6 +985,7 @@ struct DeviceBuild {
     int64_t tiles = 0, m = 0, depth = 0;
     uint32_t m32 = 0;
     bool lists_ready = false, finished32 = false, fused64 = false, sparse = false;
+    bool isa_tail_ranks = false;        // the rank set-up of the dense route wrote tail ranks (k_rr_apply FTAIL)
     int s_sym = 0, tkb = 0, key2_bits = 0;
 
 
@@ -1418,8 +1419,9 @@ struct DeviceBuild {
             PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true, uint32_t>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, sorted32,
                                                         (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
         else
-            PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)sr.keys,
-                                                        (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
+            // (also every tile's first group start: the dense route's first ranks are tail ranks, k_rr_apply FTAIL)
+            PROF(KC_RR_COUNT, n, st, hipLaunchKernelGGL((k_rr_count<true, uint64_t, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, (const uint64_t *)sr.keys,
+                                                        (const uint32_t *)nullptr, n, w.tcnt, w.thead, 0, w.tnext, 0));
         PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
         { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
         m = m32;
@@ -1483,13 +1485,28 @@ struct DeviceBuild {
         const bool dense_first = m > 0 && !lists_ready && (force_dense || (!text_ok && m > sparse_limit) || (probe_dense && m > sparse_limit));
         if (m > 0 && dense_first) {
             // ranks (ISA scatter) + compaction of the tied suffixes; SA already holds the sorted order
+            // the first ranks are TAIL ranks (a group's last slot + 1), the form the dense rounds keep (k_rr_apply): the first doubling
+            // round then writes only the ranks that change (SA_AMD_NO_FIRST_TAIL=1: head ranks, everything rewritten in round 1)
+            isa_tail_ranks = !tn.no_first_tail;
+            if (isa_tail_ranks)
+                PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan_next), dim3(1), dim3(SPINE_THREADS), 0, st, w.tnext, tiles, (uint32_t *)nullptr));
             if (binned(n, n, tn)) {
                 uint64_t *pk = (sr.keys == w.keysA) ? w.keysB : w.keysA;
+                if (isa_tail_ranks)
+                    PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 2, uint64_t, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                                sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                                SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total, 0, (const uint32_t *)w.tnext, 0, (uint32_t *)nullptr));
+                else
                 PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                             sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
                                                             SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0, pk, w.U1, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
                 rc = scatter_binned((uint32_t *)pk, w.U1, (uint32_t *)sr.keys, w.G1, n, n, w, st, &local, tn);
                 if (rc) return rc;
+            } else if (isa_tail_ranks) {
+                PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 0, uint64_t, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                            sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
+                                                            SA, w.isa, Ucur, Gcur, Vcur, (uint32_t)n, (uint32_t *)nullptr, 0,
+                                                            (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)w.tnext, 0, (uint32_t *)nullptr));
             } else {
                 PROF(KC_RR_APPLY, n, st, hipLaunchKernelGGL((k_rr_apply<true, false, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                             sr.keys, (const uint32_t *)SA, (const uint32_t *)nullptr, n, w.tcnt, w.thead,
@@ -1580,8 +1597,8 @@ struct DeviceBuild {
         int64_t h = depth;
         bool chase_ok = false;
         int split_rest = 0;                               // rounds the three-way split sits out (refine_list)
-        bool parent_tail = false;                         // the ranks in the ISA are tail ranks (set by the first dense round)
-        int64_t changed_prev = 0;                         // ranks the last dense round wrote
+        bool parent_tail = isa_tail_ranks;                // the ranks in the ISA are tail ranks (set by the first dense round, or by the rank set-up of the dense route)
+        int64_t changed_prev = isa_tail_ranks ? m : 0;    // ranks the last dense round wrote (none yet: expect every rank to change)
         int64_t m_local_off = m;                          // size of the tied list when the local pass was last in use
         int rounds_local_off = 0;
         while (m > 0) {

@@ -51,6 +51,7 @@ struct Tuning {
     bool no_run_skip = false;        // SA_AMD_NO_RUN_SKIP: never skip a radix pass whose digit is the same for every element
     int64_t run_skip_min = (int64_t)1 << 25;   // SA_AMD_RUN_SKIP_MIN: smallest refinement sort that looks for such passes
     int64_t dense_rekey_min = (int64_t)1 << 22;   // SA_AMD_DENSE_REKEY_MIN: smallest whole-list global sort that is re-keyed by group index
+    bool no_first_tail = false;      // SA_AMD_NO_FIRST_TAIL: the dense route's first ranks are head ranks (the first doubling round then rewrites every rank)
     bool no_repeat_probe = false;    // SA_AMD_NO_REPEAT_PROBE: never start rank doubling right after the initial sort
     int64_t binned_min = (int64_t)1 << 26;   // SA_AMD_BINNED_MIN: fewest (suffix, rank) pairs a round bins before scattering
     int chase = 7;                   // SA_AMD_CHASE: rank look-ups per member and dense doubling round (1 = plain doubling), 1..15
@@ -109,6 +110,7 @@ struct Tuning {
         t.binned_isa_always = env_flag("SA_AMD_BINNED_ISA_ALWAYS");
         t.no_run_skip = env_flag("SA_AMD_NO_RUN_SKIP");
         t.run_skip_min = env_int("SA_AMD_RUN_SKIP_MIN", (int64_t)1 << 25, 1, (int64_t)1 << 40);
+        t.no_first_tail = env_flag("SA_AMD_NO_FIRST_TAIL");
         t.no_repeat_probe = env_flag("SA_AMD_NO_REPEAT_PROBE");
         t.dense_rekey_min = env_int("SA_AMD_DENSE_REKEY_MIN", (int64_t)1 << 22, 1, (int64_t)1 << 40);
         t.max_text_rounds = (int)env_int("SA_AMD_MAX_TEXT_ROUNDS", 4, 0, 8);

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict_
 // (ISA = group heads, has_isa = bitmap, pair_v = counts per tile) instead of being listed, 2 = write (suffix, rank) pairs in slot order; the host bins them by suffix position
 // with one radix pass and k_scatter_pairs then writes the ISA window by window (a random 4-byte
 // store costs a whole 64-byte memory transaction, a binned one is merged in the caches).
-template <bool FIRST, bool WRITE_SA, int ISA_MODE, typename KeyT = uint64_t>
+template <bool FIRST, bool WRITE_SA, int ISA_MODE, typename KeyT = uint64_t, bool FTAIL = false>
 __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     const KeyT *__restrict__ keys, const uint32_t *__restrict__ V, const uint32_t *__restrict__ U, int64_t m,
     const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_head, uint32_t *__restrict__ SA,
@@ -248,11 +248,15 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     // the last slot only the members that leave do.  parent_tail = 0: the parents' ranks are not of this form (first
     // doubling round: ranks from the initial order), everything is written.  changed_cnt: ranks written (steers the
     // host's choice between binned and direct ISA stores in the next round).
-    constexpr bool TAIL = !FIRST && (ISA_MODE == 0 || ISA_MODE == 2);
+    // FTAIL: the FIRST ranks (set-up of the dense route, straight from the initial order) are of this form already, so the first
+    // doubling round leaves alone every group that does not split and every parent's last subgroup -- on a corpus with copied
+    // passages that is most of what stays tied.  (tile_next then comes from k_rr_count<true, ., true> + k_rr_scan_next.)
+    constexpr bool TAIL = (FIRST ? FTAIL : true) && (ISA_MODE == 0 || ISA_MODE == 2);
+    constexpr bool COUNT_CHANGED = TAIL && !FIRST;      // (the first ranks are all new: nothing to count)
     constexpr int NW = RR_THREADS / WAVE;
     __shared__ uint32_t wcnt[NW], whead[NW], wfirst[NW];
     __shared__ uint32_t s_chg;
-    if (TAIL && threadIdx.x == 0) s_chg = 0;          // (the barrier behind the wave totals orders it before the adds)
+    if (COUNT_CHANGED && threadIdx.x == 0) s_chg = 0;          // (the barrier behind the wave totals orders it before the adds)
     if (FIRST && !WRITE_SA && SPARSE) {
         // compaction-only pass (no SA, no ISA write): a tile without tied suffixes has nothing to do
         const uint32_t here = tile_cnt[blockIdx.x];
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     // PAIRS (dense rounds that bin their ISA writes): only the ranks that change become (suffix, rank) pairs, packed: the
     // workgroup counts them, takes a block of the pair arrays with ONE atomic on changed_cnt[0] (which so also ends up
     // as the number of pairs) and its waves fill it in order
-    constexpr bool PAIRS = TAIL && ISA_MODE == 2;
+    constexpr bool PAIRS = COUNT_CHANGED && ISA_MODE == 2;
     uint64_t cmask[PAIRS ? RR_ITEMS : 1];
     uint32_t pair_off = 0;
     if (PAIRS) {
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
             // the group's slots are consecutive: its last one = my slot + (members behind me)
             rank = slot[r] + ((code >> 1) - 1u - (uint32_t)i) + 1u;
             changed = !(parent_tail && (code & 1u));
-            if (!PAIRS) n_changed += (uint32_t)__popcll(__ballot(i < m && changed));
+            if (COUNT_CHANGED && !PAIRS) n_changed += (uint32_t)__popcll(__ballot(i < m && changed));
         }
         if (i < m) {
             if (WRITE_SA && slot[r] < n_text) SA[slot[r]] = v[r];
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
         if (g.head[r]) run_head = (uint32_t)__shfl((int)slot[r], 63 - __builtin_clzll(g.head[r]), WAVE) + 1u;
         if (PAIRS) pair_off += (uint32_t)__popcll(cmask[r]);
     }
-    if (TAIL && !PAIRS) {
+    if (COUNT_CHANGED && !PAIRS) {
         // one global atomic per workgroup, spread over RR_CHG_COUNTERS words in different 128-byte lines (a single
         // counter bumped by every wave serialises in one L2 channel: 465 K atomics cost 4 ms at 256 MiB)
         if (l == 0 && n_changed) atomicAdd(&s_chg, n_changed);

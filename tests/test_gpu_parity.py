@@ -315,16 +315,24 @@ def test_dense_rounds_keep_the_ranks_of_the_last_subgroup(oracle, monkeypatch):
         np.concatenate([np.tile(np.array([5, 6, 7], dtype=np.uint8), 90_000), [8], np.tile(np.array([5, 6, 7], dtype=np.uint8), 60_000), [1]]).astype(np.uint8),
         np.concatenate([rng.integers(0, 3, 5000, dtype=np.uint8)] * 40 + [rng.integers(0, 3, 777, dtype=np.uint8)]),   # one block 40 times
     ]
+    # (+ texts whose FIRST ranks matter: word-structured with copied passages, groups that never split before the last rounds)
+    texts += [corpus.english_corpus(1 << 20, 4, 2000, 0.3), np.concatenate([corpus.english(150_000, 8)] * 2), _planted(400_000, 11, 3),
+              corpus.dna_repeats(250_000, 5)]
     exp = [oracle.sais(s) for s in texts]
-    for env in ({"SA_AMD_FORCE_DENSE": "1"}, {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_BINNED_ISA_ALWAYS": "1"},
-                {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_BINNED_ISA_ALWAYS": "1", "SA_AMD_NO_LOCAL_SORT": "1", "SA_AMD_DENSE_REKEY_MIN": "1"},
-                {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_DENSE_REKEY_MIN": "1", "SA_AMD_GROUP_CAP": "16"}, {}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        for s, e in zip(texts, exp):
-            assert np.array_equal(build(s), e), env
-        for k in env:
-            monkeypatch.delenv(k)
+    # the rank set-up of the dense route writes tail ranks too (k_rr_apply FTAIL; SA_AMD_NO_FIRST_TAIL=1: head ranks, as before)
+    for first in ({}, {"SA_AMD_NO_FIRST_TAIL": "1"}):
+        for env in ({"SA_AMD_FORCE_DENSE": "1"}, {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_BINNED_ISA_ALWAYS": "1"},
+                    {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_BINNED_ISA_ALWAYS": "1", "SA_AMD_NO_LOCAL_SORT": "1", "SA_AMD_DENSE_REKEY_MIN": "1"},
+                    {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_NO_TOP32": "1", "SA_AMD_BINNED_MIN": "1"},
+                    {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_NO_TOP32": "1", "SA_AMD_NO_BINNED_ISA": "1", "SA_AMD_CHASE": "1"},
+                    {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_DENSE_REKEY_MIN": "1", "SA_AMD_GROUP_CAP": "16"}, {}):
+            env = dict(env); env.update(first)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for s, e in zip(texts, exp):
+                assert np.array_equal(build(s), e), (env, s.size)
+            for k in env:
+                monkeypatch.delenv(k)
 
 
 @pytest.mark.parametrize("g", ["0", "2", "3", "5"])
@@ -791,7 +799,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_FORCE_DENSE", "SA_AMD_NO_TEXT_ROUNDS", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TOP32", "SA_AMD_FORCE_TOP32",
              "SA_AMD_NO_FUSED_FINISH", "SA_AMD_FUSED64", "SA_AMD_NO_PACKED_TEXT", "SA_AMD_NO_BINNED_ISA",
              "SA_AMD_BINNED_ISA_ALWAYS", "SA_AMD_NO_RUN_SKIP", "SA_AMD_RUN_SKIP_MIN", "SA_AMD_TIMING_ONLY_INITIAL_SORT",
-             "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
+             "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_NO_FIRST_TAIL", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_GRAM_TAIL", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
              "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT",
