@@ -254,4 +254,73 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     return rc;
 }
 
+// Many SMALL texts of one device (sa_amd_saca_batch): the texts of up to SA_AMD_SMALL_MAX bytes are packed into pooled pinned
+// blocks (zero-copy, like the single small call above) and built by ONE launch per block of k_small_sa_batch, one workgroup
+// per text -- 256 texts at a time on the chip, one synchronisation per chunk instead of one per text.  A chunk holds up to
+// SMALL_BATCH_BYTES of texts + arrays + descriptors.  status[i] of the items handled is set; returns the first failure.
+constexpr size_t SMALL_BATCH_BYTES = (size_t)96 << 20;
+constexpr int SMALL_BATCH_TEXTS = 1 << 16;
+
+static int build_host_small_batch(const uint8_t *const *T, uint32_t *const *SA, const int32_t *n, const int *items, size_t count,
+                                  int device, int32_t *status)
+{
+    if (count == 0) return SA_AMD_OK;
+    DeviceGuard guard(device);
+    if (guard.rc != SA_AMD_OK) { for (size_t k = 0; k < count; ++k) status[items[k]] = guard.rc; return guard.rc; }
+    int cur = 0;
+    int rc = hip_status(hipGetDevice(&cur));
+    hipStream_t st = nullptr;
+    if (rc == SA_AMD_OK) rc = pool().stream(cur, &st);
+    if (rc != SA_AMD_OK) { for (size_t k = 0; k < count; ++k) status[items[k]] = rc; return rc; }
+    int first = SA_AMD_OK;
+    size_t k0 = 0;
+    while (k0 < count) {
+        // the chunk [k0, k1): descriptors first, then the texts (16-byte slots), then the arrays (4 (n + 1) bytes each, 16-byte slots)
+        size_t k1 = k0, tbytes = 0, sbytes = 0;
+        while (k1 < count && k1 - k0 < (size_t)SMALL_BATCH_TEXTS) {
+            const size_t nn = (size_t)n[items[k1]];
+            const size_t tb = align_up(nn, 16), sb = align_up((nn + 1) * 4, 16);
+            if (k1 > k0 && (k1 - k0 + 1) * 16 + tbytes + tb + sbytes + sb > SMALL_BATCH_BYTES) break;
+            tbytes += tb; sbytes += sb; ++k1;
+        }
+        const size_t cnt = k1 - k0, dbytes = align_up(cnt * 16, 256), need = dbytes + align_up(tbytes, 256) + sbytes;
+        PinBlock pb;
+        int rcc = pool().pinned(need < ((size_t)64 << 10) ? ((size_t)64 << 10) : need, -1, cur, &pb);
+        void *dbase = nullptr;
+        if (rcc == SA_AMD_OK) rcc = hip_status(hipHostGetDevicePointer(&dbase, pb.p, 0));
+        if (rcc == SA_AMD_OK) {
+            uint4 *desc = (uint4 *)pb.p;
+            char *tpart = (char *)pb.p + dbytes, *spart = tpart + align_up(tbytes, 256);
+            size_t to = 0, so = 0;
+            for (size_t k = k0; k < k1; ++k) {
+                const int i = items[k];
+                const size_t nn = (size_t)n[i];
+                memcpy(tpart + to, T[i], nn);
+                desc[k - k0] = make_uint4((unsigned)to, (unsigned)so, (unsigned)nn, 0u);
+                to += align_up(nn, 16); so += align_up((nn + 1) * 4, 16);
+            }
+            hipLaunchKernelGGL((k_small_sa_batch), dim3((unsigned)cnt), dim3(SM_THREADS), 0, st,
+                               (const uint8_t *)dbase + dbytes, (uint8_t *)dbase + dbytes + align_up(tbytes, 256), (const uint4 *)dbase);
+            rcc = hip_status(hipGetLastError());
+            const int rs = hip_status(hipStreamSynchronize(st));
+            if (rcc == SA_AMD_OK) rcc = rs;
+            if (rcc == SA_AMD_OK) {
+                so = 0;
+                for (size_t k = k0; k < k1; ++k) {
+                    const int i = items[k];
+                    const size_t nn = (size_t)n[i];
+                    memcpy(SA[i], spart + so, (nn + 1) * 4);
+                    so += align_up((nn + 1) * 4, 16);
+                }
+            }
+        }
+        if (pb.p) pool().release_pinned(pb);
+        for (size_t k = k0; k < k1; ++k) status[items[k]] = rcc;
+        if (first == SA_AMD_OK) first = rcc;
+        k0 = k1;
+    }
+    pool().release_stream(cur, st);
+    return first;
+}
+
 }  // namespace sa

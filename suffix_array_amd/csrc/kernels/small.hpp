@@ -55,8 +55,9 @@ __device__ __forceinline__ void sm_bitonic_steps(unsigned long long *key, int N2
     }
 }
 
-__global__ __launch_bounds__(SM_THREADS) void k_small_sa(const uint8_t *__restrict__ T, uint32_t *__restrict__ SA, int n,
-                                                         uint32_t *__restrict__ rounds_out)
+// one workgroup builds the array of one text (the body of both kernels below)
+__device__ __forceinline__ void small_sa_block(const uint8_t *__restrict__ T, uint32_t *__restrict__ SA, int n,
+                                               uint32_t *__restrict__ rounds_out)
 {
     __shared__ unsigned long long key[SM_MAX_N];
     __shared__ uint16_t rnk[SM_MAX_N + 2];
@@ -205,6 +206,23 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_sa(const uint8_t *__restri
     }
     for (int p = tid; p < n; p += SM_THREADS) SA[1 + p] = (uint32_t)(key[sm_phys(p)] & idx_mask);
     if (tid == 0) { SA[0] = (uint32_t)n; if (rounds_out) *rounds_out = rounds; }
+}
+
+__global__ __launch_bounds__(SM_THREADS) void k_small_sa(const uint8_t *__restrict__ T, uint32_t *__restrict__ SA, int n,
+                                                         uint32_t *__restrict__ rounds_out)
+{
+    small_sa_block(T, SA, n, rounds_out);
+}
+
+// MANY small texts in one launch, one workgroup each (sa_amd_saca_batch: a caller that indexes thousands of short strings --
+// the reference's own test domain, src/tests.rs:13-17 -- pays one launch and one synchronisation for all of them, and the
+// chip works on 256 texts at a time).  desc[b] = { byte offset of text b, byte offset of its array (a multiple of 4), n, - }
+// relative to the two bases; the texts need no alignment (byte loads).
+__global__ __launch_bounds__(SM_THREADS) void k_small_sa_batch(const uint8_t *__restrict__ tbase, uint8_t *__restrict__ sbase,
+                                                               const uint4 *__restrict__ desc)
+{
+    const uint4 d = desc[blockIdx.x];
+    small_sa_block(tbase + d.x, (uint32_t *)(sbase + d.y), (int)d.z, nullptr);
 }
 
 }  // namespace sa

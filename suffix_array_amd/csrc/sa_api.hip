@@ -43,12 +43,20 @@ SA_EXPORT int32_t sa_amd_saca_batch(const uint8_t *const *T, uint32_t *const *SA
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SA_AMD_ENODEVICE;
     SA_ABI_GUARD_BEGIN
     std::vector<int32_t> st((size_t)count, SA_AMD_OK);
-    std::vector<std::vector<int>> per_dev((size_t)ndev);
+    std::vector<std::vector<int>> per_dev((size_t)ndev), small_dev((size_t)ndev);
+    // texts of up to SA_AMD_SMALL_MAX bytes (the one-workgroup kernel's) are built together, one launch per device and chunk
+    // (host/host_path.hpp, build_host_small_batch) -- unless a device has a single one, which takes the single-call path
+    const int small_max = (int)sa::env_int("SA_AMD_SMALL_MAX", 8192, 0, sa::SM_MAX_N);
     for (int i = 0; i < count; ++i) {
         const int d = device ? device[i] : i % ndev;
         if (d < 0 || d >= ndev) { st[(size_t)i] = SA_AMD_EINVAL; continue; }
-        per_dev[(size_t)d].push_back(i);
+        if (n[i] > 0 && n[i] <= small_max && T[i] && SA[i]) small_dev[(size_t)d].push_back(i);
+        else per_dev[(size_t)d].push_back(i);
     }
+    for (int d = 0; d < ndev; ++d)
+        if (small_dev[(size_t)d].size() == 1) { per_dev[(size_t)d].push_back(small_dev[(size_t)d][0]); small_dev[(size_t)d].clear(); }
+    std::vector<std::atomic<int>> small_taken((size_t)ndev);
+    for (auto &a : small_taken) a.store(0);
     // Two host threads per device (SA_AMD_BATCH_THREADS, 1..4), each with its own stream and device block, take the
     // device's items in turn: while one waits for its 4(n+1)-byte copy back over PCIe the other uploads and computes,
     // so the link and the GPU overlap instead of alternating.
@@ -56,6 +64,12 @@ SA_EXPORT int32_t sa_amd_saca_batch(const uint8_t *const *T, uint32_t *const *SA
     std::vector<std::atomic<size_t>> next((size_t)ndev);
     for (auto &a : next) a.store(0);
     auto work = [&](int d) {
+        if (!small_dev[(size_t)d].empty() && small_taken[(size_t)d].exchange(1) == 0) {
+            // (the first worker of the device to get here; the others go on with the large texts meanwhile)
+            try { (void)sa::build_host_small_batch(T, SA, n, small_dev[(size_t)d].data(), small_dev[(size_t)d].size(), d, st.data()); }
+            catch (const std::bad_alloc &) { for (int i : small_dev[(size_t)d]) st[(size_t)i] = SA_AMD_ENOMEM; }
+            catch (...) { for (int i : small_dev[(size_t)d]) st[(size_t)i] = SA_AMD_EINTERNAL; }
+        }
         for (;;) {
             const size_t q = next[(size_t)d].fetch_add(1);
             if (q >= per_dev[(size_t)d].size()) break;
@@ -70,7 +84,7 @@ SA_EXPORT int32_t sa_amd_saca_batch(const uint8_t *const *T, uint32_t *const *SA
     std::vector<std::thread> workers;
     bool spawn_failed = false;
     for (int d = 0; d < ndev && !spawn_failed; ++d) {
-        const size_t items = per_dev[(size_t)d].size();
+        const size_t items = per_dev[(size_t)d].size() + (small_dev[(size_t)d].empty() ? 0 : 1);
         for (int k = 0; k < per && (size_t)k < items; ++k) {
             try { workers.emplace_back(work, d); }
             catch (...) { spawn_failed = true; break; }         // (std::system_error: no more threads)

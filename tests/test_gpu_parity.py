@@ -287,6 +287,52 @@ def test_batch_entry_point(oracle):
         assert np.array_equal(o, oracle.sais(t))
 
 
+def _small_texts(rng, count, max_n):
+    out = []
+    for i in range(count):
+        n = int(rng.choice([rng.integers(1, 40), rng.integers(1, 700), rng.integers(1, max_n + 1)]))
+        kind = i % 5
+        if kind == 0: t = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1: t = corpus.english(n, int(rng.integers(0, 1 << 30)))
+        elif kind == 2: t = np.full(n, int(rng.integers(0, 256)), dtype=np.uint8)
+        elif kind == 3: t = np.resize(rng.integers(0, 4, int(rng.integers(1, 9)), dtype=np.uint8), n).astype(np.uint8)
+        else: t = rng.integers(0, 3, n, dtype=np.uint8)
+        out.append(np.ascontiguousarray(t, dtype=np.uint8))
+    return out
+
+
+def test_batch_of_small_texts_is_one_launch_per_chunk(oracle, monkeypatch):
+    """sa_amd_saca_batch builds the texts of up to SA_AMD_SMALL_MAX bytes of a device together (k_small_sa_batch, one workgroup
+    per text; the reference's own test domain is n < 4096, src/tests.rs:13-17): every length class, runs / periods / small
+    alphabets, the sizes around the kernel's limits, empty and larger texts in the same call (those take the single-text path),
+    a batch that needs several chunks, one small text alone, and the same arrays with the batched path off"""
+    rng = np.random.default_rng(20260)
+    texts = _small_texts(rng, 700, 8192)
+    texts += [rng.integers(0, 256, n, dtype=np.uint8) for n in (1, 2, 4095, 4096, 4097, 8191, 8192)]
+    texts += [np.zeros(0, dtype=np.uint8), corpus.english(20_000, 3), corpus.uniform(8193, 4), np.zeros(0, dtype=np.uint8)]
+    order = rng.permutation(len(texts))
+    texts = [texts[i] for i in order]
+    exp = [oracle.sais(t) for t in texts]
+    outs = sa.saca_batch(texts)
+    for k, (o, e) in enumerate(zip(outs, exp)):
+        assert np.array_equal(o, e), (k, texts[k].size)
+    # several chunks: 2 600 texts of 8 192 bytes are 104 MiB of texts + arrays (a chunk holds 96 MiB)
+    big = [rng.integers(0, 256, 8192, dtype=np.uint8) for _ in range(2600)]
+    outs = sa.saca_batch(big)
+    for k in range(0, len(big), 37):
+        assert np.array_equal(outs[k], oracle.sais(big[k])), k
+    assert all(o[0] == 8192 and np.array_equal(np.sort(o[1:]), np.arange(8192, dtype=np.uint32)) for o in outs[:: 11])
+    assert np.array_equal(outs[-1], oracle.sais(big[-1]))
+    # one small text among large ones, and a lower / disabled small-text limit: same arrays
+    outs = sa.saca_batch([corpus.uniform(30_000, 1), texts[0], corpus.dna(40_000, 2)])
+    assert np.array_equal(outs[1], exp[0])
+    for lim in ("0", "100"):
+        monkeypatch.setenv("SA_AMD_SMALL_MAX", lim)
+        outs = sa.saca_batch(texts[:60])
+        for k, (o, e) in enumerate(zip(outs, exp[:60])):
+            assert np.array_equal(o, e), (lim, k, texts[k].size)
+
+
 def test_degenerate_large_runs(oracle, monkeypatch):
     """runs and periodic texts: one or a few huge groups in every round -- whole-list global sorts keyed by group index, radix
     passes whose digit is constant skipped (both forced on at this size), the local pass given up and probed again"""
