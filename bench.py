@@ -22,7 +22,8 @@ Prints ONE JSON line on rank 0:
                         hands over: src/sa.rs:23-27): H2D + build + D2H, all ranks concurrently
   batch_c5              (N > 1) BASELINE config 5: one 512 MiB uniform text per rank, device-resident and end to end
   batch_api             (N = 1) BASELINE config 5 through its C-ABI form: ONE call of sa_amd_saca_batch with 8 texts of 512 MiB
-                        over all visible devices, host pointers in and out
+                        over all visible devices, host pointers in and out (+ small_texts: 4 096 texts of 4 KiB through one
+                        call of the same entry point, the reference's own size domain)
   cpu_baseline          CPU suffix sorter on a bounded sample, one pinned core (N = 1 only): libdivsufsort if a probe finds
                         one (kind "reference"), else the oracle's own SA-IS (kind "port"); the probe log is in the object
 """
@@ -67,6 +68,7 @@ def parse(argv=None):
     ap.add_argument("--no-batch", action="store_true", help="N > 1: skip the config-5 batch leg")
     ap.add_argument("--no-batch-api", action="store_true", help="N = 1: skip the sa_amd_saca_batch leg (8 x 512 MiB, host pointers)")
     ap.add_argument("--batch-texts", type=int, default=8)
+    ap.add_argument("--small-batch-texts", type=int, default=4096, help="texts of 4 KiB in the small-text part of the sa_amd_saca_batch leg (0: skip)")
     ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload timed on the CPU")
     ap.add_argument("--e2e-calls", type=int, default=5)
     return ap.parse_args(argv)
@@ -393,9 +395,28 @@ def batch_api_leg(backend, args):
     ok = rc == 0 and all(x == 0 for x in st) and all(int(o[0]) == t.size for t, o in zip(texts, outs))
     ok = ok and all(backend.check_host(t, o) for t, o in zip(texts, outs))
     total = sum(int(t.size) for t in texts)
-    return {"entry_point": "sa_amd_saca_batch", "texts": k, "bytes_each": int(texts[0].size), "devices": backend.device_count(),
-            "ms_first_call": round(times[0] * 1e3, 1), "ms": round(times[1] * 1e3, 1),
-            "MB_per_s": round(total / 1e6 / times[1], 1), "verified": bool(ok)}
+    res = {"entry_point": "sa_amd_saca_batch", "texts": k, "bytes_each": int(texts[0].size), "devices": backend.device_count(),
+           "ms_first_call": round(times[0] * 1e3, 1), "ms": round(times[1] * 1e3, 1),
+           "MB_per_s": round(total / 1e6 / times[1], 1), "verified": bool(ok)}
+    ks = int(getattr(args, "small_batch_texts", 0) or 0)
+    if ks > 0:
+        # the same entry point on the reference's own size domain (src/tests.rs:13-17: texts below 4 KiB): MANY small texts in one
+        # call -- the library builds them together, one workgroup per text, one launch per chunk (kernels/small.hpp)
+        del texts, outs
+        small = [corpus.english(4096, 9000 + i) for i in range(ks)]
+        souts = [np.zeros(4097, dtype=np.uint32) for _ in small]
+        stimes = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc, st = backend.build_batch(small, souts)
+            stimes.append(time.perf_counter() - t0)
+        oks = rc == 0 and all(x == 0 for x in st) and all(int(o[0]) == 4096 for o in souts)
+        oks = oks and all(backend.check_host(small[i], souts[i]) for i in range(0, ks, max(ks // 16, 1)))
+        best = min(stimes[1:])
+        res["small_texts"] = {"texts": ks, "bytes_each": 4096, "ms": round(best * 1e3, 3), "us_per_text": round(best * 1e6 / ks, 3),
+                              "MB_per_s": round(ks * 4096 / 1e6 / best, 1), "verified": bool(oks),
+                              "what": "one sa_amd_saca_batch call over all of them, wall time including the ctypes pointer arrays"}
+    return res
 
 
 def run(args, backend, rank, world, dist=None, share=False):

@@ -141,10 +141,11 @@ def test_single_rank_path_with_stand_in():
     sys.path.insert(0, ROOT)
     import bench
     args = bench.parse(["--steps", "2", "--warmup", "0", "--workload", "c4_dna_1g", "--n", "30000", "--cpu-sample", "20000",
-                        "--e2e-calls", "1", "--batch-texts", "3"])
+                        "--e2e-calls", "1", "--batch-texts", "3", "--small-batch-texts", "40"])
     out = bench.run(args, OracleStandIn(), 0, 1)
     assert out["n_gpus"] == 1 and out["verified"] is True and out["batch_c5"] is None
     assert out["batch_api"]["texts"] == 3 and out["batch_api"]["verified"] is True and out["batch_api"]["MB_per_s"] > 0
+    assert out["batch_api"]["small_texts"]["texts"] == 40 and out["batch_api"]["small_texts"]["verified"] is True
     cb = out["cpu_baseline"]
     assert cb["cores"] == 1 and cb["kind"] in ("port", "reference") and len(cb["probe"]) >= 1
     # the probe order of SURVEY.md 8d: cargo + crate, system library, python package, stand-in
