@@ -61,7 +61,7 @@ int32_t sa_amd_saca_u8(const uint8_t *T, uint32_t *SA, int32_t n);
  * Each SA[i] has n[i] + 1 entries (layout of sa_amd_saca_u8).
  * The texts of up to SA_AMD_SMALL_MAX (8192) bytes of a device are built together: one launch per chunk
  * of up to 96 MiB of them, one workgroup per text (a caller that indexes thousands of short strings, the
- * reference's own test domain src/tests.rs:13-17, pays ~0.06-1.1 us per text instead of 20-100 us per call).
+ * reference's own test domain src/tests.rs:13-17, pays ~0.04-1.6 us per text instead of 20-100 us per call).
  */
 int32_t sa_amd_saca_batch(const uint8_t *const *T, uint32_t *const *SA, const int32_t *n,
                           const int32_t *device, int32_t count, int32_t *status);

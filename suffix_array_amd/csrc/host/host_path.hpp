@@ -293,29 +293,44 @@ static int build_host_small_batch(const uint8_t *const *T, uint32_t *const *SA, 
         if (rcc == SA_AMD_OK) {
             uint4 *desc = (uint4 *)pb.p;
             char *tpart = (char *)pb.p + dbytes, *spart = tpart + align_up(tbytes, 256);
-            size_t to = 0, so = 0;
+            // descriptors: the texts of up to SM_LITE_N bytes first (the light kernel's: eight workgroups per CU), then the others
+            size_t n_lite = 0;
+            for (size_t k = k0; k < k1; ++k) n_lite += n[items[k]] <= SM_LITE_N ? 1 : 0;
+            std::vector<uint32_t> slot_of(cnt);
+            size_t to = 0, so = 0, li = 0, fi = n_lite;
             for (size_t k = k0; k < k1; ++k) {
                 const size_t nn = (size_t)n[items[k]];
-                desc[k - k0] = make_uint4((unsigned)to, (unsigned)so, (unsigned)nn, 0u);
+                const size_t d = nn <= (size_t)SM_LITE_N ? li++ : fi++;
+                slot_of[k - k0] = (uint32_t)d;
+                desc[d] = make_uint4((unsigned)to, (unsigned)so, (unsigned)nn, 0u);
                 to += align_up(nn, 16); so += align_up((nn + 1) * 4, 16);
             }
+            const uint32_t *slot = slot_of.data();
             // the copies in and out are split over the node's helpers when there is enough to copy (4 096 texts of 4 KiB: 16 MiB in,
             // 64 MiB out -- one thread's memcpy was three quarters of the call)
             const int slices = (tbytes + sbytes) >= ((size_t)4 << 20) ? copy_slices : 1;
             const size_t per = (cnt + (size_t)slices - 1) / (size_t)slices;
             hp.parallel_for(slices, [=](int t) {
                 const size_t b = k0 + (size_t)t * per, e = b + per < k1 ? b + per : k1;
-                for (size_t k = b; k < e; ++k) memcpy(tpart + desc[k - k0].x, T[items[k]], (size_t)desc[k - k0].z);
+                for (size_t k = b; k < e; ++k) { const uint4 d = desc[slot[k - k0]]; memcpy(tpart + d.x, T[items[k]], (size_t)d.z); }
             });
-            hipLaunchKernelGGL((k_small_sa_batch), dim3((unsigned)cnt), dim3(SM_THREADS), 0, st,
-                               (const uint8_t *)dbase + dbytes, (uint8_t *)dbase + dbytes + align_up(tbytes, 256), (const uint4 *)dbase);
+            const uint8_t *d_texts = (const uint8_t *)dbase + dbytes;
+            uint8_t *d_arrays = (uint8_t *)dbase + dbytes + align_up(tbytes, 256);
+            if (n_lite > 0)
+                hipLaunchKernelGGL((k_small_sa_batch<SM_LITE_N, SM_LITE_THREADS>), dim3((unsigned)n_lite), dim3(SM_LITE_THREADS), 0, st,
+                                   d_texts, d_arrays, (const uint4 *)dbase);
             rcc = hip_status(hipGetLastError());
+            if (cnt > n_lite && rcc == SA_AMD_OK) {
+                hipLaunchKernelGGL((k_small_sa_batch<SM_MAX_N, SM_THREADS>), dim3((unsigned)(cnt - n_lite)), dim3(SM_THREADS), 0, st,
+                                   d_texts, d_arrays, (const uint4 *)dbase + n_lite);
+                rcc = hip_status(hipGetLastError());
+            }
             const int rs = hip_status(hipStreamSynchronize(st));
             if (rcc == SA_AMD_OK) rcc = rs;
             if (rcc == SA_AMD_OK)
                 hp.parallel_for(slices, [=](int t) {
                     const size_t b = k0 + (size_t)t * per, e = b + per < k1 ? b + per : k1;
-                    for (size_t k = b; k < e; ++k) memcpy(SA[items[k]], spart + desc[k - k0].y, ((size_t)desc[k - k0].z + 1) * 4);
+                    for (size_t k = b; k < e; ++k) { const uint4 d = desc[slot[k - k0]]; memcpy(SA[items[k]], spart + d.y, ((size_t)d.z + 1) * 4); }
                 });
         }
         if (pb.p) pool().release_pinned(pb);

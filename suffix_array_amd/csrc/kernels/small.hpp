@@ -30,12 +30,12 @@ __device__ __forceinline__ int sm_phys(int e) { return e ^ ((e >> 5) & 7) ^ (((e
 // between: a thread takes the 2^G elements whose indices differ only in those G bits -- every partner of every step is
 // its own -- so a sort of 8192 elements takes 35 barriers instead of 91.  Keys are distinct (the suffix number is part of
 // them), padding is all ones.
-template <int G>
+template <int G, int THREADS>
 __device__ __forceinline__ void sm_bitonic_steps(unsigned long long *key, int N2, int k, int J, int tid)
 {
     constexpr int E = 1 << G;
     const int p0 = __ffs(J >> (G - 1)) - 1;               // lowest of the G bits
-    for (int t = tid; t < (N2 >> G); t += SM_THREADS) {
+    for (int t = tid; t < (N2 >> G); t += THREADS) {
         const int base = ((t >> p0) << (p0 + G)) | (t & ((1 << p0) - 1));
         const bool up = (base & k) == 0;
         unsigned long long kk[E];
@@ -55,17 +55,19 @@ __device__ __forceinline__ void sm_bitonic_steps(unsigned long long *key, int N2
     }
 }
 
-// one workgroup builds the array of one text (the body of both kernels below)
+// one workgroup of THREADS threads builds the array of one text of up to MAXN bytes (the body of the kernels below)
+template <int MAXN, int THREADS>
 __device__ __forceinline__ void small_sa_block(const uint8_t *__restrict__ T, uint32_t *__restrict__ SA, int n,
                                                uint32_t *__restrict__ rounds_out)
 {
-    __shared__ unsigned long long key[SM_MAX_N];
-    __shared__ uint16_t rnk[SM_MAX_N + 2];
-    __shared__ uint16_t grp[SM_MAX_N + 2];                // counting rounds: the first place of the tied group a place belongs to
-    __shared__ uint8_t txt[SM_MAX_N + 8];
-    __shared__ uint32_t scan_lds[SM_THREADS / WAVE + 1];
-    __shared__ uint32_t s_shift[SM_THREADS + 1];
+    __shared__ unsigned long long key[MAXN];
+    __shared__ uint16_t rnk[MAXN + 2];
+    __shared__ uint16_t grp[MAXN + 2];                // counting rounds: the first place of the tied group a place belongs to
+    __shared__ uint8_t txt[MAXN + 8];
+    __shared__ uint32_t scan_lds[THREADS / WAVE + 1];
+    __shared__ uint32_t s_shift[THREADS + 1];
     __shared__ uint32_t s_groups;
+    constexpr int PER = MAXN / THREADS;                 // places per thread in the rank scan
     const int tid = threadIdx.x;
     int N2 = 2;
     while (N2 < n) N2 <<= 1;
@@ -73,10 +75,10 @@ __device__ __forceinline__ void small_sa_block(const uint8_t *__restrict__ T, ui
     const int comps = n <= 4096 ? 4 : 3;                  // ranks per key in the later rounds: 4 x 13 + 12 = 64, 3 x 14 + 13 = 55 bits
     const unsigned long long idx_mask = (1ull << ib) - 1;
 
-    for (int i = tid; i < n + 8; i += SM_THREADS) txt[i] = i < n ? T[i] : (uint8_t)0;
+    for (int i = tid; i < n + 8; i += THREADS) txt[i] = i < n ? T[i] : (uint8_t)0;
     __syncthreads();
     // first key: the suffix's first 6 symbols as one base-257 number (symbol = byte + 1, 0 past the end), 49 bits
-    for (int i = tid; i < N2; i += SM_THREADS) {
+    for (int i = tid; i < N2; i += THREADS) {
         unsigned long long k = ~0ull;                     // padding sorts behind every suffix
         if (i < n) {
             k = 0;
@@ -99,22 +101,22 @@ __device__ __forceinline__ void small_sa_block(const uint8_t *__restrict__ T, ui
             while (j > 0) {
                 const int left = 32 - __clz(j);            // steps left in this stage: j, j / 2, ..., 1
                 const int g = left % 3 ? left % 3 : 3;
-                if (g == 3) sm_bitonic_steps<3>(key, N2, k, j, tid);
-                else if (g == 2) sm_bitonic_steps<2>(key, N2, k, j, tid);
-                else sm_bitonic_steps<1>(key, N2, k, j, tid);
+                if (g == 3) sm_bitonic_steps<3, THREADS>(key, N2, k, j, tid);
+                else if (g == 2) sm_bitonic_steps<2, THREADS>(key, N2, k, j, tid);
+                else sm_bitonic_steps<1, THREADS>(key, N2, k, j, tid);
                 j >>= g;
                 __syncthreads();
             }
         }
         // ---- ranks: a group = run of equal keys, rank = place of its first member + 1 (0 = past the end of the text) ----
         uint32_t last_head = 0, heads = 0;                // (last_head: place + 1 of the latest group start at or before my places)
-        uint32_t mine[SM_PER];
-        uint16_t who[SM_PER];
-        unsigned long long prev = tid ? key[sm_phys(tid * SM_PER - 1)] >> ib : 0ull;
-        uint16_t prev_g = light && tid ? grp[tid * SM_PER - 1] : (uint16_t)0;
+        uint32_t mine[PER];
+        uint16_t who[PER];
+        unsigned long long prev = tid ? key[sm_phys(tid * PER - 1)] >> ib : 0ull;
+        uint16_t prev_g = light && tid ? grp[tid * PER - 1] : (uint16_t)0;
 #pragma unroll
-        for (int r = 0; r < SM_PER; ++r) {
-            const int p = tid * SM_PER + r;
+        for (int r = 0; r < PER; ++r) {
+            const int p = tid * PER + r;
             const unsigned long long e = p < N2 ? key[sm_phys(p)] : ~0ull;
             const uint16_t g = light && p < n ? grp[p] : (uint16_t)0;
             const bool head = p < n && (p == 0 || (e >> ib) != prev || g != prev_g);
@@ -125,19 +127,19 @@ __device__ __forceinline__ void small_sa_block(const uint8_t *__restrict__ T, ui
             mine[r] = last_head;
         }
         uint32_t all_max, all_heads;
-        const uint32_t before = block_incl_max<SM_THREADS>(last_head, scan_lds, &all_max);      // includes my own places
+        const uint32_t before = block_incl_max<THREADS>(last_head, scan_lds, &all_max);      // includes my own places
         (void)all_max;
         // the group start in front of my first place is the inclusive max of the threads before me: shift by one thread
         s_shift[tid + 1] = before;
         if (tid == 0) s_shift[0] = 0;
         __syncthreads();
         const uint32_t carry = s_shift[tid];
-        (void)block_excl_sum<SM_THREADS>(heads, scan_lds, &all_heads);
+        (void)block_excl_sum<THREADS>(heads, scan_lds, &all_heads);
         if (tid == 0) s_groups = all_heads;
         uint32_t my_off = 0;                              // largest distance of one of my places from its group's first place
 #pragma unroll
-        for (int r = 0; r < SM_PER; ++r) {
-            const int p = tid * SM_PER + r;
+        for (int r = 0; r < PER; ++r) {
+            const int p = tid * PER + r;
             if (!mine[r]) mine[r] = carry;
             if (p < n) {
                 rnk[who[r]] = (uint16_t)mine[r];
@@ -145,16 +147,16 @@ __device__ __forceinline__ void small_sa_block(const uint8_t *__restrict__ T, ui
             }
         }
         uint32_t max_off;
-        (void)block_incl_max<SM_THREADS>(my_off, scan_lds, &max_off);      // (its barriers also publish rnk and s_groups)
+        (void)block_incl_max<THREADS>(my_off, scan_lds, &max_off);      // (its barriers also publish rnk and s_groups)
         if ((int)s_groups == n || h >= n) break;          // every suffix has a place of its own (h >= n cannot leave ties)
         if (max_off < (uint32_t)SM_LIGHT) {
             // ---- counting round: every tied group is short.  The suffixes stay at their places except inside a group, where
             //      a member's new place is the group's first place + the number of members with a smaller key
             //      (rank[i + h], rank[i + 2h] [, rank[i + 3h]], i) -- no sort of the whole array ----
-            unsigned long long sub[SM_PER];
+            unsigned long long sub[PER];
 #pragma unroll
-            for (int r = 0; r < SM_PER; ++r) {
-                const int p = tid * SM_PER + r;
+            for (int r = 0; r < PER; ++r) {
+                const int p = tid * PER + r;
                 if (p < n) {
                     const int i = who[r];
                     unsigned long long k = 0;
@@ -166,10 +168,10 @@ __device__ __forceinline__ void small_sa_block(const uint8_t *__restrict__ T, ui
             }
             if (tid == 0) grp[n] = (uint16_t)0xFFFF;       // ends the last group's walk
             __syncthreads();
-            uint16_t dest[SM_PER];
+            uint16_t dest[PER];
 #pragma unroll
-            for (int r = 0; r < SM_PER; ++r) {
-                const int p = tid * SM_PER + r;
+            for (int r = 0; r < PER; ++r) {
+                const int p = tid * PER + r;
                 if (p < n) {
                     const uint16_t g = (uint16_t)(mine[r] - 1u);
                     uint32_t below = 0;
@@ -179,8 +181,8 @@ __device__ __forceinline__ void small_sa_block(const uint8_t *__restrict__ T, ui
             }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < SM_PER; ++r) {
-                const int p = tid * SM_PER + r;
+            for (int r = 0; r < PER; ++r) {
+                const int p = tid * PER + r;
                 if (p < n) key[sm_phys(dest[r])] = sub[r];
             }
             __syncthreads();
@@ -190,7 +192,7 @@ __device__ __forceinline__ void small_sa_block(const uint8_t *__restrict__ T, ui
             continue;
         }
         // ---- next round: (rank[i], rank[i + h], rank[i + 2h] [, rank[i + 3h]]) -- the compared length triples / quadruples ----
-        for (int i = tid; i < N2; i += SM_THREADS) {
+        for (int i = tid; i < N2; i += THREADS) {
             unsigned long long k = ~0ull;                  // (a real key is smaller: its leading rank is at most n = 2^ib)
             if (i < n) {
                 k = 0;
@@ -204,25 +206,30 @@ __device__ __forceinline__ void small_sa_block(const uint8_t *__restrict__ T, ui
         h *= comps;
         ++rounds;
     }
-    for (int p = tid; p < n; p += SM_THREADS) SA[1 + p] = (uint32_t)(key[sm_phys(p)] & idx_mask);
+    for (int p = tid; p < n; p += THREADS) SA[1 + p] = (uint32_t)(key[sm_phys(p)] & idx_mask);
     if (tid == 0) { SA[0] = (uint32_t)n; if (rounds_out) *rounds_out = rounds; }
 }
 
 __global__ __launch_bounds__(SM_THREADS) void k_small_sa(const uint8_t *__restrict__ T, uint32_t *__restrict__ SA, int n,
                                                          uint32_t *__restrict__ rounds_out)
 {
-    small_sa_block(T, SA, n, rounds_out);
+    small_sa_block<SM_MAX_N, SM_THREADS>(T, SA, n, rounds_out);
 }
 
 // MANY small texts in one launch, one workgroup each (sa_amd_saca_batch: a caller that indexes thousands of short strings --
 // the reference's own test domain, src/tests.rs:13-17 -- pays one launch and one synchronisation for all of them, and the
 // chip works on 256 texts at a time).  desc[b] = { byte offset of text b, byte offset of its array (a multiple of 4), n, - }
 // relative to the two bases; the texts need no alignment (byte loads).
-__global__ __launch_bounds__(SM_THREADS) void k_small_sa_batch(const uint8_t *__restrict__ tbase, uint8_t *__restrict__ sbase,
-                                                               const uint4 *__restrict__ desc)
+// MAXN / THREADS: the shape; the host gives the texts of up to SM_LITE_N bytes to the light one (256 threads, 15 KB of LDS:
+// eight workgroups per CU instead of one) and launches it over its own descriptor list.
+constexpr int SM_LITE_N = 1024;
+constexpr int SM_LITE_THREADS = 256;
+template <int MAXN, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_small_sa_batch(const uint8_t *__restrict__ tbase, uint8_t *__restrict__ sbase,
+                                                            const uint4 *__restrict__ desc)
 {
     const uint4 d = desc[blockIdx.x];
-    small_sa_block(tbase + d.x, (uint32_t *)(sbase + d.y), (int)d.z, nullptr);
+    small_sa_block<MAXN, THREADS>(tbase + d.x, (uint32_t *)(sbase + d.y), (int)d.z, nullptr);
 }
 
 }  // namespace sa
