@@ -132,8 +132,12 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
         rc = hip_status(hipHostGetDevicePointer(&dbase, pb.p, 0));
         if (rc == SA_AMD_OK) {
             memcpy(pb.p, T, (size_t)n);
-            hipLaunchKernelGGL((k_small_sa), dim3(1), dim3(SM_THREADS), 0, st, (const uint8_t *)dbase, (uint32_t *)((char *)dbase + tb), (int)n,
-                               (uint32_t *)nullptr);
+            if (n <= SM_LITE_SINGLE_N)
+                hipLaunchKernelGGL((k_small_sa_lite), dim3(1), dim3(SM_LITE_THREADS), 0, st, (const uint8_t *)dbase, (uint32_t *)((char *)dbase + tb), (int)n,
+                                   (uint32_t *)nullptr);
+            else
+                hipLaunchKernelGGL((k_small_sa), dim3(1), dim3(SM_THREADS), 0, st, (const uint8_t *)dbase, (uint32_t *)((char *)dbase + tb), (int)n,
+                                   (uint32_t *)nullptr);
             rc = hip_status(hipGetLastError());
             const int rs = hip_status(hipStreamSynchronize(st));
             if (rc == SA_AMD_OK) rc = rs;

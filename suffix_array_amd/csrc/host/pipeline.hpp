@@ -1717,7 +1717,10 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     if ((int64_t)w.bytes > work_bytes) return SA_AMD_EINVAL;
     if (n <= tn.small_max) {
         // small texts: the whole construction in one launch of one workgroup, everything in LDS (kernels/small.hpp)
-        PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_small_sa), dim3(1), dim3(SM_THREADS), 0, st, dT, dSA, (int)n, w.total));
+        if (n <= SM_LITE_SINGLE_N)
+            PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_small_sa_lite), dim3(1), dim3(SM_LITE_THREADS), 0, st, dT, dSA, (int)n, w.total));
+        else
+            PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_small_sa), dim3(1), dim3(SM_THREADS), 0, st, dT, dSA, (int)n, w.total));
         uint32_t rounds = 0;
         { const int rcw = read_words(&rounds, w.total, 4, st); if (rcw) return rcw; }
         local.rounds = (int)rounds;

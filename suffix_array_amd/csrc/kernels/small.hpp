@@ -16,6 +16,9 @@ namespace sa {
 
 constexpr int SM_MAX_N = 8192;
 constexpr int SM_THREADS = 1024;
+constexpr int SM_LITE_N = 1024;                    // the light shape: texts of up to this many bytes, SM_LITE_THREADS threads, 15 KB of LDS
+constexpr int SM_LITE_THREADS = 256;
+constexpr int SM_LITE_SINGLE_N = 512;             // a single call takes the light shape up to here (measured: 16 B 21.0 -> 19.5 us, 256 B 25.7 -> 24.3, 1 KiB 30.7 -> 33.8)
 constexpr int SM_PER = SM_MAX_N / SM_THREADS;      // places per thread in the rank scan
 constexpr int SM_LIGHT = 48;                       // largest tied group that is ordered by counting instead of a full sort
 // a suffix number rides in the low bits of its key: 12 bits up to 4096 suffixes, else 13; a rank (0 ..= n) takes one bit more
@@ -220,10 +223,15 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_sa(const uint8_t *__restri
 // the reference's own test domain, src/tests.rs:13-17 -- pays one launch and one synchronisation for all of them, and the
 // chip works on 256 texts at a time).  desc[b] = { byte offset of text b, byte offset of its array (a multiple of 4), n, - }
 // relative to the two bases; the texts need no alignment (byte loads).
+// the light shape for a single text of up to SM_LITE_N bytes (four waves to start and to wait for instead of sixteen)
+__global__ __launch_bounds__(SM_LITE_THREADS) void k_small_sa_lite(const uint8_t *__restrict__ T, uint32_t *__restrict__ SA, int n,
+                                                       uint32_t *__restrict__ rounds_out)
+{
+    small_sa_block<SM_LITE_N, SM_LITE_THREADS>(T, SA, n, rounds_out);
+}
+
 // MAXN / THREADS: the shape; the host gives the texts of up to SM_LITE_N bytes to the light one (256 threads, 15 KB of LDS:
 // eight workgroups per CU instead of one) and launches it over its own descriptor list.
-constexpr int SM_LITE_N = 1024;
-constexpr int SM_LITE_THREADS = 256;
 template <int MAXN, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_small_sa_batch(const uint8_t *__restrict__ tbase, uint8_t *__restrict__ sbase,
                                                             const uint4 *__restrict__ desc)
