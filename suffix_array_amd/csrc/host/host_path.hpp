@@ -86,7 +86,8 @@ static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipSt
 // threads) take turns PER PHASE: one upload, one build and one download at a time per device.  Left alone, threads that
 // start together stay in step -- both upload, both build on half a GPU, both download on half a link (measured, two threads,
 // 8 x 512 MiB: every call h2d 18 + build 32 + d2h 85 ms, 500 ms per batch) -- with the lanes one text's download runs at
-// full link speed under the next one's upload and build.  SA_AMD_NO_LANES=1: no turns (A/B).
+// full link speed under the next one's upload and build.  SA_AMD_NO_LANES=1: no turns (A/B).  Texts below SA_AMD_LANES_MIN_N
+// (32 MiB) never take turns: their builds leave most of the GPU idle and overlap (build_host).
 struct DeviceLanes { std::mutex up, run, down; };
 static DeviceLanes &device_lanes(int device)
 {
@@ -100,6 +101,8 @@ struct LaneTurn {
     LaneTurn(const LaneTurn &) = delete;
     LaneTurn &operator=(const LaneTurn &) = delete;
 };
+
+static int64_t lanes_min_n() { return env_int("SA_AMD_LANES_MIN_N", (int64_t)32 << 20, 0, (int64_t)1 << 40); }
 
 // host buffers in, host buffers out; with_sentinel writes SA[0] = n too (saca layout)
 static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_sentinel, int device)
@@ -168,7 +171,9 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     uint32_t *dSA = (uint32_t *)((char *)blk.p + tb);
     void *dW = (char *)blk.p + tb + sb;
     DeviceLanes &lanes = device_lanes(cur);
-    const bool turns = env_int("SA_AMD_NO_LANES", 0, 0, 1) == 0;
+    // (texts below SA_AMD_LANES_MIN_N bytes take no turns: a mid-size build is bound by launches and read-backs, several of them
+    // in flight on one device overlap -- 128 x 1 MiB of English through one batch call 195 -> 66 ms with four host threads)
+    const bool turns = env_int("SA_AMD_NO_LANES", 0, 0, 1) == 0 && n >= lanes_min_n();
     // The caller's array is usually FRESH memory (`vec![0; n + 1]`, reference src/sa.rs:24: zero pages that are mapped on first
     // write): the helpers touch its pages -- read a byte, write it back: the contents stay whatever they were -- while the GPU
     // builds, so the download later copies into mapped memory (C3, fresh buffer: d2h 26-31 -> 20 ms).  SA_AMD_NO_PREFAULT=1: off.

@@ -57,10 +57,20 @@ SA_EXPORT int32_t sa_amd_saca_batch(const uint8_t *const *T, uint32_t *const *SA
         if (small_dev[(size_t)d].size() == 1) { per_dev[(size_t)d].push_back(small_dev[(size_t)d][0]); small_dev[(size_t)d].clear(); }
     std::vector<std::atomic<int>> small_taken((size_t)ndev);
     for (auto &a : small_taken) a.store(0);
-    // Two host threads per device (SA_AMD_BATCH_THREADS, 1..4), each with its own stream and device block, take the
+    // Two host threads per device (SA_AMD_BATCH_THREADS, 1..16), each with its own stream and device block, take the
     // device's items in turn: while one waits for its 4(n+1)-byte copy back over PCIe the other uploads and computes,
     // so the link and the GPU overlap instead of alternating.
-    const int per = (int)sa::env_int("SA_AMD_BATCH_THREADS", 2, 1, 4);
+    // (SA_AMD_BATCH_THREADS = 0, the default: two per device; six for a device whose texts are all below SA_AMD_LANES_MIN_N, twelve
+    // when they are all below 8 MiB -- those builds leave most of the GPU idle and take no turns, host/host_path.hpp; measured,
+    // one GPU: 128 x 1 MiB of English 196 ms with two threads and turns, 67 with eight, 58 with twelve; 16 x 16 MiB 75 / 65 / 71)
+    const int per_env = (int)sa::env_int("SA_AMD_BATCH_THREADS", 0, 0, 16);
+    const int64_t lanes_min = sa::lanes_min_n();
+    std::vector<int> per_of((size_t)ndev, 2);
+    for (int d = 0; d < ndev; ++d) {
+        int64_t largest = 0;
+        for (int i : per_dev[(size_t)d]) largest = n[i] > largest ? n[i] : largest;
+        per_of[(size_t)d] = per_env > 0 ? per_env : (largest < lanes_min ? (largest < ((int64_t)8 << 20) ? 12 : 6) : 2);
+    }
     std::vector<std::atomic<size_t>> next((size_t)ndev);
     for (auto &a : next) a.store(0);
     auto work = [&](int d) {
@@ -85,7 +95,7 @@ SA_EXPORT int32_t sa_amd_saca_batch(const uint8_t *const *T, uint32_t *const *SA
     bool spawn_failed = false;
     for (int d = 0; d < ndev && !spawn_failed; ++d) {
         const size_t items = per_dev[(size_t)d].size() + (small_dev[(size_t)d].empty() ? 0 : 1);
-        for (int k = 0; k < per && (size_t)k < items; ++k) {
+        for (int k = 0; k < per_of[(size_t)d] && (size_t)k < items; ++k) {
             try { workers.emplace_back(work, d); }
             catch (...) { spawn_failed = true; break; }         // (std::system_error: no more threads)
         }
