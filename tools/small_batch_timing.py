@@ -25,6 +25,10 @@ for kind in ("uniform", "english"):
         for _ in range(5):
             t0 = time.perf_counter(); rc = sa.lib().sa_amd_saca_batch(T, S, N, None, cnt, stt); best = min(best, time.perf_counter() - t0)
             assert rc == 0
+        py = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter(); outs2 = sa.saca_batch(texts); py = min(py, time.perf_counter() - t0)
+        assert all(np.array_equal(a, b) for a, b in zip(outs[::97], outs2[::97]))
         out = np.zeros(n + 1, dtype=np.uint32)
         k = min(count, 512)
         t0 = time.perf_counter()
@@ -32,4 +36,4 @@ for kind in ("uniform", "english"):
         single = (time.perf_counter() - t0) / k
         ok = np.array_equal(outs[k - 1], out)
         print(f"{kind:8s} n={n:5d} x {count:6d}: batch {best*1e3:8.2f} ms = {best/count*1e6:6.2f} us per text, {count*n/best/1e6:8.1f} MB/s of text | "
-              f"one call per text {single*1e6:6.1f} us -> {single/(best/count):5.1f}x  (same array: {ok})", flush=True)
+              f"one call per text {single*1e6:6.1f} us -> {single/(best/count):5.1f}x  (same array: {ok}) | python saca_batch {py*1e3:7.2f} ms", flush=True)
