@@ -295,6 +295,7 @@ static int build_host_small_batch(const uint8_t *const *T, uint32_t *const *SA, 
             tbytes += tb; sbytes += sb; ++k1;
         }
         const size_t cnt = k1 - k0, dbytes = align_up(cnt * 16, 256), need = dbytes + align_up(tbytes, 256) + sbytes;
+        std::vector<uint32_t> slot_of(cnt);               // (before the pinned block is taken: the only thing here that can throw)
         PinBlock pb;
         int rcc = pool().pinned(need < ((size_t)64 << 10) ? ((size_t)64 << 10) : need, -1, cur, &pb);
         void *dbase = nullptr;
@@ -305,7 +306,6 @@ static int build_host_small_batch(const uint8_t *const *T, uint32_t *const *SA, 
             // descriptors: the texts of up to SM_LITE_N bytes first (the light kernel's: eight workgroups per CU), then the others
             size_t n_lite = 0;
             for (size_t k = k0; k < k1; ++k) n_lite += n[items[k]] <= SM_LITE_N ? 1 : 0;
-            std::vector<uint32_t> slot_of(cnt);
             size_t to = 0, so = 0, li = 0, fi = n_lite;
             for (size_t k = k0; k < k1; ++k) {
                 const size_t nn = (size_t)n[items[k]];
