@@ -20,6 +20,12 @@ Prints ONE JSON line on rank 0:
                         EVERY rank, outside the timed region -- always on
   end_to_end            median of 5 sa_amd_saca_u8 calls on host buffers (what the reference's `SuffixArray::new`
                         hands over: src/sa.rs:23-27): H2D + build + D2H, all ranks concurrently
+  configs               (N = 1) the other BASELINE.json configs behind the headline workload, same measurement each: C2 64 MiB uniform,
+                        north_star's literal 256 MiB random-byte text, C4 1 GiB DNA, C5's 512 MiB per-GPU text -- device-resident
+                        ms per build (1 warm-up + --config-steps timed), MB/s, verified, the class with the most device time
+                        against the HBM roofline (HIP events inside the timed region), (5n + 4) / t, host-pointer calls
+  ranks                 every rank's HIP device, PCI bus id, own ms per step and own verification (N > 1: the bus ids must be
+                        distinct unless SA_BENCH_SHARE_GPU=1 asks for a rehearsal on one GPU)
   batch_c5              (N > 1) BASELINE config 5: one 512 MiB uniform text per rank, device-resident and end to end
   batch_api             (N = 1) BASELINE config 5 through its C-ABI form: ONE call of sa_amd_saca_batch with 8 texts of 512 MiB
                         over all visible devices, host pointers in and out (+ small_texts: 4 096 texts of 4 KiB through one
@@ -69,7 +75,12 @@ def parse(argv=None):
     ap.add_argument("--no-batch-api", action="store_true", help="N = 1: skip the sa_amd_saca_batch leg (8 x 512 MiB, host pointers)")
     ap.add_argument("--batch-texts", type=int, default=8)
     ap.add_argument("--small-batch-texts", type=int, default=4096, help="texts of 4 KiB in the small-text part of the sa_amd_saca_batch leg (0: skip)")
-    ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload timed on the CPU")
+    ap.add_argument("--cpu-sample", type=int, default=256 << 20,
+                    help="bytes of the workload timed on the CPU (default: the whole 256 MiB headline text, ~30 s of the stand-in)")
+    ap.add_argument("--configs", default="c2_uniform_64m,c2_uniform_256m,c4_dna_1g,c5_uniform_512m",
+                    help="N = 1: the other BASELINE configs measured behind the headline workload (comma list; '' or --no-configs: none)")
+    ap.add_argument("--no-configs", action="store_true")
+    ap.add_argument("--config-steps", type=int, default=5, help="timed builds per extra config (after 1 warm-up)")
     ap.add_argument("--e2e-calls", type=int, default=5)
     return ap.parse_args(argv)
 
@@ -207,8 +218,9 @@ def cpu_baseline(text, sample):
             kind, engine = "port", "oracle_sais = own single-thread SA-IS (stand-in: divsufsort unavailable offline)"
     finally:
         restore()
+    what = "the whole workload" if t.size == text.size else f"first {t.size} of the workload's {text.size} bytes"
     return {"value": round(t.size / 1e6 / dt, 3), "unit": "MB/s", "cores": 1, "kind": kind, "pinned_cpu": cpu, "probe": probe,
-            "sample": f"first {t.size} bytes of the workload; {engine}; {dt:.1f} s"}
+            "sample": f"{what} ({t.size} bytes); {engine}; {dt:.1f} s"}
 
 
 def host_info():
@@ -343,6 +355,16 @@ class HipBackend:
     def stats_dict(self):
         return self.stats.as_dict()
 
+    def identity(self):
+        """which physical GPU this rank runs on (the N > 1 line lists it per rank)"""
+        idx = self.dev.index
+        try:
+            bus = self.sa.device_pci_bus_id(idx)
+        except Exception as ex:                                   # (reported, not fatal: the line then says the ids are unknown)
+            bus = None
+            print(f"bench.py: rank device {idx}: no PCI bus id ({ex})", file=sys.stderr)
+        return {"hip_device": idx, "pci_bus_id": bus, "gpu": self.torch.cuda.get_device_name(idx), "pid": os.getpid()}
+
     def ctl_device(self, share):
         return self.torch.device("cpu") if share else self.dev
 
@@ -431,6 +453,103 @@ def batch_api_leg(backend, args):
     return res
 
 
+def load_traffic(workload, n):
+    """HBM traffic per kernel class from the committed PMC passes of this same command (builder-run: tools/profile_round.sh ->
+    tools/pmc_traffic.py -> profiles/traffic.json); None when the file is for another workload"""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    tj = json.load(open(tpath))
+    if tj.get("workload") != workload or tj.get("n_bytes") != n:
+        return None
+    return tj
+
+
+def roofline_lines(names, prof, steps, tj=None):
+    """one line per kernel class timed inside a timed region (HIP events on the launch stream), most device time first:
+    ms per step, algorithmic bytes per element and launch (ALGO_BYTES x units), achieved GB/s, fraction of the HBM peak and --
+    where profiles/traffic.json has the class -- the PMC-measured bytes per launch over the algorithmic ones"""
+    timed_ms = sum(ms for ms, _, _ in prof)
+    lines = []
+    for i in sorted((i for i in range(len(prof)) if prof[i][1]), key=lambda i: -prof[i][0]):
+        ms, launches, units = prof[i]
+        nm = names[i]
+        ab = ALGO_BYTES.get(nm)
+        line = {"name": nm, "ms_per_step": round(ms / max(steps, 1), 3), "launches_per_step": launches / max(steps, 1),
+                "share_of_timed_classes": round(ms / timed_ms, 4) if timed_ms > 0 else None,
+                "algorithmic_bytes_per_element": ab, "avg_launch_ms": round(ms / max(launches, 1), 4)}
+        if ab and ms > 0:
+            line["algorithmic_bytes_per_launch"] = round(ab * units / max(launches, 1))
+            line["achieved"] = round(ab * units / (ms * 1e-3) / 1e9, 2)
+            line["frac"] = round(line["achieved"] / HBM_PEAK_GBS, 5)
+        if tj and nm in tj.get("kernels", {}):
+            line["traffic"] = tj["kernels"][nm]["hbm_bytes_per_launch"]
+            if ab and units:
+                line["traffic_over_algorithmic"] = round(line["traffic"] / (ab * units / max(launches, 1)), 3)
+            # the rate the kernel moves FETCHED bytes at: a kernel of random 4-byte look-ups sits far below the roofline on
+            # algorithmic bytes and AT it on these -- every look-up is a 128-byte request on gfx950 (tools/gather_probe.hip,
+            # profiles/r03_gather_probe.txt)
+            if ms > 0 and launches:
+                line["traffic_rate"] = round(line["traffic"] / (ms / launches * 1e-3) / 1e9, 1)
+                line["traffic_frac"] = round(line["traffic_rate"] / HBM_PEAK_GBS, 4)
+        lines.append(line)
+    return lines
+
+
+def measure_resident(backend, barrier, steps, warmup, bcast_mask=None):
+    """the text is loaded: first touch, one build with events around every launch (which classes matter), then `warmup` untimed
+    and `steps` timed builds with events around the classes that had >= EVENT_SHARE of the device time.  Returns
+    (seconds for the timed steps on this rank, per-class rows of the timed region, rows of the profiled build, its device ms)."""
+    backend.step()                                            # (first touch of the workspace, pool, pinned read-back buffer)
+    backend.profile_begin(~0 & 0xFFFFFFFFFFFFFFFF)
+    backend.step()
+    backend.sync()
+    prof_all = backend.profile_end()
+    device_ms = sum(ms for ms, _, _ in prof_all)
+    ev_mask = sum(1 << i for i, (ms, _, _) in enumerate(prof_all) if device_ms > 0 and ms >= EVENT_SHARE * device_ms)
+    if bcast_mask is not None:                                # (every rank times the same classes: rank 0 decides)
+        ev_mask = bcast_mask(ev_mask)
+    dt, prof = timed_steps(backend, barrier, steps, warmup, ev_mask)
+    return dt, prof, prof_all, device_ms
+
+
+def config_leg(backend, args, workload, barrier, names):
+    """one of the other BASELINE.json configs behind the headline workload (N = 1): the same measurement -- device-resident
+    builds timed as the contract says, verified on the device, the class with the most device time against the HBM roofline
+    from HIP events inside the timed region, (5n + 4) / t, and the host-pointer call -- at `--config-steps` timed builds"""
+    from suffix_array_amd import corpus
+    t_gen = time.perf_counter()
+    text_h = corpus.workload(workload, rank=0, n_override=args.n)
+    t_gen = time.perf_counter() - t_gen
+    n = int(text_h.size)
+    backend.load(text_h)
+    steps = max(int(args.config_steps), 1)
+    dt, prof, prof_all, device_ms = measure_resident(backend, barrier, steps, 1)
+    stats = backend.stats_dict()
+    ok = bool(backend.verify())
+    per = dt / steps
+    lines = roofline_lines(names, prof, steps)
+    dom = lines[0] if lines else {"name": None}
+    res = {"workload": workload, "n_bytes": n, "steps": steps, "warmup": 1, "ms_per_build": round(per * 1e3, 3),
+           "MB_per_s": round(n / 1e6 / per, 1), "device_ms_per_build": round(device_ms, 3), "verified": ok,
+           "sigma": stats["sigma"], "refinement_rounds": stats["rounds"], "radix_passes": stats["sort_passes"],
+           "roofline": {"kernel": dom.get("name"), "achieved": dom.get("achieved"), "frac": dom.get("frac"), "unit": "GB/s",
+                        "avg_launch_ms": dom.get("avg_launch_ms"), "launches_per_step": dom.get("launches_per_step"),
+                        "algorithmic_bytes_per_element": dom.get("algorithmic_bytes_per_element"),
+                        "algorithmic_bytes_per_launch": dom.get("algorithmic_bytes_per_launch"),
+                        "kernels": [{k: ln.get(k) for k in ("name", "ms_per_step", "launches_per_step", "avg_launch_ms", "achieved", "frac")}
+                                    for ln in lines if device_ms > 0 and ln["ms_per_step"] >= REPORT_SHARE * device_ms]},
+           "whole_job": {"algorithmic_bytes": 5 * n + 4, "achieved": round((5 * n + 4) / per / 1e9, 3),
+                         "frac": round((5 * n + 4) / per / 1e9 / HBM_PEAK_GBS, 6)},
+           "corpus_generation_s": round(t_gen, 2)}
+    if not args.no_end_to_end:
+        e = end_to_end(backend, text_h, max(min(args.e2e_calls, 3), 1), barrier)
+        res["end_to_end"] = {m: {"ms": e[m]["ms"], "MB_per_s": e[m]["MB_per_s"], "phases_ms_last_call": e[m]["phases_ms_last_call"]}
+                             for m in ("reused_buffer", "fresh_buffer")}
+    backend.unload()
+    return res
+
+
 def run(args, backend, rank, world, dist=None, share=False):
     """one rank of the benchmark; returns the result dict on rank 0 (None elsewhere).  `backend` is the HipBackend; the
     world-size-2 CPU test of tests/test_dist.py injects its own object with the same methods."""
@@ -451,6 +570,14 @@ def run(args, backend, rank, world, dist=None, share=False):
         dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
         return float(t.item())
 
+    def bcast_mask(mask):
+        if dist is None:
+            return mask
+        import torch
+        tm = torch.tensor([mask], dtype=torch.int64, device=backend.ctl_device(share))
+        dist.broadcast(tm, src=0)
+        return int(tm.item())
+
     # ---- synthetic input, resident in HBM before the timed region ----
     text_h = corpus.workload(args.workload, rank=rank, n_override=args.n)
     n = int(text_h.size)
@@ -459,20 +586,8 @@ def run(args, backend, rank, world, dist=None, share=False):
     # per-kernel table first: one untimed build with events around every launch.  It also says which classes matter: the
     # timed region then carries events around every class with at least EVENT_SHARE of the device time (an event pair
     # around each of the ~200 launches of a build would cost ~0.7 ms of host time per step)
-    backend.step()                                            # (first touch of the workspace, pool, pinned read-back buffer)
-    backend.profile_begin(~0 & 0xFFFFFFFFFFFFFFFF)
-    backend.step()
-    backend.sync()
-    prof_all = backend.profile_end()
-    device_ms = sum(ms for ms, _, _ in prof_all)
-    ev_mask = sum(1 << i for i, (ms, _, _) in enumerate(prof_all) if device_ms > 0 and ms >= EVENT_SHARE * device_ms)
-    if dist is not None:                                      # (every rank times the same classes: rank 0 decides)
-        import torch
-        tm = torch.tensor([ev_mask], dtype=torch.int64, device=backend.ctl_device(share))
-        dist.broadcast(tm, src=0)
-        ev_mask = int(tm.item())
-    dt, prof = timed_steps(backend, barrier, args.steps, args.warmup, ev_mask)
-    dt = reduce(dt, "MAX")
+    dt_rank, prof, prof_all, device_ms = measure_resident(backend, barrier, args.steps, args.warmup, bcast_mask)
+    dt = reduce(dt_rank, "MAX")
     stats = backend.stats_dict()
     # correctness gate of every run, outside the timed region: every rank's last array
     ok = bool(backend.verify())
@@ -481,6 +596,18 @@ def run(args, backend, rank, world, dist=None, share=False):
         got = backend.download()
         ok = ok and orc.oracle_verify_sa_mt(text_h.ctypes.data, n, got.ctypes.data, n + 1, 16) == 1
     verified = reduce(1.0 if ok else 0.0, "MIN") == 1.0
+
+    # who ran where: every rank's device identity, its own time and its own check (the driver's N > 1 runs: N distinct GPUs)
+    ident = dict(backend.identity()) if hasattr(backend, "identity") else {}
+    mine = {"rank": rank, **ident, "ms_per_step": round(dt_rank / max(args.steps, 1) * 1e3, 3), "verified": ok}
+    ranks = [mine]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+    bus_ids = [r.get("pci_bus_id") for r in ranks]
+    distinct = len(set(bus_ids)) == len(bus_ids) and None not in bus_ids
+    if world > 1 and not share and not distinct and os.environ.get("SA_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"bench.py: {world} ranks but their GPUs are not distinct ({bus_ids}); SA_BENCH_SHARE_GPU=1 allows a rehearsal")
 
     e2e = None
     if not args.no_end_to_end:
@@ -500,19 +627,29 @@ def run(args, backend, rank, world, dist=None, share=False):
         backend.unload()
         t5 = corpus.workload("c5_uniform_512m", rank=rank, n_override=args.n)
         backend.load(t5)
-        dt5, _ = timed_steps(backend, barrier, max(args.steps // 2, 2), 1)
+        k5 = max(args.steps // 2, 2)
+        dt5, _ = timed_steps(backend, barrier, k5, 1)
         dt5 = reduce(dt5, "MAX")
         ok5 = reduce(1.0 if backend.verify() else 0.0, "MIN") == 1.0
         e5 = end_to_end(backend, t5, 3, barrier)
         ms5 = reduce(e5["reused_buffer"]["ms"], "MAX")
-        k5 = max(args.steps // 2, 2)
         batch = {"workload": f"c5_uniform_512m: {t5.size} bytes per GPU, seeds 50 + rank", "texts": world,
                  "device_resident": {"ms_per_text": round(dt5 / k5 * 1e3, 3), "MB_per_s": round(world * t5.size / 1e6 / (dt5 / k5), 1)},
                  "end_to_end": {"ms_per_text": round(ms5, 3), "MB_per_s": round(world * t5.size / 1e3 / ms5, 1)},
                  "verified": ok5}
 
+    # the other BASELINE configs, same measurement (N = 1: they are single-GPU configs; C5's per-GPU text is one of them)
+    configs = None
+    cfg_names = [c for c in (args.configs or "").split(",") if c and c != args.workload]
+    if world == 1 and not args.no_configs and cfg_names:
+        backend.unload()
+        t_cfg = time.perf_counter()
+        configs = {c: config_leg(backend, args, c, barrier, names) for c in cfg_names}
+        configs["_seconds"] = round(time.perf_counter() - t_cfg, 1)
+
     batch_api = None
     if world == 1 and not args.no_batch_api and not args.no_end_to_end:
+        backend.unload()
         batch_api = batch_api_leg(backend, args)
 
     if rank != 0:
@@ -522,40 +659,8 @@ def run(args, backend, rank, world, dist=None, share=False):
     for i, (ms, launches, units) in enumerate(prof_all):
         if launches:
             kernels[names[i]] = {"ms_per_step": round(ms, 3), "launches_per_step": float(launches), "units_per_step": int(units)}
-    # HBM traffic per kernel class from the committed PMC passes of this same command (if any)
-    tj = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("workload") != args.workload or tj.get("n_bytes") != n:
-            tj = None
-    timed_ms = sum(ms for ms, _, _ in prof)
-
-    def kernel_line(i):
-        ms, launches, units = prof[i]
-        nm = names[i]
-        ab = ALGO_BYTES.get(nm)
-        line = {"name": nm, "ms_per_step": round(ms / max(args.steps, 1), 3), "launches_per_step": launches / max(args.steps, 1),
-                "share_of_timed_classes": round(ms / timed_ms, 4) if timed_ms > 0 else None,
-                "algorithmic_bytes_per_element": ab, "avg_launch_ms": round(ms / max(launches, 1), 4)}
-        if ab and ms > 0:
-            line["algorithmic_bytes_per_launch"] = round(ab * units / max(launches, 1))
-            line["achieved"] = round(ab * units / (ms * 1e-3) / 1e9, 2)
-            line["frac"] = round(line["achieved"] / HBM_PEAK_GBS, 5)
-        if tj and nm in tj.get("kernels", {}):
-            line["traffic"] = tj["kernels"][nm]["hbm_bytes_per_launch"]
-            if ab and units:
-                line["traffic_over_algorithmic"] = round(line["traffic"] / (ab * units / max(launches, 1)), 3)
-            # the rate the kernel moves FETCHED bytes at (profiles/traffic.json is measured on the headline workload): a
-            # kernel of random 4-byte look-ups sits far below the roofline on algorithmic bytes and AT it on these --
-            # every look-up is a 128-byte request on gfx950 (tools/gather_probe.hip, profiles/r03_gather_probe.txt)
-            if ms > 0 and launches and tj.get("workload") == args.workload:
-                line["traffic_rate"] = round(line["traffic"] / (ms / launches * 1e-3) / 1e9, 1)
-                line["traffic_frac"] = round(line["traffic_rate"] / HBM_PEAK_GBS, 4)
-        return line
-
-    timed = sorted((i for i in range(len(prof)) if prof[i][1]), key=lambda i: -prof[i][0])
-    lines = [kernel_line(i) for i in timed]
+    tj = load_traffic(args.workload, n)
+    lines = roofline_lines(names, prof, args.steps, tj)
     dom = lines[0] if lines else {"name": None, "achieved": 0.0, "frac": 0.0}
     reported = [ln for ln in lines if device_ms > 0 and ln["ms_per_step"] >= REPORT_SHARE * device_ms]
     whole_build = None
@@ -591,6 +696,8 @@ def run(args, backend, rank, world, dist=None, share=False):
                    "unresolved_after_initial_sort": stats["unresolved_after_initial"], **facts},
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": dom.get("achieved", 0.0), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": dom.get("frac", 0.0), "traffic": dom.get("traffic"),
+                     "traffic_source": "profiles/traffic.json (builder-run PMC passes of this command, tools/profile_round.sh); "
+                                       "not measured in this run" if tj else None,
                      "algorithmic_bytes_per_launch": dom.get("algorithmic_bytes_per_launch"),
                      "algorithmic_bytes_per_element": dom.get("algorithmic_bytes_per_element"),
                      "avg_launch_ms": dom.get("avg_launch_ms"), "launches_per_step": dom.get("launches_per_step"),
@@ -604,7 +711,10 @@ def run(args, backend, rank, world, dist=None, share=False):
         "kernels": kernels,
         "device_ms_per_step": round(device_ms, 3),
         "verified": verified,
+        "ranks": ranks,
+        "distinct_gpus": distinct if world > 1 else None,
         "end_to_end": e2e,
+        "configs": configs,
         "batch_c5": batch,
         "batch_api": batch_api,
         "host": host_info(),
@@ -622,7 +732,7 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args, argv)                       # (nothing above this line initialises the GPU)
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("SA_BENCH_FORCE_LOCAL_RANK", os.environ.get("LOCAL_RANK", "0")))      # (forced: tests only)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # rehearsal on a one-GPU box: SA_BENCH_SHARE_GPU=1 puts every rank on device 0; the driver's real runs use one GPU per rank.
     # Control plane: the data path has NO collective (one independent text per GPU); what the ranks exchange is a

@@ -109,6 +109,9 @@ void sa_amd_last_stats(sa_amd_stats *out);
 
 /* number of visible HIP devices (0 when none; never initialises a context by itself) */
 int32_t sa_amd_device_count(void);
+/* PCI address ("0000:c1:00.0") of HIP device `device` into buf (capacity >= 16): which physical GPU an ordinal is -- bench.py
+ * prints it per rank so that an N-GPU run can be seen to have used N distinct GPUs */
+int32_t sa_amd_device_pci_bus_id(int32_t device, char *buf, int32_t capacity);
 
 const char *sa_amd_strerror(int32_t code);
 const char *sa_amd_version(void);
@@ -117,14 +120,18 @@ const char *sa_amd_version(void);
  *
  * Bucket table of `enable_buckets` (reference src/sa.rs:89-119): 256 * 257 + 1 = 65 793 entries in the
  * layout of src/sa.rs:94; bkt[i] = exclusive right edge of bucket i inside the SA (what the reference
- * gets by counting bigrams, src/sa.rs:100-108, and prefix-summing, src/sa.rs:112-116).  Here it is
- * read off the finished suffix array with one binary search per bucket.
+ * gets by counting bigrams, src/sa.rs:100-108, and prefix-summing, src/sa.rs:112-116).  Built the same
+ * way here -- from the TEXT alone: a bigram histogram kernel (two half tables of 32-bit LDS counters per
+ * pair of workgroups) and one scan; only the text is uploaded (n bytes), 257 KiB come back.
  */
 #define SA_AMD_BUCKET_TABLE_LEN 65793
-/* T: n bytes, SA: n + 1 entries (a valid suffix array of T), bkt: 65 793 entries; host buffers */
+/* T: n bytes, bkt: 65 793 entries; host buffers.  SA is not read (the reference's enable_buckets never touches the
+ * array either) and may be NULL; the parameter stays for callers of the earlier form */
 int32_t sa_amd_bucket_table(const uint8_t *T, int32_t n, const uint32_t *SA, uint32_t *bkt);
-/* SuffixArray::new followed by enable_buckets in one device round trip (text and SA stay in HBM) */
+/* SuffixArray::new followed by enable_buckets in one device round trip (the text is uploaded once) */
 int32_t sa_amd_saca_u8_buckets(const uint8_t *T, uint32_t *SA, int32_t n, uint32_t *bkt);
+/* dSA == NULL: from the text alone (bigram counts; dBkt doubles as the scratch); dSA = a valid device-resident suffix
+ * array of dT: one binary search per bucket edge instead (what sa_amd_index_buckets uses) */
 int32_t sa_amd_bucket_table_device(const uint8_t *dT, const uint32_t *dSA, int32_t n, uint32_t *dBkt, void *stream);
 
 /*

@@ -20,7 +20,7 @@ from typing import Optional
 import numpy as np
 
 __all__ = ["MAX_LENGTH", "saca", "SuffixArray", "SuffixArrayError", "lib", "diag_lib", "library_path", "Stats", "last_host_timing",
-           "saca_batch", "workspace_bytes", "saca_device_ptr", "bucket_table", "check_integrity", "last_stats", "DeviceIndex", "pack", "unpack"]
+           "saca_batch", "workspace_bytes", "device_pci_bus_id", "saca_device_ptr", "bucket_table", "check_integrity", "last_stats", "DeviceIndex", "pack", "unpack"]
 
 #: reference src/saca.rs:6
 MAX_LENGTH = 2**31 - 1
@@ -76,6 +76,10 @@ def lib() -> ctypes.CDLL:
         L.sa_amd_saca_device.argtypes = [c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int64, c_vp, c_vp]
         L.sa_amd_saca_device.restype = ctypes.c_int32
         L.sa_amd_device_count.restype = ctypes.c_int32
+        L.sa_amd_device_pci_bus_id.argtypes = [ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
+        L.sa_amd_device_pci_bus_id.restype = ctypes.c_int32
+        L.sa_amd_bucket_table_device.argtypes = [c_vp, c_vp, ctypes.c_int32, c_vp, c_vp]
+        L.sa_amd_bucket_table_device.restype = ctypes.c_int32
         L.sa_amd_last_stats.argtypes = [c_vp]
         L.sa_amd_index_create.argtypes = [c_vp, ctypes.c_int32, c_vp, ctypes.POINTER(ctypes.c_void_p)]
         L.sa_amd_index_create.restype = ctypes.c_int32
@@ -158,6 +162,13 @@ def diag_lib() -> ctypes.CDLL:
         L.sa_amd_version.restype = ctypes.c_char_p
         _diag = L
     return _diag
+
+
+def device_pci_bus_id(device: int = 0) -> str:
+    """PCI address of HIP device `device` ("0000:c1:00.0"): which physical GPU an ordinal is"""
+    buf = ctypes.create_string_buffer(64)
+    _check(lib().sa_amd_device_pci_bus_id(int(device), buf, 64))
+    return buf.value.decode()
 
 
 def _check(code: int) -> None:
@@ -244,14 +255,15 @@ def last_stats() -> dict:
 BUCKET_TABLE_LEN = 256 * 257 + 1        # reference src/sa.rs:95
 
 
-def bucket_table(s, sa: np.ndarray) -> np.ndarray:
-    """the table `enable_buckets` builds (reference src/sa.rs:89-119), computed on the GPU from the
-    text and its suffix array"""
+def bucket_table(s, sa: np.ndarray | None = None) -> np.ndarray:
+    """the table `enable_buckets` builds (reference src/sa.rs:89-119), computed on the GPU the way the reference computes
+    it: bigram counts of the TEXT + prefix sum (src/sa.rs:96-116).  `sa` is not needed (and not uploaded); it is accepted for
+    callers of the earlier form and only its length is checked"""
     t = _as_u8(s)
-    a = np.ascontiguousarray(sa, dtype=np.uint32)
-    assert a.size == t.size + 1
+    if sa is not None:
+        assert np.asarray(sa).size == t.size + 1
     bkt = np.empty(BUCKET_TABLE_LEN, dtype=np.uint32)
-    _check(lib().sa_amd_bucket_table(t.ctypes.data, t.size, a.ctypes.data, bkt.ctypes.data))
+    _check(lib().sa_amd_bucket_table(t.ctypes.data, t.size, None, bkt.ctypes.data))
     return bkt
 
 

@@ -17,14 +17,14 @@ static size_t cache_limit()
 
 // ---- pool of device blocks, streams and pinned staging buffers (process-wide, mutex-protected) ----
 struct DevBlock { int device = -1; void *p = nullptr; size_t bytes = 0; uint64_t stamp = 0; };      // stamp: when it was last handed back
-struct PinBlock { void *p = nullptr; size_t bytes = 0; int node = -1; };      // node: NUMA node its pages were first touched on (-1: wherever)
+struct PinBlock { void *p = nullptr; size_t bytes = 0; int node = -1; uint64_t stamp = 0; };      // node: NUMA node its pages were first touched on (-1: wherever); stamp: when it was last handed back
 
 class ResourcePool {
     std::mutex mu_;
     std::vector<DevBlock> blocks_;                 // free device blocks
     std::vector<std::pair<int, hipStream_t>> streams_;
     std::vector<PinBlock> pinned_;
-    size_t retained_ = 0;
+    size_t retained_ = 0, pinned_retained_ = 0;
     uint64_t clock_ = 0;
 
 public:
@@ -123,29 +123,69 @@ public:
     // a pinned host block of at least `bytes`, first-touched on NUMA node `node` (-1: no placement).  New blocks of a node
     // are allocated by a helper thread that runs on that node's CPUs (helpers.hpp): hipHostMalloc pins -- touches -- the
     // pages from the allocating thread, and the default memory policy puts them on the node it runs on.
+    // Blocks are PORTABLE and MAPPED (hipHostMallocPortable | hipHostMallocMapped): a block allocated while device A was
+    // current may be handed to a caller on device B of the same NUMA node, whose kernels read and write it zero-copy (the
+    // small-text path) and whose DMA engines target it (staging) -- portable makes it pinned for every device's context,
+    // mapped gives every device a pointer to it, so the pool needs no device key.  The smallest free block that fits is
+    // taken, and only one that is not more than four times the request (1 MiB for tiny requests): the 4 KiB read-back
+    // buffer of a thread does not sit on a 96 MiB small-batch chunk for the thread's lifetime.  Retained pinned memory is
+    // bounded (SA_AMD_PINNED_MAX_BYTES, default 2 GiB): beyond it the blocks that have been idle longest are freed.
+    static size_t pinned_size_class(size_t bytes)
+    {
+        if (bytes <= ((size_t)1 << 20)) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
+        return (bytes + (((size_t)4 << 20) - 1)) & ~(((size_t)4 << 20) - 1);
+    }
     int pinned(size_t bytes, int node, int device, PinBlock *out)
     {
+        const size_t want = pinned_size_class(bytes);
         {
             std::lock_guard<std::mutex> lk(mu_);
+            const size_t most = want * 4 > ((size_t)1 << 20) ? want * 4 : ((size_t)1 << 20);
+            int best = -1;
             for (int i = 0; i < (int)pinned_.size(); ++i)
-                if (pinned_[i].bytes >= bytes && pinned_[i].node == node) { *out = pinned_[i]; pinned_.erase(pinned_.begin() + i); return SA_AMD_OK; }
+                if (pinned_[i].bytes >= bytes && pinned_[i].bytes <= most && pinned_[i].node == node &&
+                    (best < 0 || pinned_[i].bytes < pinned_[best].bytes)) best = i;
+            if (best >= 0) {
+                *out = pinned_[best];
+                pinned_retained_ -= out->bytes;
+                pinned_.erase(pinned_.begin() + best);
+                return SA_AMD_OK;
+            }
         }
         void *p = nullptr;
         hipError_t e = hipErrorUnknown;
         auto alloc = [&]() {
             if (device >= 0) (void)hipSetDevice(device);
-            e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+            e = hipHostMalloc(&p, want, hipHostMallocPortable | hipHostMallocMapped);
         };
         if (node >= 0) helper_pool(node).run_on_helper(alloc); else alloc();
         if (e != hipSuccess) { (void)hipGetLastError(); return hip_status(e); }
-        out->p = p; out->bytes = bytes; out->node = node;
+        out->p = p; out->bytes = want; out->node = node; out->stamp = 0;
         return SA_AMD_OK;
     }
     void release_pinned(const PinBlock &b)
     {
         if (!b.p) return;
-        std::lock_guard<std::mutex> lk(mu_);
-        pinned_.push_back(b);
+        const size_t limit = (size_t)env_int("SA_AMD_PINNED_MAX_BYTES", (int64_t)2 << 30, 0, (int64_t)1 << 44);
+        std::vector<PinBlock> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (b.bytes > limit) drop.push_back(b);
+            else {
+                while (pinned_retained_ + b.bytes > limit && !pinned_.empty()) {
+                    int old = 0;
+                    for (int i = 1; i < (int)pinned_.size(); ++i) if (pinned_[i].stamp < pinned_[old].stamp) old = i;
+                    pinned_retained_ -= pinned_[old].bytes;
+                    drop.push_back(pinned_[old]);
+                    pinned_.erase(pinned_.begin() + old);
+                }
+                PinBlock kept = b;
+                kept.stamp = ++clock_;
+                pinned_.push_back(kept);
+                pinned_retained_ += b.bytes;
+            }
+        }
+        for (auto &d : drop) (void)hipHostFree(d.p);
     }
     void clear()
     {
@@ -153,7 +193,7 @@ public:
         {
             std::lock_guard<std::mutex> lk(mu_);
             drop.swap(blocks_); pdrop.swap(pinned_); sdrop.swap(streams_);
-            retained_ = 0;
+            retained_ = 0; pinned_retained_ = 0;
         }
         for (auto &d : drop) (void)hipFree(d.p);
         for (auto &d : pdrop) (void)hipHostFree(d.p);

@@ -1,7 +1,8 @@
 // kernels/extras.hpp -- the "next" rows of SURVEY.md section 8f that sit directly on either side of the
 // construction path, as HIP kernels working on the device-resident text and suffix array:
 //   k_bucket_table     reference src/sa.rs:89-119 (enable_buckets): right edge of every 1-/2-byte
-//                      prefix bucket of the SA, 65 793 entries
+//                      prefix bucket of the SA, 65 793 entries, read off a device-resident suffix array
+//   k_bigram_hist/scan the same table from the text alone, as the reference builds it (src/sa.rs:96-116)
 //   k_ci_*             reference src/sa.rs:72-84 (check_integrity) in its linear-time form
 #pragma once
 #include "common.hpp"
@@ -35,6 +36,97 @@ __global__ __launch_bounds__(256) void k_bucket_table(const uint8_t *__restrict_
         if (bucket_class(T, n, (int64_t)SA[mid]) <= (uint32_t)b) lo = mid + 1; else hi = mid;
     }
     bkt[b] = (uint32_t)lo;
+}
+
+// ---- the bucket table as the reference builds it: from the TEXT alone (src/sa.rs:96-116, no suffix array) ----
+// 65 536 bigram bins do not fit one CU's LDS as 32-bit counters (256 KiB against 160), and 16-bit halves of a packed word
+// cannot be spilled safely (a carry out of the low half is visible in the high half until it is taken back).  So the bins are
+// split in two halves by the low bit of the SECOND byte (the top bit of the first would leave half the workgroups idle on
+// ASCII text) and a PAIR of workgroups reads the same chunks of the text at the same time, each counting its half in 128 KiB of
+// LDS: one LDS atomic per bigram, the text read once from HBM and once more from the cache.  The non-zero bins of a workgroup
+// are then added to the global table (hist: 65 536 words, zeroed by the caller).
+constexpr int BG_THREADS = 1024;
+constexpr int BG_BINS = 32768;
+constexpr int BG_MAX_PAIRS = 128;                 // 256 workgroups: one per CU (128 KiB of LDS each)
+constexpr int64_t BG_MIN_CHUNK = 1 << 18;         // text bytes per pair below which fewer pairs are launched
+
+__device__ __forceinline__ void bigram_count(uint32_t *h, uint32_t part, uint32_t c0, uint32_t c1)
+{
+    if ((c1 & 1u) == part) atomicAdd(&h[(c0 << 7) | (c1 >> 1)], 1u);
+}
+
+__global__ __launch_bounds__(BG_THREADS) void k_bigram_hist(const uint8_t *__restrict__ T, int64_t n, int pairs, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[BG_BINS];
+    for (int i = threadIdx.x; i < BG_BINS; i += BG_THREADS) h[i] = 0;
+    __syncthreads();
+    const uint32_t part = blockIdx.x & 1u;
+    const int pair = (int)(blockIdx.x >> 1);
+    const int64_t nb = n - 1;                                             // bigrams: positions 0 .. n - 2
+    // positions in front of the first 16-byte aligned address, then whole groups of 16 positions (a uint4 + the byte behind
+    // it), then the rest: head and rest byte by byte, by the first pair
+    int64_t head = (int64_t)((16u - (uint32_t)((uintptr_t)T & 15u)) & 15u);
+    if (head > nb) head = nb > 0 ? nb : 0;
+    const int64_t groups = nb > head ? (nb - head) / 16 : 0;
+    const int64_t rest0 = head + groups * 16;
+    if (pair == 0) {
+        for (int64_t p = threadIdx.x; p < head; p += BG_THREADS) bigram_count(h, part, T[p], T[p + 1]);
+        for (int64_t p = rest0 + threadIdx.x; p < nb; p += BG_THREADS) bigram_count(h, part, T[p], T[p + 1]);
+    }
+    const uint4 *__restrict__ V = (const uint4 *)(T + head);
+    for (int64_t g = (int64_t)pair * BG_THREADS + threadIdx.x; g < groups; g += (int64_t)pairs * BG_THREADS) {
+        const uint4 v = V[g];
+        const uint32_t nx = T[head + g * 16 + 16];                        // (g < groups: position head + 16 g + 15 has a successor)
+        const uint32_t w[5] = { v.x, v.y, v.z, v.w, nx };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t x = w[k], y = w[k + 1];
+            bigram_count(h, part, x & 255u, (x >> 8) & 255u);
+            bigram_count(h, part, (x >> 8) & 255u, (x >> 16) & 255u);
+            bigram_count(h, part, (x >> 16) & 255u, x >> 24);
+            bigram_count(h, part, x >> 24, y & 255u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BG_BINS; i += BG_THREADS) {
+        const uint32_t c = h[i];
+        if (c) atomicAdd(&hist[(((uint32_t)i >> 7) << 8) | (((uint32_t)i & 127u) << 1) | part], c);
+    }
+}
+
+// bigram counts -> the table of reference src/sa.rs:94-116: entry 0 = the empty suffix (src/sa.rs:98), entry c0 * 257 + 1 =
+// the suffix that is the lone last byte c0 (src/sa.rs:106-108), entry c0 * 257 + c1 + 2 = bigram (c0, c1) (src/sa.rs:103), then
+// the inclusive prefix sum (src/sa.rs:112-116).  ONE workgroup; hist and bkt may be the same memory (hist in the first 65 536
+// words of bkt): every count is read before the barrier of the block scan, every entry written behind it.
+constexpr int BGS_THREADS = 1024;
+constexpr int BGS_ITEMS = 65;
+static_assert(BGS_THREADS * BGS_ITEMS >= BKT_LEN, "one pass over the table");
+__global__ __launch_bounds__(BGS_THREADS) void k_bigram_scan(const uint32_t *hist, const uint8_t *__restrict__ T, int64_t n, uint32_t *bkt)
+{
+    __shared__ uint32_t lds[BGS_THREADS / WAVE + 1];
+    const uint32_t last = n > 0 ? (uint32_t)T[n - 1] : 0xffffffffu;
+    uint32_t v[BGS_ITEMS];
+    uint32_t sum = 0;
+    const uint32_t e0 = threadIdx.x * BGS_ITEMS;
+#pragma unroll
+    for (int k = 0; k < BGS_ITEMS; ++k) {
+        const uint32_t e = e0 + (uint32_t)k;
+        uint32_t c = 0;
+        if (e == 0) c = 1;
+        else if (e < (uint32_t)BKT_LEN) {
+            const uint32_t c0 = (e - 1u) / 257u, r = (e - 1u) % 257u;
+            c = r == 0 ? (c0 == last ? 1u : 0u) : hist[c0 * 256u + r - 1u];
+        }
+        sum += c;
+        v[k] = sum;
+    }
+    uint32_t total;
+    const uint32_t base = block_excl_sum<BGS_THREADS>(sum, lds, &total);
+#pragma unroll
+    for (int k = 0; k < BGS_ITEMS; ++k) {
+        const uint32_t e = e0 + (uint32_t)k;
+        if (e < (uint32_t)BKT_LEN) bkt[e] = base + v[k];
+    }
 }
 
 // ---- check_integrity, linear-time form ----

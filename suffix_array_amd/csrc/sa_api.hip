@@ -133,9 +133,21 @@ SA_EXPORT int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n
 SA_EXPORT int32_t sa_amd_bucket_table_device(const uint8_t *dT, const uint32_t *dSA, int32_t n, uint32_t *dBkt, void *stream)
 {
     SA_ABI_GUARD_BEGIN
-    if (n < 0 || !dSA || !dBkt || (n > 0 && !dT)) return SA_AMD_EINVAL;
+    if (n < 0 || !dBkt || (n > 0 && !dT)) return SA_AMD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sa::k_bucket_table, dim3((sa::BKT_LEN + 255) / 256), dim3(256), 0, st, dT, dSA, (int64_t)n, dBkt);
+    if (dSA) {
+        // a device-resident index has the sorted order at hand: one binary search per bucket edge (~0.08 ms whatever n)
+        hipLaunchKernelGGL(sa::k_bucket_table, dim3((sa::BKT_LEN + 255) / 256), dim3(256), 0, st, dT, dSA, (int64_t)n, dBkt);
+    } else {
+        // as the reference builds it (src/sa.rs:96-116): bigram counts of the text + prefix sum, no suffix array needed.  The
+        // counts live in the first 65 536 words of dBkt itself (k_bigram_scan reads them all before it writes)
+        if (hipMemsetAsync(dBkt, 0, (size_t)65536 * 4, st) != hipSuccess) return SA_AMD_EHIP;
+        int64_t pairs = sa::ceil_div((int64_t)n, sa::BG_MIN_CHUNK);
+        if (pairs > sa::BG_MAX_PAIRS) pairs = sa::BG_MAX_PAIRS;
+        if (n >= 2)
+            hipLaunchKernelGGL(sa::k_bigram_hist, dim3((unsigned)(2 * pairs)), dim3(sa::BG_THREADS), 0, st, dT, (int64_t)n, (int)pairs, dBkt);
+        hipLaunchKernelGGL(sa::k_bigram_scan, dim3(1), dim3(sa::BGS_THREADS), 0, st, (const uint32_t *)dBkt, dT, (int64_t)n, dBkt);
+    }
     if (hipGetLastError() != hipSuccess) return SA_AMD_EHIP;
     return hipStreamSynchronize(st) == hipSuccess ? SA_AMD_OK : SA_AMD_EHIP;
     SA_ABI_GUARD_END(0)
@@ -238,7 +250,37 @@ SA_EXPORT int32_t sa_amd_check_integrity_device(const uint8_t *dT, int32_t n, co
     SA_ABI_GUARD_END(0)
 }
 
-// host buffers; which = 1: bucket table, 2: integrity check, 3: build SA (into SA, n + 1 entries) then bucket table
+// enable_buckets on host buffers (reference src/sa.rs:89-119): the text goes up, 257 KiB come back; nothing else is needed --
+// the reference builds the table from the text alone.  Device block and stream come from the process-wide pool.
+static int32_t bucket_table_host(const uint8_t *T, int32_t n, uint32_t *bkt)
+{
+    using namespace sa;
+    if (n < 0 || !bkt || (n > 0 && !T)) return SA_AMD_EINVAL;
+    if (sa_amd_device_count() <= 0) return SA_AMD_ENODEVICE;
+    DeviceGuard guard(pick_device());
+    if (guard.rc != SA_AMD_OK) return guard.rc;
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    const size_t tb = align_up((size_t)n + 16, 256);
+    DevBlock blk;
+    hipStream_t st = nullptr;
+    int32_t rc = pool().stream(cur, &st);
+    if (rc != SA_AMD_OK) return rc;
+    rc = pool().acquire(cur, tb + (size_t)BKT_LEN * 4, &blk);
+    if (rc != SA_AMD_OK) { pool().release_stream(cur, st); return rc; }
+    uint8_t *dT = (uint8_t *)blk.p;
+    uint32_t *dB = (uint32_t *)((char *)blk.p + tb);
+    if (n > 0) rc = hip_status(hipMemcpyAsync(dT, T, (size_t)n, hipMemcpyHostToDevice, st));
+    if (rc == SA_AMD_OK) rc = sa_amd_bucket_table_device(dT, nullptr, n, dB, st);
+    if (rc == SA_AMD_OK) rc = hip_status(hipMemcpyAsync(bkt, dB, (size_t)BKT_LEN * 4, hipMemcpyDeviceToHost, st));
+    const int32_t rs = hip_status(hipStreamSynchronize(st));       // (also drains the stream after a failure)
+    if (rc == SA_AMD_OK) rc = rs;
+    pool().release(blk);
+    pool().release_stream(cur, st);
+    return rc;
+}
+
+// host buffers; which = 2: integrity check, 3: build SA (into SA, n + 1 entries) then bucket table
 static int32_t extras_host(const uint8_t *T, int32_t n, uint32_t *SA, int64_t sa_len, uint32_t *bkt, int which)
 {
     using namespace sa;
@@ -258,15 +300,13 @@ static int32_t extras_host(const uint8_t *T, int32_t n, uint32_t *SA, int64_t sa
         if ((rc = dW.alloc((size_t)wb))) return rc;
         if ((rc = build_device(dT.as<uint8_t>(), dSA.as<uint32_t>(), n, dW.p, wb, nullptr, nullptr))) return rc;
         HIP_TRY(hipMemcpy(SA, dSA.p, (N + 1) * 4, hipMemcpyDeviceToHost));
-    } else {
-        HIP_TRY(hipMemcpy(dSA.p, SA, (N + 1) * 4, hipMemcpyHostToDevice));
-    }
-    if (which == 1 || which == 3) {
+        // the text is in HBM already: the table from its bigrams, as the reference counts them
         if ((rc = dB.alloc((size_t)BKT_LEN * 4))) return rc;
-        if ((rc = sa_amd_bucket_table_device(dT.as<uint8_t>(), dSA.as<uint32_t>(), n, dB.as<uint32_t>(), nullptr))) return rc;
+        if ((rc = sa_amd_bucket_table_device(dT.as<uint8_t>(), nullptr, n, dB.as<uint32_t>(), nullptr))) return rc;
         HIP_TRY(hipMemcpy(bkt, dB.p, (size_t)BKT_LEN * 4, hipMemcpyDeviceToHost));
         return SA_AMD_OK;
     }
+    HIP_TRY(hipMemcpy(dSA.p, SA, (N + 1) * 4, hipMemcpyHostToDevice));
     int64_t wb = sa_amd_check_integrity_work_bytes(n);              // the streaming form; the small block if that much is not to be had
     rc = dW.alloc((size_t)wb);
     if (rc == SA_AMD_ENOMEM) { (void)hipGetLastError(); wb = ((int64_t)n + 1) * 4 + 256; rc = dW.alloc((size_t)wb); }
@@ -278,7 +318,8 @@ SA_EXPORT int32_t sa_amd_bucket_table(const uint8_t *T, int32_t n, const uint32_
 {
     if (!bkt) return SA_AMD_EINVAL;
     SA_ABI_GUARD_BEGIN
-    return extras_host(T, n, (uint32_t *)SA, (int64_t)n + 1, bkt, 1);
+    (void)SA;                       // (the reference builds the table from the text alone, src/sa.rs:96-116)
+    return bucket_table_host(T, n, bkt);
     SA_ABI_GUARD_END(0)
 }
 
@@ -546,6 +587,17 @@ SA_EXPORT int32_t sa_amd_device_count(void)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
     return ndev;
+}
+
+SA_EXPORT int32_t sa_amd_device_pci_bus_id(int32_t device, char *buf, int32_t capacity)
+{
+    if (!buf || capacity < 16) return SA_AMD_EINVAL;
+    buf[0] = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SA_AMD_ENODEVICE;
+    if (device < 0 || device >= ndev) return SA_AMD_EINVAL;
+    if (hipDeviceGetPCIBusId(buf, capacity, device) != hipSuccess) { (void)hipGetLastError(); buf[0] = 0; return SA_AMD_EHIP; }
+    return SA_AMD_OK;
 }
 
 SA_EXPORT const char *sa_amd_strerror(int32_t code)

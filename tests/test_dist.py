@@ -90,6 +90,11 @@ class OracleStandIn:
         import torch
         return torch.device("cpu")
 
+    def identity(self):
+        # (two stand-in "GPUs": one per rank, as on the driver's multi-GPU node)
+        r = int(os.environ.get("RANK", "0"))
+        return {"hip_device": r, "pci_bus_id": f"0000:{0x10 + r:02x}:00.0", "gpu": "stand-in", "pid": os.getpid()}
+
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
@@ -132,7 +137,11 @@ def test_world_size_2_gloo_runs_bench_rank_logic():
     rf = out0["roofline"]
     assert rf["kernel"] == "k_group_sort" and rf["bound"] == "hbm" and rf["algorithmic_bytes_per_element"] == 29
     assert [k["name"] for k in rf["kernels"]] == ["k_group_sort", "k_onesweep"] and rf["kernels"][1]["achieved"] > 0
-    assert out0["batch_api"] is None                          # (N = 1 only)
+    assert out0["batch_api"] is None and out0["configs"] is None       # (N = 1 only)
+    # who ran where: one entry per rank, distinct devices, each with its own time and its own verification
+    assert [r["rank"] for r in out0["ranks"]] == [0, 1] and out0["distinct_gpus"] is True
+    assert len({r["pci_bus_id"] for r in out0["ranks"]}) == 2 and all(r["verified"] and r["ms_per_step"] > 0 for r in out0["ranks"])
+    assert out0["ms_per_step"] == pytest.approx(max(r["ms_per_step"] for r in out0["ranks"]), rel=0.05)
     json.dumps(out0)                                          # serialisable as the one line the driver reads
     assert b0 == b1 and b0 >= 2 + 1 + 3                       # first touch + profiled build, warm-up, timed steps -- on every rank
 
@@ -141,8 +150,18 @@ def test_single_rank_path_with_stand_in():
     sys.path.insert(0, ROOT)
     import bench
     args = bench.parse(["--steps", "2", "--warmup", "0", "--workload", "c4_dna_1g", "--n", "30000", "--cpu-sample", "20000",
-                        "--e2e-calls", "1", "--batch-texts", "3", "--small-batch-texts", "40"])
+                        "--e2e-calls", "1", "--batch-texts", "3", "--small-batch-texts", "40", "--configs", "c2_uniform_64m,c5_uniform_512m",
+                        "--config-steps", "2"])
     out = bench.run(args, OracleStandIn(), 0, 1)
+    # the other BASELINE configs ride behind the headline workload, each verified and with its own dominant class
+    cf = out["configs"]
+    assert set(cf) == {"c2_uniform_64m", "c5_uniform_512m", "_seconds"}
+    for name in ("c2_uniform_64m", "c5_uniform_512m"):
+        c = cf[name]
+        assert c["verified"] is True and c["n_bytes"] == 30000 and c["steps"] == 2 and c["MB_per_s"] > 0
+        assert c["roofline"]["kernel"] == "k_group_sort" and c["roofline"]["frac"] > 0 and c["whole_job"]["frac"] > 0
+        assert c["end_to_end"]["fresh_buffer"]["ms"] > 0
+    assert out["ranks"][0]["rank"] == 0 and out["distinct_gpus"] is None
     assert out["n_gpus"] == 1 and out["verified"] is True and out["batch_c5"] is None
     assert out["batch_api"]["texts"] == 3 and out["batch_api"]["verified"] is True and out["batch_api"]["MB_per_s"] > 0
     assert out["batch_api"]["small_texts"]["texts"] == 40 and out["batch_api"]["small_texts"]["verified"] is True

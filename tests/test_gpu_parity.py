@@ -848,7 +848,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_NO_FIRST_TAIL", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_GRAM_TAIL", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
@@ -1047,6 +1047,46 @@ def test_bench_two_ranks_share_one_gpu():
     rf = out["roofline"]
     assert rf["kernel"] == rf["kernels"][0]["name"] and rf["achieved"] > 0          # the class with the most measured time
     assert all(k["ms_per_step"] <= rf["kernels"][0]["ms_per_step"] for k in rf["kernels"])
+    # who ran where: both ranks report the device they used (the same one here, which the line says) and their own check
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and all(r["verified"] for r in out["ranks"])
+    assert out["ranks"][0]["pci_bus_id"] == out["ranks"][1]["pci_bus_id"] is not None and out["distinct_gpus"] is False
+    assert out["ranks"][0]["pid"] != out["ranks"][1]["pid"]
+
+
+def test_bench_refuses_ranks_that_share_a_gpu_unasked():
+    """without SA_BENCH_SHARE_GPU=1 an N > 1 run whose ranks do not sit on N distinct GPUs is an error, not a number: here
+    LOCAL_RANK 0 is forced on both ranks of a real two-rank launch"""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("SA_BENCH_SHARE_GPU", None)
+    env["SA_BENCH_FORCE_LOCAL_RANK"] = "0"
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                           "--workload", "c2_uniform_64m", "--n", str(1 << 20), "--no-end-to-end", "--no-batch"],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert proc.returncode != 0
+    assert "not distinct" in proc.stderr and not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_six_ranks_share_one_gpu():
+    """the N > 1 path with more ranks than the two of the test above (six: the most processes a GPU box lets on its card at
+    once): every rank builds and verifies its own text, one line for the whole job, six entries in ranks[]"""
+    import subprocess
+    import sys
+    env = dict(os.environ, SA_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--steps", "2", "--warmup", "1",
+                           "--workload", "c2_uniform_64m", "--n", str(4 << 20), "--e2e-calls", "1"],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 6 and out["verified"] is True and len(out["ranks"]) == 6
+    assert sorted(r["rank"] for r in out["ranks"]) == list(range(6)) and all(r["verified"] for r in out["ranks"])
+    assert out["value"] == pytest.approx(6 * (4 << 20) / 1e6 / (out["ms_per_step"] / 1e3), rel=1e-3)
+    assert out["batch_c5"]["texts"] == 6 and out["batch_c5"]["verified"] is True
 
 
 def test_bench_single_rank_line_with_batch_api():
@@ -1057,7 +1097,8 @@ def test_bench_single_rank_line_with_batch_api():
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload",
-                           "c3_english_256m", "--n", str(8 << 20), "--e2e-calls", "2", "--batch-texts", "4", "--cpu-sample", str(1 << 20)],
+                           "c3_english_256m", "--n", str(8 << 20), "--e2e-calls", "2", "--batch-texts", "4", "--cpu-sample", str(1 << 20),
+                           "--config-steps", "2"],
                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
     out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0])
@@ -1066,6 +1107,16 @@ def test_bench_single_rank_line_with_batch_api():
     assert out["roofline"]["kernel"] == names[0] and len(names) >= 1
     assert out["batch_api"]["texts"] == 4 and out["batch_api"]["verified"] is True and out["batch_api"]["entry_point"] == "sa_amd_saca_batch"
     assert out["cpu_baseline"]["probe"][0]["step"].startswith("cargo") and out["cpu_baseline"]["pinned_cpu"] is not None
+    # the other BASELINE configs behind the headline workload (here at 8 MiB each): verified, their own dominant class, end to end
+    cf = out["configs"]
+    assert [c for c in cf if not c.startswith("_")] == ["c2_uniform_64m", "c2_uniform_256m", "c4_dna_1g", "c5_uniform_512m"]
+    for name, c in cf.items():
+        if name.startswith("_"):
+            continue
+        assert c["verified"] is True and c["n_bytes"] == 8 << 20 and c["ms_per_build"] > 0, name
+        assert c["roofline"]["kernel"] and 0 < c["roofline"]["frac"] < 1 and c["end_to_end"]["fresh_buffer"]["MB_per_s"] > 0, name
+    assert cf["c4_dna_1g"]["sigma"] == 4 and cf["c2_uniform_64m"]["sigma"] == 256
+    assert out["ranks"][0]["pci_bus_id"] and out["roofline"]["traffic_source"] is None      # (traffic.json is for the full-size text)
 
 
 # ---- next rows: bucket table and integrity check --------------------------------
@@ -1085,6 +1136,49 @@ def test_bucket_table_matches_reference_restatement(oracle):
         got = sa.bucket_table(s, arr)
         assert got.size == 256 * 257 + 1
         assert np.array_equal(got, oracle.bucket_table(s)), name
+
+
+def test_bucket_table_needs_the_text_only(oracle):
+    """the reference's enable_buckets reads the text and nothing else (src/sa.rs:96-116): no suffix array is handed over (NULL),
+    on every tiny length, on a text of all 256 byte values large enough for every pair of workgroups (k_bigram_hist) and on
+    texts of one and two byte values (every count in one or four bins)"""
+    L = sa.lib()
+    rng = np.random.default_rng(77)
+    cases = [np.zeros(0, dtype=np.uint8)] + [rng.integers(0, 256, size=k, dtype=np.uint8) for k in (1, 2, 3, 15, 16, 17, 18, 31, 33, 255, 4097)]
+    cases += [corpus.uniform((40 << 20) + 13, 21), np.full(3_000_001, 255, dtype=np.uint8), (rng.integers(0, 2, size=5_000_003) * 255).astype(np.uint8),
+              corpus.english_corpus(9_000_001, 5)]
+    for t in cases:
+        bkt = np.zeros(256 * 257 + 1, dtype=np.uint32)
+        assert L.sa_amd_bucket_table(t.ctypes.data if t.size else None, t.size, None, bkt.ctypes.data) == 0
+        assert np.array_equal(bkt, oracle.bucket_table(t)), t.size
+        assert int(bkt[-1]) == t.size + 1
+
+
+def test_bucket_table_device_form_on_unaligned_texts(oracle):
+    """sa_amd_bucket_table_device with dSA == NULL (bigram counts) takes the text at any byte offset: 16-byte loads from the
+    first aligned address, bytes in front of and behind them; with a suffix array it answers by binary search -- same table"""
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    L = sa.lib()
+    for t in (corpus.english(300_007, 3), corpus.uniform(1_000_003, 5), corpus.uniform(37, 6), corpus.dna(70_001, 4)):
+        n = int(t.size)
+        exp = oracle.bucket_table(t)
+        arr = oracle.sais(t)
+        dt, db, ds = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dt), n + 64) == 0 and hip.hipMalloc(ctypes.byref(db), 4 * (256 * 257 + 1)) == 0
+        assert hip.hipMalloc(ctypes.byref(ds), 4 * (n + 1)) == 0
+        assert hip.hipMemcpy(ds.value, arr.ctypes.data, 4 * (n + 1), 1) == 0
+        for off in (0, 1, 7, 15):
+            assert hip.hipMemcpy(dt.value + off, t.ctypes.data, n, 1) == 0
+            for dsa in (None, ds.value):
+                got = np.zeros(256 * 257 + 1, dtype=np.uint32)
+                assert L.sa_amd_bucket_table_device(dt.value + off, dsa, n, db.value, None) == 0
+                assert hip.hipMemcpy(got.ctypes.data, db.value, got.nbytes, 2) == 0
+                assert np.array_equal(got, exp), (n, off, dsa is None)
+        for q in (dt, db, ds):
+            hip.hipFree(q)
 
 
 def test_enable_buckets_on_constructed_array(oracle):
