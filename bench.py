@@ -606,7 +606,7 @@ def run(args, backend, rank, world, dist=None, share=False):
         dist.all_gather_object(ranks, mine)
     bus_ids = [r.get("pci_bus_id") for r in ranks]
     distinct = len(set(bus_ids)) == len(bus_ids) and None not in bus_ids
-    if world > 1 and not share and not distinct and os.environ.get("SA_BENCH_SHARE_GPU") != "1":
+    if world > 1 and not distinct and os.environ.get("SA_BENCH_SHARE_GPU") != "1":
         raise SystemExit(f"bench.py: {world} ranks but their GPUs are not distinct ({bus_ids}); SA_BENCH_SHARE_GPU=1 allows a rehearsal")
 
     e2e = None
