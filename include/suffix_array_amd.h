@@ -80,6 +80,8 @@ typedef struct sa_amd_stats {
     int32_t text_rounds;      /* of `rounds`: text-keyed rounds (secondary key read from the text, no rank array) */
     int32_t top32_first;      /* 1: the entropy probe chose to sort on the top 32 key bits first and finish the ties locally */
     int64_t locally_sorted;   /* tied suffixes refined by the in-LDS group sort instead of the global radix sort */
+    int32_t readbacks;        /* blocking device -> host read-backs of counters during the build (each one drains the stream) */
+    int32_t reserved;
 } sa_amd_stats;
 
 /* bytes of device scratch sa_amd_saca_device needs for a text of n bytes */

@@ -44,7 +44,8 @@ class Stats(ctypes.Structure):
                 ("symbols_per_key", ctypes.c_int32), ("rounds", ctypes.c_int32),
                 ("sort_passes", ctypes.c_int32), ("sparse_mode", ctypes.c_int32),
                 ("sorted_elements", ctypes.c_int64), ("unresolved_after_initial", ctypes.c_int64),
-                ("text_rounds", ctypes.c_int32), ("top32_first", ctypes.c_int32), ("locally_sorted", ctypes.c_int64)]
+                ("text_rounds", ctypes.c_int32), ("top32_first", ctypes.c_int32), ("locally_sorted", ctypes.c_int64),
+                ("readbacks", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

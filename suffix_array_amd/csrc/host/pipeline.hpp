@@ -126,9 +126,10 @@ static Workspace carve(void *base, int64_t n)
 
 // ------------------------------------------------------------------------------------------
 // Single-pass tile scatter (kernels/onesweep.hpp): host side of one LSD sort.
-// Scratch inside the spine slab: two ZONES of OS_ZONE words, zone = [OS_TICKETS ticket words | RADIX * OS_NSEG segment counts].
-// Pass p reads its digit's counts from zone z and writes the next digit's counts -- and takes its tickets -- in zone z ^ 1,
-// which the host zeroes right before the launch.
+// Scratch inside the spine slab: ZONES of OS_ZONE words, zone = [OS_TICKETS ticket words | RADIX * OS_NSEG segment counts].
+// Pass p reads its digit's counts from zone z and writes the next digit's counts -- and takes its tickets -- in zone z + 1.
+// Every pass has a zone of its own and ONE memset in front of the sort zeroes them all (a memset per pass was a 5 us launch
+// per pass: eight of them in the initial sort of a 1 MiB text, whose passes take 40 us).
 // ------------------------------------------------------------------------------------------
 // Tile shapes (threads, keys per thread, values through the keys' LDS buffer, workgroups per CU).  SA_AMD_ONESWEEP64_SHAPE /
 // SA_AMD_ONESWEEP32_SHAPE select one for A/B measurements; every shape sorts correctly.
@@ -143,7 +144,8 @@ constexpr int OS_TICKETS = 64;                 // words in front of a zone's cou
 constexpr int OS_MAX_RADIX = 512;              // widest digit of the single-pass scatter (9 bits: the two passes in front of the bucket sort of large texts)
 constexpr int OS_ZONE = OS_TICKETS + OS_MAX_RADIX * OS_NSEG;  // words
 static_assert(OS_NSEG <= OS_TICKETS, "one ticket word per segment");
-static_assert(2 * OS_ZONE <= RADIX * SORT_MAX_WG, "both zones live in the spine slab");
+constexpr int OS_MAX_ZONES = 2 * 8 + 2;         // eight passes, each possibly behind a skipped one that needed a recount, + the producer's zone
+static_assert(OS_MAX_ZONES * OS_ZONE <= RADIX * SORT_MAX_WG, "the zones live in the spine slab");
 
 static bool onesweep_on(const SortScratch &ss, const Tuning &tn) { return ss.status != nullptr && !tn.no_onesweep; }
 
@@ -199,10 +201,18 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
     static_assert(TILE >= OS_MIN_TILE, "the granule slab is sized for tiles of at least OS_MIN_TILE elements");
     constexpr bool K64 = sizeof(KeyT) == 8;
     const OnesweepGeom g = onesweep_geom(count, TILE);
-    uint32_t *zone[2] = { ss.spine, ss.spine + OS_ZONE };
+    auto zone = [&](int i) { return ss.spine + (size_t)i * OS_ZONE; };
     int z = 0;                                    // zone that holds (or will hold) the counts of the coming pass's digit
     bool have_counts = first_counted;
     HIP_TRY(hipMemsetAsync(ss.status, 0, (size_t)g.tiles * R * 8, st));
+    {
+        // zone 0 holds the producer's counts (first_counted) and stays; everything behind it starts from zero
+        const int npass = (int)ceil_div(end_bit - begin_bit, RBITS);
+        int zones = (may_skip ? 2 * npass : npass) + 1;
+        if (zones > OS_MAX_ZONES) return SA_AMD_EINTERNAL;
+        const int z0 = first_counted ? 1 : 0;
+        HIP_TRY(hipMemsetAsync(zone(z0), 0, (size_t)(zones - z0) * OS_ZONE * 4, st));
+    }
     KeyT *kin = keys_in, *kout = keys_alt;
     uint32_t *vin = vals_in, *vout = vals_alt;
     constexpr int WG_PER_CU = THREADS <= 512 ? 2 : 1;
@@ -217,32 +227,31 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         if (!have_counts) {
             if (RBITS != RADIX_BITS) return SA_AMD_EINTERNAL;     // (the counting kernels have 256 bins: a wide-digit sort gets its first counts from the producer of the keys)
             // one read of the keys for the counts of this digit (first pass of a sort whose producer did not count, or the
-            // pass after a skipped one)
-            HIP_TRY(hipMemsetAsync(zone[z], 0, (size_t)OS_ZONE * 4, st));
+            // pass after a skipped one); zone z is still zero
             int split = 2048 / g.nseg;
             while (split > 1 && g.seg_elems / split < 8192) split /= 2;
             const int64_t sub = K64 ? ((ceil_div(g.seg_elems, split) + 1) & ~(int64_t)1) : ((ceil_div(g.seg_elems, split) + 3) & ~(int64_t)3);
             if (K64)
                 PROF(KC_UPSWEEP, count, st, hipLaunchKernelGGL((k_radix_upsweep), dim3(g.nseg * split), dim3(SORT_THREADS), 0, st, (const uint64_t *)kin,
-                                                               zone[z] + OS_TICKETS, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
+                                                               zone(z) + OS_TICKETS, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
             else
                 PROF(KC_UPSWEEP32, count, st, hipLaunchKernelGGL((k_radix_upsweep32), dim3(g.nseg * split), dim3(SORT_THREADS), 0, st, (const uint32_t *)kin,
-                                                                 zone[z] + OS_TICKETS, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
+                                                                 zone(z) + OS_TICKETS, count, shift, dmask, g.seg_elems, g.nseg, split, sub));
         }
         if (RBITS == RADIX_BITS && may_skip && !tn.no_run_skip && count >= tn.run_skip_min && !(iota && *passes == 0) && !(last && final_vals)) {
             // a digit that is the same for EVERY element makes the pass the identity (the sort is stable): skip it
-            hipLaunchKernelGGL(k_os_digit_totals, dim3(1), dim3(RADIX), 0, st, (const uint32_t *)(zone[z] + OS_TICKETS), g.nseg, ss.digit_tot);
+            hipLaunchKernelGGL(k_os_digit_totals, dim3(1), dim3(RADIX), 0, st, (const uint32_t *)(zone(z) + OS_TICKETS), g.nseg, ss.digit_tot);
             LAUNCH_CHECK(st);
             uint32_t tot[RADIX];
             { const int rcw = read_words(tot, ss.digit_tot, sizeof(tot), st); if (rcw) return rcw; }
             bool constant = false;
             for (int d = 0; d < RADIX; ++d) constant |= (int64_t)tot[d] == count;
-            if (constant) { ++*skipped; have_counts = false; continue; }
+            if (constant) { ++*skipped; have_counts = false; ++z; continue; }     // (zone z holds the skipped digit's counts: the recount takes the next, clean one)
         }
         OnesweepPass P;
-        P.hist_cur = zone[z] + OS_TICKETS;
-        P.hist_next = last ? nullptr : zone[z ^ 1] + OS_TICKETS;
-        P.tickets = zone[z ^ 1];
+        P.hist_cur = zone(z) + OS_TICKETS;
+        P.hist_next = last ? nullptr : zone(z + 1) + OS_TICKETS;
+        P.tickets = zone(z + 1);
         P.status = ss.status;
         P.err = ss.err;
         P.n = count;
@@ -253,7 +262,6 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         P.epoch = ++epoch;
         P.flags = (uint32_t)tn.onesweep_flags;
         P.text = text; P.text_n = text_n; P.text_bits = text_bits;
-        HIP_TRY(hipMemsetAsync(zone[z ^ 1], 0, (size_t)OS_ZONE * 4, st));
         if (!K64 && !SEQ && text && *passes == 0)
             PROF(KC_ONESWEEP32, count, st,
                  hipLaunchKernelGGL((k_onesweep<THREADS, ITEMS, KeyT, SEQ, WG_PER_CU, RBITS, !K64 && !SEQ>), dim3(grid), dim3(THREADS), 0, st, (const KeyT *)kin,
@@ -267,7 +275,7 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         vin = vdst;
         vout = free_v;
         ++*passes;
-        z ^= 1;
+        ++z;
         have_counts = !last;
     }
     *keys_res = kin; *vals_res = vin;
@@ -587,8 +595,10 @@ struct PinnedWords {
     ~PinnedWords() { if (b.p) pool().release_pinned(b); }
 };
 static thread_local PinnedWords g_pinned;
+static thread_local int g_readbacks = 0;        // blocking read-backs of the calling thread's current build (sa_amd_stats.readbacks)
 static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)     // bytes <= 4096; synchronises the stream
 {
+    ++g_readbacks;
     if (!g_pinned.b.p && !g_pinned.failed && pool().pinned(4096, -1, -1, &g_pinned.b) != SA_AMD_OK) g_pinned.failed = true;
     if (!g_pinned.b.p) {
         HIP_TRY(hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, st));
@@ -665,6 +675,26 @@ static int scatter_binned(uint32_t *pk, uint32_t *pv, uint32_t *altk, uint32_t *
 
 struct Refined { const uint64_t *keys; const uint32_t *vals; uint32_t *vnext; int64_t m_global; };   // m_global: members ordered by the global sort
 
+// Read-backs of a refinement round (DeviceBuild::doubling_rounds).  A round used to block twice: once in the middle for the number
+// of members the local pass could not order (they go through the global sort before the re-rank) and once at its end for the
+// number still tied.  From the second round of a kind on nearly every round has NO such members, so the caller may ask
+// refine_list to DEFER the first question: the local pass and its counting kernels are launched, the count stays on the device
+// (w.total[RC_FLAGGED]) and the re-rank kernels behind it are launched GATED on it -- they do nothing when it is not zero.
+// One read-back at the end of the round then answers both; in the rare round that did have such members the caller calls
+// refine_list again with the words it read (resume_tot), which runs the global sort of those members, and launches the
+// re-rank kernels ungated.
+constexpr int RC_FLAGGED = 16, RC_GROUPS = 8, RC_BIG_LISTED = 12, RC_BIG_ORDERED = 13, RC_WORDS = 17;      // words of w.total
+constexpr int RC_BIG_LISTED_SAVED = 14, RC_BIG_ORDERED_SAVED = 15;     // ... where k_rr_scan_round puts the two big-group counters before it zeroes them for the next round
+struct RoundCtl {
+    bool defer = false;                    // in: do not read the local pass's counts back, return right behind its launches
+    const uint32_t *resume_tot = nullptr;  // in: the counts (RC_WORDS words of w.total) of a deferred call that did have flagged members
+    bool skip_big = false;                 // in: no group can be larger than GS_CAP any more: k_group_sort_big is not launched
+    bool counters_clear = false;           // in: the previous round's k_rr_scan_round has zeroed w.total[RC_BIG_LISTED .. +1]
+    bool deferred = false;                 // out: the counts were left on the device
+    int64_t m_flagged = -1;                // out: members the local pass left to the global sort (-1: no local pass ran)
+    int64_t big_listed = -1;               // out: groups listed for k_group_sort_big (-1: not looked for)
+};
+
 // Three-way split of giant groups around their majority key (kernels/refine.hpp, k_split_*): the keys in rkA carry the dense
 // group index above bit kb, w.ft_cnt the exclusive group-start counts per tile.  *taken = false: the count pass found more
 // than an eighth of the members off their group's pivot key (or the scratch buffers too small) -- nothing has been changed,
@@ -733,8 +763,10 @@ static int split_giant_groups(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint
 static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *Valt, const uint32_t *Ucur, const uint32_t *Gcur,
                        uint32_t *scratchU, uint32_t *scratchG, int64_t m, int64_t n, const uint8_t *dT, const KeyParams &P,
                        const KeySrc &K, int g_bits, bool *local_ok, const Workspace &w, hipStream_t st, sa_amd_stats *local,
-                       Refined *out, const Tuning &tn, bool retry_local = false, int *split_rest = nullptr)   // split_rest: rounds the three-way split sits out after its count pass found no majority
+                       Refined *out, const Tuning &tn, bool retry_local = false, int *split_rest = nullptr,   // split_rest: rounds the three-way split sits out after its count pass found no majority
+                       RoundCtl *ctl = nullptr)
 {
+    const bool resume = ctl && ctl->resume_tot;
     const int64_t tiles = ceil_div(m, RR_TILE);
     const int kb = K.kb;
     SortResult sr;
@@ -760,9 +792,11 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         const int cap = tn.group_cap;                    // largest group ordered in LDS (C3: 1024 beats 512 by 1%)
         // groups of up to GB_CAP (8 192) members whose keys fit 32 bits: one workgroup each, in LDS (k_group_sort_big), on the list of
         // their first members that k_group_sort writes (scratchU is free until k_flag_gather); the rest goes through the global sort
-        const bool big_local = !tn.no_big_group_sort && kb <= 32 && m > GS_CAP;
-        uint32_t *bheads = big_local ? scratchU : (uint32_t *)nullptr, *bcount = big_local ? w.total + 12 : (uint32_t *)nullptr;
-        HIP_TRY(hipMemsetAsync(w.total + 12, 0, 8, st));           // [12] listed first members, [13] members ordered by k_group_sort_big
+        const bool big_local = !tn.no_big_group_sort && kb <= 32 && m > GS_CAP && !(ctl && ctl->skip_big);
+        uint32_t *bheads = big_local ? scratchU : (uint32_t *)nullptr, *bcount = big_local ? w.total + RC_BIG_LISTED : (uint32_t *)nullptr;
+        if (!resume) {
+        if (!(ctl && ctl->counters_clear))
+            HIP_TRY(hipMemsetAsync(w.total + RC_BIG_LISTED, 0, 8, st));           // [12] listed first members, [13] members ordered by k_group_sort_big
         if (K.mode == KS_TEXT)
             PROF(KC_LOCAL, m, st, hipLaunchKernelGGL((k_group_sort<KS_TEXT>), dim3(gs_blocks), dim3(GS_THREADS), 0, st, (const uint32_t *)Vcur,
                                                      Gcur, Ucur, dT, P, m, n, K, rkA, Vcur, flags, cap, bheads, bcount));
@@ -796,11 +830,23 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
         }
         PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_flag_count), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                     (const uint8_t *)flags, Ucur, Gcur, m, w.tcnt, w.ft_cnt));
-        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.thead, tiles, w.total + 8));
-        uint32_t tot9[14] = { 0 };                            // [0] flagged members, [8] flagged groups, [13] members k_group_sort_big ordered
-        { const int rcw = read_words(tot9, w.total, sizeof(tot9), st); if (rcw) return rcw; }
-        const int64_t m_big = tot9[0], m_big_local = tot9[13];
+        // (flagged members -> w.total[RC_FLAGGED], flagged groups -> w.total[RC_GROUPS]; one launch)
+        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan_pair), dim3(2), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, w.total + RC_FLAGGED,
+                                                       w.ft_cnt, (uint32_t *)nullptr, w.total + RC_GROUPS, tiles));
+        }
+        if (ctl && ctl->defer && !resume) {
+            // the counts stay on the device: the caller launches the re-rank kernels gated on w.total[RC_FLAGGED] and reads everything at once
+            ctl->deferred = true;
+            out->keys = rkA; out->vals = Vcur; out->vnext = Valt; out->m_global = 0;
+            return SA_AMD_OK;
+        }
+        uint32_t tot9[RC_WORDS] = { 0 };                      // [RC_FLAGGED] flagged members, [RC_GROUPS] flagged groups, [RC_BIG_ORDERED] members k_group_sort_big ordered
+        if (resume) memcpy(tot9, ctl->resume_tot, sizeof(tot9));
+        else {
+            const int rcw = read_words(tot9, w.total, sizeof(tot9), st); if (rcw) return rcw;
+            }
+        const int64_t m_big = tot9[RC_FLAGGED], m_big_local = tot9[RC_BIG_ORDERED];
+        if (ctl) { ctl->m_flagged = m_big; ctl->big_listed = big_local ? (int64_t)tot9[RC_BIG_LISTED] : -1; }
         // the flagged members are sorted in the first `half` entries of rkB / Valt with the second half as the alternate
         // buffers: half is even (16-byte aligned 8-byte keys) and half + m_big never exceeds the n entries the slabs hold
         const size_t half = ((size_t)n / 2) & ~(size_t)1;
@@ -808,7 +854,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
             if (m_big > 0) {
                 // groups no tile owns: global sort of (index of the group among them, key2), then back to their list positions
                 // (a text that is one long run has ONE such group: no index bits at all, four passes instead of eight)
-                const int idx_bits = bit_length((uint64_t)(tot9[8] > 0 ? tot9[8] - 1 : 0));
+                const int idx_bits = bit_length((uint64_t)(tot9[RC_GROUPS] > 0 ? tot9[RC_GROUPS] - 1 : 0));
                 PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_flag_gather), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
                                                             (const uint8_t *)flags, (const uint64_t *)rkA, (const uint32_t *)Vcur, Ucur, Gcur, m,
                                                             (const uint32_t *)w.tcnt, (const uint32_t *)w.ft_cnt, kb, rkB, Valt, scratchU));
@@ -838,7 +884,7 @@ static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *V
                                                         (const uint8_t *)nullptr, Ucur, Gcur, m, w.tcnt, w.ft_cnt));
             PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.ft_cnt, w.thead, tiles, w.total + 8));
             { const int rcw = read_words(&groups, w.total + 8, 4, st); if (rcw) return rcw; }
-        }
+            }
         const int idx_bits = bit_length((uint64_t)(groups > 0 ? groups - 1 : 0));
         if (ceil_div(kb + idx_bits, RADIX_BITS) < ceil_div(kb + g_bits, RADIX_BITS)) {
             sort_bits = kb + idx_bits;
@@ -987,6 +1033,8 @@ struct DeviceBuild {
     bool lists_ready = false, finished32 = false, fused64 = false, sparse = false;
     bool isa_tail_ranks = false;        // the rank set-up of the dense route wrote tail ranks (k_rr_apply FTAIL)
     int s_sym = 0, tkb = 0, key2_bits = 0;
+    bool prev_clean = true;             // the last refinement round's local pass ordered every member (optimistic for the first one: a miss costs three empty launches)
+    int deferred_misses = 0;            // rounds that deferred their mid-round read-back and did have members for the global sort (RoundCtl)
 
 
     // Bucket sort of the 32-bit first stage: which key bits do the global passes order?  16 (two passes of 8 bits) when an average
@@ -1527,26 +1575,45 @@ struct DeviceBuild {
             // ---- text-keyed rounds ----
             bool progressing = true;     // a text round that resolves little (runs, long repeats) is the last one
 
+            bool counters_clear = false;      // (RoundCtl: one read-back per round while the rounds have nothing for the global sort)
             while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < tn.max_text_rounds && progressing) {
                 const int64_t m_before = m;
                 uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
                 Refined rf;
                 KeySrc K = KeySrc(); K.mode = KS_TEXT; K.h = depth; K.s = s_sym; K.kb = tkb;
-                rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, Ptext, K, g_bits, &local_ok, w, st, &local, &rf, tn);
+                RoundCtl ctl;
+                ctl.defer = prev_clean && local_ok && !tn.no_defer;
+                ctl.counters_clear = counters_clear;
+                rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, Ptext, K, g_bits, &local_ok, w, st, &local, &rf, tn, false, nullptr, &ctl);
                 if (rc) return rc;
-                const uint64_t *keysS = rf.keys;                  // (group, text key) pairs ordered inside every group
-                const uint32_t *valsS = rf.vals;
+                uint32_t words[RC_WORDS];
+                for (int attempt = 0; ; ++attempt) {
+                    const uint32_t *gate = ctl.deferred ? (const uint32_t *)(w.total + RC_FLAGGED) : (const uint32_t *)nullptr;
+                    tiles = ceil_div(m, RR_TILE);
+                    PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, rf.keys,
+                                                                (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0, gate));
+                    PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan_round), dim3(2), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total,
+                                                                   (uint32_t *)nullptr, (uint32_t *)nullptr, w.total + RC_BIG_LISTED, gate));
+                    PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                                rf.keys, rf.vals, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
+                                                                (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, rf.vnext,
+                                                                (uint32_t)n, (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                                                (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr, gate));
+                    { const int rcw = read_words(words, w.total, sizeof(words), st); if (rcw) return rcw; }
+                    if (!ctl.deferred) break;
+                    if (words[RC_FLAGGED] == 0) { ctl.m_flagged = 0; local.locally_sorted += m; break; }
+                    if (attempt > 0) return SA_AMD_EINTERNAL;
+                    uint32_t tot[RC_WORDS];
+                    memcpy(tot, words, sizeof(tot));
+                    ctl.resume_tot = tot; ctl.defer = false; ctl.deferred = false;
+                    rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, Ptext, K, g_bits, &local_ok, w, st, &local, &rf, tn, false, nullptr, &ctl);
+                    if (rc) return rc;
+                    ctl.resume_tot = nullptr;
+                }
+                prev_clean = ctl.m_flagged == 0;
+                counters_clear = true;
                 uint32_t *Vnext = rf.vnext;
-                tiles = ceil_div(m, RR_TILE);
-                PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS,
-                                                            (const uint32_t *)Ucur, m, w.tcnt, w.thead, 0, (uint32_t *)nullptr, 0));
-                PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 3>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                            keysS, valsS, (const uint32_t *)Ucur, m, (const uint32_t *)w.tcnt,
-                                                            (const uint32_t *)w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                            (uint32_t)n, (uint32_t *)nullptr, 0, (uint64_t *)nullptr, (uint32_t *)nullptr,
-                                                            (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
-                { const int rcw = read_words(&m32, w.total, 4, st); if (rcw) return rcw; }
+                m32 = words[0];
                 m = m32;
                 uint32_t *t;
                 t = Ucur; Ucur = Unext; Unext = t;
@@ -1601,6 +1668,9 @@ struct DeviceBuild {
         int64_t changed_prev = isa_tail_ranks ? m : 0;    // ranks the last dense round wrote (none yet: expect every rank to change)
         int64_t m_local_off = m;                          // size of the tied list when the local pass was last in use
         int rounds_local_off = 0;
+        // read-backs (RoundCtl): a round whose predecessor had nothing for the global sort defers that question and blocks ONCE
+        bool all_small = false;                           // ... and listed no group for k_group_sort_big: no group is larger than GS_CAP any more
+        bool counters_clear = false;                      // the previous round's k_rr_scan_round zeroed the big-group counters
         while (m > 0) {
             if (local.rounds >= 48) return SA_AMD_EINTERNAL;
             uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
@@ -1621,56 +1691,87 @@ struct DeviceBuild {
             K.has_isa = w.has_isa; K.sorted_keys = sorted0; K.sorted_top32 = sorted32; K.sa = SA; K.depth = depth_text; K.top_shift = top_shift;
             Refined rf;
             if (local_ok) { m_local_off = m; rounds_local_off = 0; }
-            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn, retry_local, &split_rest);
-            if (rc) return rc;
-            if (retry_local && rf.m_global < m) { m_local_off = m; rounds_local_off = 0; }      // (the local pass ran again)
-            const uint64_t *keysS = rf.keys; const uint32_t *valsS = rf.vals; uint32_t *Vnext = rf.vnext;
-            tiles = ceil_div(m, RR_TILE);
-            // dense rounds: a group's rank is its last slot + 1 and a parent's last subgroup keeps it (k_rr_apply, TAIL); the tiles
-            // then also need the first group start BEHIND them (k_rr_scan_next)
-            if (sparse)
-                PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m, w.tcnt,
-                                   w.thead, 0, (uint32_t *)nullptr, 0));
-            else
-                PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false, uint64_t, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m,
-                                   w.tcnt, w.thead, 0, w.tnext, key2_bits));
-            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
-            if (!sparse)
-                PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan_next), dim3(1), dim3(SPINE_THREADS), 0, st, w.tnext, tiles, w.chg));
             // binned or direct ISA stores: by the number of ranks this round is expected to write -- all of them when the parents'
             // ranks are not tail ranks yet, otherwise about as many as the round before wrote
             const int64_t expect = (!parent_tail || m < changed_prev) ? m : changed_prev;
-            if (sparse) {
-                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                            keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                            (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr));
-            } else if (binned(n, expect, tn)) {
-                // Gcur has been consumed by the gather, the other key buffer by nothing: they take the pairs
-                uint64_t *pk = (keysS == rkA) ? rkB : rkA;
-                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                            keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                            (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total, 0,
-                                                            (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg));
-                // (only the ranks that change became pairs; their number is in the counters)
-                uint32_t chg[RR_CHG_COUNTERS * 32];
-                { const int rcw = read_words(chg, w.chg, sizeof(chg), st); if (rcw) return rcw; }
-                int64_t pairs = 0;
-                for (int c = 0; c < RR_CHG_COUNTERS; ++c) pairs += chg[c * 32];
-                if (pairs > 0) {
-                    rc = scatter_binned((uint32_t *)pk, Gcur, (uint32_t *)keysS, (uint32_t *)valsS, pairs, n, w, st, &local, tn);
-                    if (rc) return rc;
+            const bool bin = !sparse && binned(n, expect, tn);
+            RoundCtl ctl;
+            ctl.defer = prev_clean && !bin && local_ok && !tn.no_defer;
+            ctl.skip_big = all_small;
+            ctl.counters_clear = counters_clear;
+            rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn, retry_local, &split_rest, &ctl);
+            if (rc) return rc;
+            uint32_t words[64 + RR_CHG_COUNTERS * 32];
+            for (int attempt = 0; ; ++attempt) {
+                if (retry_local && rf.m_global < m) { m_local_off = m; rounds_local_off = 0; }      // (the local pass ran again)
+                const uint64_t *keysS = rf.keys; const uint32_t *valsS = rf.vals; uint32_t *Vnext = rf.vnext;
+                const uint32_t *gate = ctl.deferred ? (const uint32_t *)(w.total + RC_FLAGGED) : (const uint32_t *)nullptr;
+                tiles = ceil_div(m, RR_TILE);
+                // dense rounds: a group's rank is its last slot + 1 and a parent's last subgroup keeps it (k_rr_apply, TAIL); the tiles
+                // then also need the first group start BEHIND them (k_rr_scan_next, second block of k_rr_scan_round)
+                if (sparse)
+                    PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m, w.tcnt,
+                                       w.thead, 0, (uint32_t *)nullptr, 0, gate));
+                else
+                    PROF(KC_RR_COUNT, m, st, hipLaunchKernelGGL((k_rr_count<false, uint64_t, true>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st, keysS, Ucur, m,
+                                       w.tcnt, w.thead, 0, w.tnext, key2_bits, gate));
+                PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan_round), dim3(2), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total,
+                                                               sparse ? (uint32_t *)nullptr : w.tnext, sparse ? (uint32_t *)nullptr : w.chg, w.total + RC_BIG_LISTED, gate));
+                if (sparse) {
+                    PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 1>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                                keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                                (uint32_t)n, w.has_isa, key2_bits, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)w.total, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr, gate));
+                } else if (bin) {
+                    // Gcur has been consumed by the gather, the other key buffer by nothing: they take the pairs
+                    uint64_t *pk = (keysS == rkA) ? rkB : rkA;
+                    PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 2>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                                keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                                (uint32_t)n, (uint32_t *)nullptr, key2_bits, pk, Gcur, (const uint32_t *)w.total, 0,
+                                                                (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg));
+                    // (only the ranks that change became pairs; their number is in the counters -- read together with the round's
+                    // other results: the one read-back of this round)
+                    { const int rcw = read_words(words, w.total, sizeof(words), st); if (rcw) return rcw; }
+                    int64_t pairs = 0;
+                    for (int c = 0; c < RR_CHG_COUNTERS; ++c) pairs += words[64 + c * 32];
+                    if (pairs > 0) {
+                        rc = scatter_binned((uint32_t *)pk, Gcur, (uint32_t *)keysS, (uint32_t *)valsS, pairs, n, w, st, &local, tn);
+                        if (rc) return rc;
+                    }
+                    break;
+                } else {
+                    PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
+                                                                keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
+                                                                (uint32_t)n, (uint32_t *)nullptr, key2_bits, (uint64_t *)nullptr,
+                                                                (uint32_t *)nullptr, (const uint32_t *)w.total, 0,
+                                                                (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg, gate));
                 }
-            } else {
-                PROF(KC_RR_APPLY, m, st, hipLaunchKernelGGL((k_rr_apply<false, true, 0>), dim3((unsigned)tiles), dim3(RR_THREADS), 0, st,
-                                                            keysS, valsS, Ucur, m, w.tcnt, w.thead, SA, w.isa, Unext, Gnext, Vnext,
-                                                            (uint32_t)n, (uint32_t *)nullptr, key2_bits, (uint64_t *)nullptr,
-                                                            (uint32_t *)nullptr, (const uint32_t *)w.total, 0,
-                                                            (const uint32_t *)w.tnext, parent_tail ? 1 : 0, w.chg));
-            }
-            {
                 // w.total (64 words) and the changed-rank counters behind it (w.chg) in one read-back
-                uint32_t words[64 + RR_CHG_COUNTERS * 32];
-                const int rcw = read_words(words, w.total, sparse ? 4 : sizeof(words), st); if (rcw) return rcw;
+                { const int rcw = read_words(words, w.total, sparse ? (size_t)RC_WORDS * 4 : sizeof(words), st); if (rcw) return rcw; }
+                if (!ctl.deferred) break;
+                if (words[RC_FLAGGED] == 0) {
+                    // as expected: the local pass ordered everything (what k_group_sort_big ordered was not chased: one look-up)
+                    ctl.m_flagged = 0;
+                    ctl.big_listed = ctl.skip_big ? -1 : (int64_t)words[RC_BIG_LISTED_SAVED];
+                    rf.m_global = words[RC_BIG_ORDERED_SAVED];
+                    local.locally_sorted += m;
+                    break;
+                }
+                // the gated launches did nothing: the flagged members go through the global sort now (refine_list picks up behind its
+                // local pass with the counts just read), then the same re-rank kernels run ungated
+                if (attempt > 0) return SA_AMD_EINTERNAL;
+                uint32_t tot[RC_WORDS];
+                memcpy(tot, words, sizeof(tot));
+                ctl.resume_tot = tot; ctl.defer = false; ctl.deferred = false;
+                rc = refine_list(rkA, rkB, Vcur, Valt, Ucur, Gcur, Unext, Gnext, m, n, dT, P, K, g_bits, &local_ok, w, st, &local, &rf, tn, retry_local, &split_rest, &ctl);
+                if (rc) return rc;
+                ctl.resume_tot = nullptr;
+                ++deferred_misses;
+            }
+            uint32_t *Vnext = rf.vnext;
+            prev_clean = ctl.m_flagged == 0;
+            if (prev_clean && (ctl.big_listed == 0 || m <= GS_CAP)) all_small = true;
+            counters_clear = true;                        // (k_rr_scan_round ran ungated in the end)
+            {
                 m32 = words[0];
                 if (!sparse) {
                     changed_prev = 0;
@@ -1704,6 +1805,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     B.trace = env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 3;      // one line per refinement round on stderr
     B.trace_t = now_ms();
     memset(&B.local, 0, sizeof(B.local));
+    g_readbacks = 0;
     const Tuning &tn = B.tn;
     sa_amd_stats &local = B.local;
     if (n == 0) {
@@ -1724,6 +1826,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         uint32_t rounds = 0;
         { const int rcw = read_words(&rounds, w.total, 4, st); if (rcw) return rcw; }
         local.rounds = (int)rounds;
+        local.readbacks = g_readbacks;
         g_prof.resolve();
         g_last_stats = local;
         if (stats) *stats = local;
@@ -1747,6 +1850,8 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         const int rcw = read_words(gave_up, w.os_err, 16, st); if (rcw) return rcw;
         if (gave_up[0] || gave_up[3]) return SA_AMD_EINTERNAL;
     }
+    local.readbacks = g_readbacks;
+    if (B.trace) fprintf(stderr, "suffix_array_amd: %d blocking read-backs in this build (%d rounds deferred their mid-round count and had to run the global sort after all)\n", g_readbacks, B.deferred_misses);
     g_prof.resolve();
     g_last_stats = local;
     if (stats) *stats = local;

@@ -106,9 +106,11 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_count(const KeyT *__restrict_
                                                           const uint32_t *__restrict__ U, int64_t m,
                                                           uint32_t *__restrict__ tile_cnt,
                                                           uint32_t *__restrict__ tile_head, int key_shift,
-                                                          uint32_t *__restrict__ tile_first, int g_shift)
+                                                          uint32_t *__restrict__ tile_first, int g_shift,
+                                                          const uint32_t *__restrict__ gate = nullptr)      // != nullptr: the launch does nothing when *gate != 0 (see RoundCtl, host/pipeline.hpp)
 {
     __shared__ uint32_t wcnt[RR_THREADS / WAVE], whead[RR_THREADS / WAVE], wfirst[RR_THREADS / WAVE];
+    if (gate && *gate) return;
     const int64_t wbase = (int64_t)blockIdx.x * RR_TILE + (int64_t)wave_id() * RR_WAVE_ELEMS;
     uint64_t kk[RR_ITEMS + 1];
     const WaveGroups g = rr_wave_classify<KeyT, false>(keys, m, wbase, key_shift, 0, PARENTS ? kk : nullptr);
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_count(const KeyT *__restrict_
 
 // one workgroup: tile_first (head code of every tile's first group start) -> for every tile the smallest code of the tiles
 // BEHIND it (RR_NO_HEAD: no group starts behind this tile); also clears the round's changed-rank counter
-__global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan_next(uint32_t *__restrict__ tile_first, int64_t tiles, uint32_t *__restrict__ changed_cnt)
+__device__ __forceinline__ void rr_scan_next_body(uint32_t *__restrict__ tile_first, int64_t tiles, uint32_t *__restrict__ changed_cnt)
 {
     __shared__ uint32_t s_min[SPINE_THREADS];
     const int t = threadIdx.x;
@@ -179,12 +181,17 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan_next(uint32_t *__rest
     if (t < RR_CHG_COUNTERS && changed_cnt) changed_cnt[t * 32] = 0u;
 }
 
+__global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan_next(uint32_t *__restrict__ tile_first, int64_t tiles, uint32_t *__restrict__ changed_cnt)
+{
+    rr_scan_next_body(tile_first, tiles, changed_cnt);
+}
+
 // one workgroup: tile_cnt -> exclusive sums (+ total), tile_head -> exclusive running max.
 // Every thread owns a contiguous run of entries (a multiple of 4, read and written as 16-byte vectors:
 // the run is a chain of dependent L2 accesses, so fewer, wider ones).
-__global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict__ tile_cnt,
-                                                            uint32_t *__restrict__ tile_head, int64_t tiles,
-                                                            uint32_t *__restrict__ out_total)
+// (tile_head may be nullptr: sums only)
+__device__ __forceinline__ void rr_scan_body(uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ tile_head, int64_t tiles,
+                                             uint32_t *__restrict__ out_total)
 {
     __shared__ uint32_t lds[SPINE_THREADS / WAVE + 1];
     const int64_t per = ((tiles + SPINE_THREADS - 1) / SPINE_THREADS + 3) & ~(int64_t)3;
@@ -192,13 +199,14 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict_
     if (b > tiles) b = tiles;
     if (e > tiles) e = tiles;
     const int64_t ev = b + ((e - b) & ~(int64_t)3);           // end of the whole vectors
+    const bool heads = tile_head != nullptr;                  // (uniform)
     uint32_t s = 0, mx = 0;
     for (int64_t i = b; i < ev; i += 4) {
-        const uint4 c = *(const uint4 *)(tile_cnt + i), h = *(const uint4 *)(tile_head + i);
+        const uint4 c = *(const uint4 *)(tile_cnt + i);
         s += c.x + c.y + c.z + c.w;
-        mx = max(max(mx, max(h.x, h.y)), max(h.z, h.w));
+        if (heads) { const uint4 h = *(const uint4 *)(tile_head + i); mx = max(max(mx, max(h.x, h.y)), max(h.z, h.w)); }
     }
-    for (int64_t i = ev; i < e; ++i) { s += tile_cnt[i]; mx = max(mx, tile_head[i]); }
+    for (int64_t i = ev; i < e; ++i) { s += tile_cnt[i]; if (heads) mx = max(mx, tile_head[i]); }
     uint32_t tot, mtot;
     uint32_t off = block_excl_sum<SPINE_THREADS>(s, lds, &tot);
     uint32_t incm = block_incl_max<SPINE_THREADS>(mx, lds, &mtot);
@@ -210,19 +218,53 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict_
     if (lane_id() == 0) prevm = wave_id() ? wlast[wave_id() - 1] : 0u;
     uint32_t run = prevm;
     for (int64_t i = b; i < ev; i += 4) {
-        const uint4 c = *(const uint4 *)(tile_cnt + i), h = *(const uint4 *)(tile_head + i);
-        uint4 oc, oh;
+        const uint4 c = *(const uint4 *)(tile_cnt + i);
+        uint4 oc;
         oc.x = off; off += c.x; oc.y = off; off += c.y; oc.z = off; off += c.z; oc.w = off; off += c.w;
-        oh.x = run; run = max(run, h.x); oh.y = run; run = max(run, h.y); oh.z = run; run = max(run, h.z); oh.w = run; run = max(run, h.w);
         *(uint4 *)(tile_cnt + i) = oc;
-        *(uint4 *)(tile_head + i) = oh;
+        if (heads) {
+            const uint4 h = *(const uint4 *)(tile_head + i);
+            uint4 oh;
+            oh.x = run; run = max(run, h.x); oh.y = run; run = max(run, h.y); oh.z = run; run = max(run, h.z); oh.w = run; run = max(run, h.w);
+            *(uint4 *)(tile_head + i) = oh;
+        }
     }
     for (int64_t i = ev; i < e; ++i) {
-        uint32_t c = tile_cnt[i], h = tile_head[i];
+        const uint32_t c = tile_cnt[i];
         tile_cnt[i] = off; off += c;
-        tile_head[i] = run; run = run > h ? run : h;
+        if (heads) { const uint32_t h = tile_head[i]; tile_head[i] = run; run = run > h ? run : h; }
     }
     if (threadIdx.x == 0) *out_total = tot;
+}
+
+__global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan(uint32_t *__restrict__ tile_cnt,
+                                                            uint32_t *__restrict__ tile_head, int64_t tiles,
+                                                            uint32_t *__restrict__ out_total)
+{
+    rr_scan_body(tile_cnt, tile_head, tiles, out_total);
+}
+
+// two independent scans in one launch (grid 2): a launch of a refinement round on a short list is ~5 us whatever it does
+__global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan_pair(uint32_t *__restrict__ cntA, uint32_t *__restrict__ headA, uint32_t *__restrict__ outA,
+                                                                 uint32_t *__restrict__ cntB, uint32_t *__restrict__ headB, uint32_t *__restrict__ outB,
+                                                                 int64_t tiles)
+{
+    if (blockIdx.x == 0) rr_scan_body(cntA, headA, tiles, outA);
+    else rr_scan_body(cntB, headB, tiles, outB);
+}
+
+// the two single-workgroup steps between k_rr_count and k_rr_apply of a round in one launch (grid 2): block 0 = k_rr_scan,
+// block 1 = k_rr_scan_next (tile_first == nullptr: none) + the two counters the NEXT round's local pass starts from (clear2[0..1],
+// copied to clear2[2..3] first)
+__global__ __launch_bounds__(SPINE_THREADS) void k_rr_scan_round(uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ tile_head, int64_t tiles,
+                                                                  uint32_t *__restrict__ out_total, uint32_t *__restrict__ tile_first,
+                                                                  uint32_t *__restrict__ changed_cnt, uint32_t *__restrict__ clear2,
+                                                                  const uint32_t *__restrict__ gate)
+{
+    if (gate && *gate) return;
+    if (blockIdx.x == 0) { rr_scan_body(tile_cnt, tile_head, tiles, out_total); return; }
+    if (tile_first) rr_scan_next_body(tile_first, tiles, changed_cnt);
+    if (threadIdx.x == 0 && clear2) { clear2[2] = clear2[0]; clear2[3] = clear2[1]; clear2[0] = 0u; clear2[1] = 0u; }      // (saved for the round's one read-back, then zeroed)
 }
 
 // ISA_MODE: 0 = scatter ISA[suffix] = rank directly, 1 = the same plus the has_isa bitmap (sparse
@@ -237,9 +279,11 @@ __global__ __launch_bounds__(RR_THREADS) void k_rr_apply(
     uint32_t *__restrict__ ISA, uint32_t *__restrict__ Uo, uint32_t *__restrict__ Go, uint32_t *__restrict__ Vo,
     uint32_t n_text, uint32_t *__restrict__ has_isa, int g_shift, uint64_t *__restrict__ pair_k,
     uint32_t *__restrict__ pair_v, const uint32_t *__restrict__ tile_total, int key_shift,
-    const uint32_t *__restrict__ tile_next, int parent_tail, uint32_t *__restrict__ changed_cnt)
+    const uint32_t *__restrict__ tile_next, int parent_tail, uint32_t *__restrict__ changed_cnt,
+    const uint32_t *__restrict__ gate = nullptr)      // != nullptr: the launch does nothing when *gate != 0
 {
     constexpr bool SPARSE = ISA_MODE == 1;
+    if (gate && *gate) return;
     // Dense doubling rounds (TAIL): the rank of a group is its LAST slot + 1 (Larsson-Sadakane's group number).  When a
     // parent group splits, its last subgroup ends where the parent ended, so its members' ranks in the ISA are already
     // right and are not rewritten.  A run, a periodic text or a long repeat that runs into the end of the text sheds its
