@@ -241,9 +241,10 @@ def saca_batch(texts, devices=None):
 
 def last_host_timing() -> dict:
     """wall-clock phases (ms) of this thread's most recent host-pointer build (sa_amd_last_host_timing)"""
-    v = (ctypes.c_double * 7)()
-    lib().sa_amd_last_host_timing(v, 7)
-    return {"acquire": v[0], "h2d": v[1], "build": v[2], "d2h": v[3], "release": v[4], "total": v[5], "staged_threads": int(v[6])}
+    v = (ctypes.c_double * 8)()
+    lib().sa_amd_last_host_timing(v, 8)
+    return {"acquire": v[0], "h2d": v[1], "build": v[2], "d2h": v[3], "release": v[4], "total": v[5], "staged_threads": int(v[6]),
+            "early_fraction": v[7]}
 
 
 def last_stats() -> dict:

@@ -11,6 +11,7 @@
 #include "pipeline.hpp"
 
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <sys/mman.h>
 
@@ -33,7 +34,7 @@ static double wall_ms()
 }
 
 // phases of the last host-pointer call of this thread, in milliseconds (sa_amd_last_host_timing)
-struct HostTiming { double acquire = 0, h2d = 0, build = 0, d2h = 0, release = 0, total = 0; int staged = 0; };
+struct HostTiming { double acquire = 0, h2d = 0, build = 0, d2h = 0, release = 0, total = 0; int staged = 0; double early = 0; };      // early: fraction of the array that travelled before the build was done
 static thread_local HostTiming g_host_timing;
 
 // ---- device -> caller's pageable buffer through pinned staging + helper threads ----
@@ -103,6 +104,83 @@ struct LaneTurn {
 };
 
 static int64_t lanes_min_n() { return env_int("SA_AMD_LANES_MIN_N", (int64_t)32 << 20, 0, (int64_t)1 << 40); }
+
+// ---- early download: the front of the array travels while the last refinement rounds run (EarlyDownload, host/pipeline.hpp) ----
+// From the moment the build says that only the slots of its tied list can still change until the build is done, a few helper
+// threads pull the array chunk by chunk, front to back: device -> pinned staging block (one DMA per chunk on a copy stream of
+// their own) -> the caller's buffer (memcpy by the helper that asked for the chunk; one thread moves ~28 GB/s, four keep up with
+// the link).  A plain hipMemcpy into the pageable buffer from a helper thread reaches the link rate too, but the runtime stages
+// it under its own locks and the build thread's read-backs queued behind them: the rounds ran 25 % slower while it copied.
+// The entries that were still tied at that moment arrive with stale values: the build sends their final values behind
+// (compacted, with the bitmap that says which entries they are), the helpers patch them in while the rest of the array is
+// downloaded as before.  C3 (256 MiB): the copy starts ~9 ms before the build ends, 44 % of the array is there when it does.
+constexpr int EARLY_PULLERS = 4;
+struct EarlyPull {
+    size_t chunk = STAGE_BYTES;              // bytes per copy (SA_AMD_EARLY_CHUNK_BYTES; a multiple of 4096, at most a staging block)
+    std::atomic<size_t> issued{0};          // chunks handed to the pullers (started or about to start)
+    std::atomic<bool> stop{false};
+    std::atomic<int> rc{SA_AMD_OK};
+    std::unique_ptr<std::atomic<uint8_t>[]> done;      // per chunk: it is in the caller's buffer
+    char *dst = nullptr;
+    const char *src = nullptr;
+    size_t bytes = 0, nchunk = 0, max_chunks = 0;
+    hipStream_t cst = nullptr;
+    hipEvent_t after = nullptr;
+    int device = -1, node = -1;
+    void run(int)                           // on EARLY_PULLERS helper threads
+    {
+        if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); rc.store(SA_AMD_EHIP); return; }
+        PinBlock stage;
+        hipEvent_t ev = nullptr;
+        int r = pool().pinned(STAGE_BYTES, node, device, &stage);
+        if (r == SA_AMD_OK) r = hip_status(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        while (r == SA_AMD_OK) {
+            const size_t c = issued.fetch_add(1);
+            if (c >= max_chunks || stop.load()) break;      // (a chunk taken but not copied: the caller downloads it with the rest)
+            const size_t b = c * chunk, len = b + chunk < bytes ? chunk : bytes - b;
+            r = hip_status(hipMemcpyAsync(stage.p, src + b, len, hipMemcpyDeviceToHost, cst));
+            if (r == SA_AMD_OK) r = hip_status(hipEventRecord(ev, cst));
+            if (r == SA_AMD_OK) r = hip_status(hipEventSynchronize(ev));
+            if (r != SA_AMD_OK) break;
+            memcpy(dst + b, stage.p, len);
+            done[c].store(1);
+        }
+        if (r != SA_AMD_OK) { (void)hipGetLastError(); rc.store(r); }
+        if (ev) (void)hipEventDestroy(ev);
+        pool().release_pinned(stage);
+    }
+    size_t copied() const                   // chunks of the front that have arrived (call after the pullers have been joined)
+    {
+        size_t c = 0;
+        while (c < nchunk && c < max_chunks && done[c].load()) ++c;
+        return c;
+    }
+};
+
+// the final values of the entries that were still tied when the early copy began, into the part of the caller's array that has
+// arrived: tile_off / bits / holes are host copies of EarlyDownload's device arrays; entries [0, upto)
+static std::function<void(int)> early_patch_task(uint32_t *out, const uint32_t *tile_off, const uint32_t *bits, const uint32_t *holes, size_t upto, int threads)
+{
+    const size_t tiles = (upto + EARLY_TILE - 1) / EARLY_TILE;
+    const size_t T = (size_t)(threads < 1 ? 1 : threads);
+    const size_t per = (tiles + T - 1) / T;
+    return [=](int t) {
+        const size_t t0 = (size_t)t * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+        for (size_t tile = t0; tile < t1; ++tile) {
+            size_t k = tile_off[tile];
+            const size_t w0 = tile * (EARLY_TILE / 32), w1 = w0 + EARLY_TILE / 32;
+            for (size_t w = w0; w < w1; ++w) {
+                uint32_t b = bits[w];
+                while (b) {
+                    const size_t j = w * 32 + (size_t)__builtin_ctz(b);
+                    if (j < upto) out[j] = holes[k];
+                    ++k;
+                    b &= b - 1u;
+                }
+            }
+        }
+    };
+}
 
 // host buffers in, host buffers out; with_sentinel writes SA[0] = n too (saca layout)
 static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_sentinel, int device)
@@ -227,27 +305,136 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
             }
         });
     }
+    // early download (large arrays): see EarlyPull above.  SA_AMD_EARLY_DIV = d: the copy starts when at most n / d suffixes are
+    // still tied (0: never); the chunks it takes before the build ends are bounded so that what has to be sent behind them fits
+    // into the part of the caller's array that is still free.
+    const int64_t early_div = env_int("SA_AMD_EARLY_DIV", 4, 0, 1 << 20);
+    const size_t early_min = (size_t)env_int("SA_AMD_EARLY_MIN_BYTES", (int64_t)128 << 20, 0, (int64_t)1 << 40);
+    const uint32_t *dsrc = with_sentinel ? dSA : dSA + 1;
+    EarlyDownload early;
+    EarlyPull pull;
+    HelperPool::Async pull_job;
+    hipStream_t cst = nullptr;
+    pull.chunk = (size_t)env_int("SA_AMD_EARLY_CHUNK_BYTES", (int64_t)STAGE_BYTES, 65536, (int64_t)STAGE_BYTES) & ~(size_t)4095;
+    const int64_t early_wait = env_int("SA_AMD_EARLY_WAIT_CHUNKS", 0, 0, 1 << 20);     // tests: the build waits until so many chunks have been copied
+    const bool early_on = staged && early_div > 0 && out_bytes_all >= early_min && out_bytes_all >= 4 * pull.chunk;
+    if (early_on && rc == SA_AMD_OK && pool().stream(cur, &cst) == SA_AMD_OK) {
+        early.off = with_sentinel ? 1 : 0;
+        early.threshold = (int64_t)n / early_div;
+        pull.dst = (char *)SA_host; pull.src = (const char *)dsrc; pull.bytes = out_bytes_all;
+        pull.nchunk = (out_bytes_all + pull.chunk - 1) / pull.chunk;
+        pull.done.reset(new std::atomic<uint8_t>[pull.nchunk]);
+        for (size_t c = 0; c < pull.nchunk; ++c) pull.done[c].store(0);
+        pull.cst = cst; pull.device = cur; pull.node = node;
+        EarlyPull *pp = &pull;
+        HelperPool *hpp = &hp;
+        HelperPool::Async *pj = &pull_job;
+        EarlyDownload *ep = &early;
+        early.start = [pp, hpp, pj, ep](hipEvent_t ev) {
+            // what is sent behind the early chunks -- tile offsets, bitmap, at most min(tied at the snapshot, entries taken) final
+            // values -- lands in the end of the caller's array: the most chunks K with K chunks + all that <= the array
+            size_t k = 0;
+            for (;;) {
+                const size_t b = (k + 1) * pp->chunk, e = b / 4;
+                const size_t holes = (size_t)ep->m_snap < e ? (size_t)ep->m_snap : e;
+                if (b + b / 32 + b / 2048 + holes * 4 + 16384 > pp->bytes) break;
+                ++k;
+            }
+            pp->max_chunks = k;
+            pp->after = ev;
+            if (hipStreamWaitEvent(pp->cst, ev, 0) != hipSuccess) { (void)hipGetLastError(); return; }      // (no copy before the marks and SA[0] are in place)
+            hpp->start(*pj, EARLY_PULLERS, [pp](int t) { pp->run(t); });
+        };
+        early.stop = [pp, early_wait]() -> int64_t {
+            if (early_wait > 0) {
+                const size_t want = (size_t)early_wait < pp->max_chunks ? (size_t)early_wait : pp->max_chunks;
+                for (;;) {
+                    size_t have = 0;
+                    while (have < want && pp->done[have].load()) ++have;
+                    if (have >= want || pp->rc.load() != SA_AMD_OK) break;
+                    std::this_thread::yield();
+                }
+            }
+            pp->stop.store(true);
+            size_t k = pp->issued.load();
+            if (k > pp->max_chunks) k = pp->max_chunks;
+            const size_t b = k * pp->chunk;
+            return (int64_t)((b < pp->bytes ? b : pp->bytes) / 4);
+        };
+    }
+    struct PullEnd {                                             // (the puller holds pointers to this frame: joined on every path)
+        HelperPool &pool_; HelperPool::Async &h_; EarlyPull &p_;
+        ~PullEnd() { p_.stop.store(true); pool_.finish(h_); }
+    } pull_end{ hp, pull_job, pull };
     if (rc == SA_AMD_OK) {
         LaneTurn turn(lanes.run, turns);
-        rc = build_device(dT, dSA, n, dW, (int64_t)wb, st, nullptr);
+        rc = build_device(dT, dSA, n, dW, (int64_t)wb, st, nullptr, early.start ? &early : nullptr);
     }
     // (usually done by now; otherwise no further unit is started -- SA_AMD_PREFAULT_WAIT=1: every page is mapped first, A/B)
     if (env_int("SA_AMD_PREFAULT_WAIT", 0, 0, 1) == 0) prefault_stop.store(true, std::memory_order_relaxed);
     hp.finish(prefault);
+    pull.stop.store(true);
     t0 = wall_ms();
     tm.build = t0 - t1;
+    HelperPool::Async patch_job;
+    struct PatchEnd {                                            // (the patch tasks hold pointers into the caller's array)
+        HelperPool &pool_; HelperPool::Async &h_;
+        ~PatchEnd() { pool_.finish(h_); }
+    } patch_end{ hp, patch_job };
     if (rc == SA_AMD_OK) {
         LaneTurn turn(lanes.down, turns);
-        const uint32_t *src = with_sentinel ? dSA : dSA + 1;
+        const uint32_t *src = dsrc;
         const size_t out_bytes = out_bytes_all;
-        if (staged) {
-            tm.staged = copy_threads;
-            rc = staged_download(SA_host, src, out_bytes, st, copy_threads, cur, node);
-        } else {
-            rc = hip_status(hipMemcpyAsync(SA_host, src, out_bytes, hipMemcpyDeviceToHost, st));
-            if (rc == SA_AMD_OK) rc = hip_status(hipStreamSynchronize(st));      // (the turn ends when the copy has)
+        size_t have = 0;                                        // bytes of the array that are (or are about to be) in the caller's buffer
+        size_t zone_at = out_bytes;                             // where the values sent behind have landed: free again once the patch is done
+        if (early.started && early.covered > 0) {
+            // the values sent behind: [tile offsets | bitmap | final values] land in the END of the caller's array (free until the
+            // rest of the download gets there); the helpers patch the front part from them while the rest of the array travels
+            const size_t covered = (size_t)early.covered, got = covered * 4 < out_bytes ? covered * 4 : out_bytes;
+            const size_t tiles_c = (covered + EARLY_TILE - 1) / EARLY_TILE;
+            const size_t off_b = align_up((tiles_c + 1) * 4, 256), bits_b = align_up(tiles_c * (EARLY_TILE / 8), 256), holes_b = (size_t)early.holes * 4;
+            const size_t aux = off_b + bits_b + holes_b;
+            if (got + aux + 8192 <= out_bytes) {
+                char *zone = (char *)SA_host + ((out_bytes - aux) & ~(size_t)4095);
+                rc = hip_status(hipMemcpyAsync(zone, early.d_tile_off, (tiles_c + 1) * 4, hipMemcpyDeviceToHost, st));
+                if (rc == SA_AMD_OK) rc = hip_status(hipMemcpyAsync(zone + off_b, early.d_bits, tiles_c * (EARLY_TILE / 8), hipMemcpyDeviceToHost, st));
+                if (rc == SA_AMD_OK && holes_b) rc = hip_status(hipMemcpyAsync(zone + off_b + bits_b, early.d_holes, holes_b, hipMemcpyDeviceToHost, st));
+                if (rc == SA_AMD_OK) rc = hip_status(hipStreamSynchronize(st));
+                hp.finish(pull_job);                             // (the chunk that was in flight when the build ended has arrived by now)
+                if (rc == SA_AMD_OK && pull.rc.load() != SA_AMD_OK) rc = pull.rc.load();
+                // chunks the puller took but did not copy (it saw the stop first) are downloaded with the rest
+                const size_t copied_b = pull.copied() * pull.chunk < out_bytes ? pull.copied() * pull.chunk : out_bytes;
+                if (rc == SA_AMD_OK && copied_b > 0) {
+                    const int pt = copy_threads > 8 ? 8 : copy_threads;
+                    hp.start(patch_job, pt, early_patch_task(SA_host, (const uint32_t *)zone, (const uint32_t *)(zone + off_b),
+                                                             (const uint32_t *)(zone + off_b + bits_b), copied_b / 4, pt));
+                    have = copied_b;
+                    zone_at = (size_t)(zone - (char *)SA_host);
+                    tm.early = (double)copied_b / (double)out_bytes;
+                }
+            }
+            // (else: the early chunks are simply downloaded again with everything else)
         }
+        hp.finish(pull_job);
+        if (rc == SA_AMD_OK && pull.rc.load() != SA_AMD_OK) rc = pull.rc.load();
+        auto fetch = [&](size_t from, size_t to) {
+            if (rc != SA_AMD_OK || from >= to) return;
+            if (staged) {
+                tm.staged = copy_threads;
+                rc = staged_download((char *)SA_host + from, (const char *)src + from, to - from, st, copy_threads, cur, node);
+            } else {
+                rc = hip_status(hipMemcpyAsync((char *)SA_host + from, (const char *)src + from, to - from, hipMemcpyDeviceToHost, st));
+                if (rc == SA_AMD_OK) rc = hip_status(hipStreamSynchronize(st));      // (the turn ends when the copy has)
+            }
+        };
+        const size_t split = zone_at < out_bytes ? (zone_at > have ? zone_at & ~(STAGE_BYTES - 1) : have) : out_bytes;
+        fetch(have, split < have ? have : split);
+        hp.finish(patch_job);                                    // the landing zone is free from here on
+        fetch(split < have ? have : split, out_bytes);
     }
+    hp.finish(pull_job);
+    if (early.ev) { (void)hipEventDestroy(early.ev); early.ev = nullptr; }
+    if (cst) { (void)hipStreamSynchronize(cst); pool().release_stream(cur, cst); }
     const int rs = hip_status(hipStreamSynchronize(st));       // also drains the stream after a failure
     if (rc == SA_AMD_OK) rc = rs;
     t1 = wall_ms();
@@ -258,8 +445,8 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     tm.total = wall_ms() - t_begin;
     g_host_timing = tm;
     if (env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 2)
-        fprintf(stderr, "suffix_array_amd: n=%d device %d numa node %d acquire %.2f h2d %.2f build %.2f d2h %.2f (staged %d) release %.2f total %.2f ms\n", n,
-                cur, node, tm.acquire, tm.h2d, tm.build, tm.d2h, tm.staged, tm.release, tm.total);
+        fprintf(stderr, "suffix_array_amd: n=%d device %d numa node %d acquire %.2f h2d %.2f build %.2f d2h %.2f (staged %d, %.0f %% of the array sent before the build was done) release %.2f total %.2f ms\n", n,
+                cur, node, tm.acquire, tm.h2d, tm.build, tm.d2h, tm.staged, tm.early * 100.0, tm.release, tm.total);
     return rc;
 }
 

@@ -6,6 +6,8 @@
 #include "tuning.hpp"
 #include "pool.hpp"
 
+#include <functional>
+
 namespace sa {
 
 constexpr int SORT_MAX_WG = 1024;   // spine rows are scanned by one 1024-thread block
@@ -75,6 +77,7 @@ struct Workspace {
     unsigned long long *os_status;  // look-back granules of the single-pass tile scatter: 2 KiB per 8192-element tile
     uint32_t *os_err;
     uint32_t *bk_start;             // bucket sort of the 32-bit first stage: 2^16 + 1 or 2^18 + 1 bucket starts
+    uint32_t *early_bits, *early_cnt;    // early download: bitmap over the n + 1 entries of the downloaded array, marked entries per tile
     SortScratch ss;
     size_t bytes;
 };
@@ -118,6 +121,8 @@ static Workspace carve(void *base, int64_t n)
     w.os_status = (unsigned long long *)take(((size_t)ceil_div((int64_t)N, OS_MIN_TILE) + 1) * RADIX * 8);
     w.os_err = (uint32_t *)take(256);
     w.bk_start = (uint32_t *)take(((size_t)BK_BUCKETS_MAX + 1) * 4);
+    w.early_bits = (uint32_t *)take(((N + 1 + 31) / 32 + EARLY_THREADS) * 4);           // (whole tiles of 256 words)
+    w.early_cnt = (uint32_t *)take(((N + 1 + EARLY_TILE - 1) / EARLY_TILE + 8) * 4);
     w.ss.spine = w.spine; w.ss.digit_tot = w.digit_tot; w.ss.status = w.os_status; w.ss.err = w.os_err;
     w.bytes = off;
     return w;
@@ -992,6 +997,25 @@ static int choose_gram_keys(const uint8_t *dT, int64_t n, KeyParams *Pp, int *ke
     return SA_AMD_OK;
 }
 
+// Early download (host/host_path.hpp): what the host-pointer entry points hand to the build so that the suffix array can start
+// its way over PCIe while the last refinement rounds run.  The build calls start() once, when the tied list has come down to
+// `threshold` suffixes -- by then it has marked the snapshot of the tied slots (k_early_mark) and written SA[0] --, and stop()
+// when the rounds are done; stop() returns how many entries of the array (from its front) were or are being copied, and the
+// build compacts the final values of the marked entries among them (d_holes, in entry order; d_tile_off = where each tile of
+// EARLY_TILE entries starts in d_holes; d_bits = the marks).
+struct EarlyDownload {
+    int off = 0;                          // in: entry of slot 0 in the downloaded array (1: the array starts with the sentinel entry SA[0] = n)
+    int64_t threshold = 0;                // in: start when at most this many suffixes are tied (0: never)
+    std::function<void(hipEvent_t)> start;   // in: begin copying the array from its front; the copy stream must wait for the event first
+    std::function<int64_t()> stop;        // in: no further chunk is started; returns the entries [0, x) that were handed to the copy
+    bool started = false;
+    int64_t m_snap = 0;                   // out: tied suffixes at the snapshot
+    int64_t covered = 0;                  // out: stop()'s answer
+    int64_t holes = 0;                    // out: marked entries among the covered ones
+    const uint32_t *d_bits = nullptr, *d_tile_off = nullptr, *d_holes = nullptr;      // out (device pointers into the workspace)
+    hipEvent_t ev = nullptr;
+};
+
 // One device-resident build, phase by phase.  The members are what the phases hand to each other; every phase returns an
 // SA_AMD_* status.  The blocking 4-byte read-backs that steer the host (how many suffixes are still tied, how many groups,
 // how many ranks changed) are the read_words calls inside the phases: each one names what it reads.
@@ -1004,6 +1028,7 @@ struct DeviceBuild {
     Tuning tn;
     Workspace w;
     sa_amd_stats local;
+    EarlyDownload *early = nullptr;     // host-pointer callers: the array starts travelling before the last rounds are done
     bool trace = false;
     double trace_t = 0;
     double lap() { const double t = now_ms(), d = t - trace_t; trace_t = t; return d; }
@@ -1036,6 +1061,50 @@ struct DeviceBuild {
     bool prev_clean = true;             // the last refinement round's local pass ordered every member (optimistic for the first one: a miss costs three empty launches)
     int deferred_misses = 0;            // rounds that deferred their mid-round read-back and did have members for the global sort (RoundCtl)
 
+
+    // Early download: called wherever (Ucur, m) is the current tied list and every slot outside it is final
+    int early_maybe_start()
+    {
+        if (!early || early->started || m <= 0 || m > early->threshold || !early->start) return SA_AMD_OK;
+        if (!early->ev && hipEventCreateWithFlags(&early->ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return SA_AMD_OK; }
+        hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);   // reference src/saca.rs:13 (the first chunk carries it)
+        LAUNCH_CHECK(st);
+        HIP_TRY(hipMemsetAsync(w.early_bits, 0, (((size_t)n + 1 + 31) / 32 + EARLY_THREADS) * 4, st));
+        int64_t blocks = ceil_div(m, 256 * 8);
+        if (blocks > 65536) blocks = 65536;
+        PROF(KC_MISC, m, st, hipLaunchKernelGGL((k_early_mark), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)Ucur, m, (uint32_t)early->off, w.early_bits));
+        HIP_TRY(hipEventRecord(early->ev, st));
+        early->started = true;
+        early->m_snap = m;
+        if (trace) fprintf(stderr, "suffix_array_amd: early download starts with %lld suffixes still tied\n", (long long)m);
+        early->start(early->ev);
+        return SA_AMD_OK;
+    }
+    // ... and when the array is complete: the final values of the marked entries among those the copy has taken
+    int early_finish()
+    {
+        if (!early || !early->started) return SA_AMD_OK;
+        early->covered = early->stop ? early->stop() : 0;
+        if (early->covered > n + early->off) early->covered = n + early->off;
+        early->holes = 0;
+        if (early->covered <= 0) return SA_AMD_OK;
+        const int64_t tiles_e = ceil_div(early->covered, EARLY_TILE);
+        const int64_t words = ceil_div(early->covered, 32);
+        // (bits beyond the covered entries inside the last word belong to entries that are downloaded later: harmless, they are
+        // patched with their final values too when the host walks whole words -- the host stops at `covered`)
+        PROF(KC_MISC, early->covered, st, hipLaunchKernelGGL((k_early_count), dim3((unsigned)tiles_e), dim3(EARLY_THREADS), 0, st,
+                                                             (const uint32_t *)w.early_bits, words, w.early_cnt));
+        PROF(KC_RR_SCAN, tiles_e, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.early_cnt, (uint32_t *)nullptr, tiles_e, w.early_cnt + tiles_e));
+        uint32_t *holes = (uint32_t *)w.keysC;
+        PROF(KC_MISC, early->covered, st, hipLaunchKernelGGL((k_early_gather), dim3((unsigned)tiles_e), dim3(EARLY_THREADS), 0, st,
+                                                             (const uint32_t *)w.early_bits, words, (const uint32_t *)w.early_cnt,
+                                                             (const uint32_t *)(dSA + 1 - early->off), holes));
+        uint32_t total = 0;
+        { const int rcw = read_words(&total, w.early_cnt + tiles_e, 4, st); if (rcw) return rcw; }
+        early->holes = total;
+        early->d_bits = w.early_bits; early->d_tile_off = w.early_cnt; early->d_holes = holes;
+        return SA_AMD_OK;
+    }
 
     // Bucket sort of the 32-bit first stage: which key bits do the global passes order?  16 (two passes of 8 bits) when an average
     // bucket fits the 10-pairs-per-thread shapes (n = 2^28: 4096 pairs; 2^29: 8192), 18 (two passes of NINE bits) for larger texts
@@ -1577,6 +1646,7 @@ struct DeviceBuild {
 
             bool counters_clear = false;      // (RoundCtl: one read-back per round while the rounds have nothing for the global sort)
             while (text_ok && s_sym > 0 && m > sparse_limit && local.text_rounds < tn.max_text_rounds && progressing) {
+                if ((rc = early_maybe_start())) return rc;
                 const int64_t m_before = m;
                 uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
                 Refined rf;
@@ -1673,6 +1743,7 @@ struct DeviceBuild {
         bool counters_clear = false;                      // the previous round's k_rr_scan_round zeroed the big-group counters
         while (m > 0) {
             if (local.rounds >= 48) return SA_AMD_EINTERNAL;
+            if ((rc = early_maybe_start())) return rc;     // (every slot outside the tied list is final from here on)
             uint32_t *Valt = (Vcur == w.valsA) ? w.valsB : w.valsA;
             // the same refinement machinery as the text rounds, keyed by ranks -- small groups (a long repeat gives millions of
             // pairs) are ordered in LDS, only large groups go through the global sort.  Dense: ranks from the ISA; sparse:
@@ -1796,11 +1867,12 @@ struct DeviceBuild {
 };
 
 static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWork, int64_t work_bytes, hipStream_t st,
-                        sa_amd_stats *stats)
+                        sa_amd_stats *stats, EarlyDownload *early = nullptr)
 {
     const int64_t n = n32;
     DeviceBuild B;
     B.dT = dT; B.dSA = dSA; B.SA = dSA + 1; B.n = n; B.st = st;
+    B.early = early;
     B.tn = Tuning::from_env(N_SORT_VARIANTS, N_SORT32_VARIANTS, N_OS_SHAPES64, N_OS_SHAPES32);
     B.trace = env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 3;      // one line per refinement round on stderr
     B.trace_t = now_ms();
@@ -1841,6 +1913,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     if ((rc = B.finish_top32_ties())) return rc;
     if ((rc = B.rank_setup_and_text_rounds())) return rc;
     if ((rc = B.doubling_rounds())) return rc;
+    if ((rc = B.early_finish())) return rc;
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);   // reference src/saca.rs:13
     LAUNCH_CHECK(st);
     {

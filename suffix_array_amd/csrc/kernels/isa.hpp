@@ -93,6 +93,50 @@ __global__ __launch_bounds__(SW_THREADS) void k_scatter_windows(const uint32_t *
 
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 
+// ---- early download (host/host_path.hpp): the part of the suffix array that starts its way to the host while the last
+// refinement rounds still run.  A slot outside the tied list never changes again, so the array can be copied as it stands;
+// the slots that WERE still tied when the copy began (the snapshot list U, marked in a bitmap over the entries of the
+// downloaded array: entry = slot + off) are sent again when the build is done -- compacted in entry order (k_early_count /
+// k_rr_scan / k_early_gather) -- and patched into the caller's array by the host.
+constexpr int EARLY_TILE = 8192;          // entries per counting tile: 256 bitmap words
+constexpr int EARLY_THREADS = 256;
+
+__global__ __launch_bounds__(256) void k_early_mark(const uint32_t *__restrict__ U, int64_t m, uint32_t off, uint32_t *__restrict__ bits)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
+        const uint32_t j = U[i] + off;
+        atomicOr(&bits[j >> 5], 1u << (j & 31u));
+    }
+}
+
+// marked entries per tile of EARLY_TILE entries (one workgroup per tile, one bitmap word per thread)
+__global__ __launch_bounds__(EARLY_THREADS) void k_early_count(const uint32_t *__restrict__ bits, int64_t words, uint32_t *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t lds[EARLY_THREADS / WAVE + 1];
+    const int64_t w = (int64_t)blockIdx.x * EARLY_THREADS + threadIdx.x;
+    const uint32_t c = w < words ? (uint32_t)__popc(bits[w]) : 0u;
+    uint32_t total;
+    (void)block_excl_sum<EARLY_THREADS>(c, lds, &total);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+// holes[tile_off[tile] + rank inside the tile] = src[entry] for every marked entry, in entry order
+__global__ __launch_bounds__(EARLY_THREADS) void k_early_gather(const uint32_t *__restrict__ bits, int64_t words, const uint32_t *__restrict__ tile_off,
+                                                                 const uint32_t *__restrict__ src, uint32_t *__restrict__ holes)
+{
+    __shared__ uint32_t lds[EARLY_THREADS / WAVE + 1];
+    const int64_t w = (int64_t)blockIdx.x * EARLY_THREADS + threadIdx.x;
+    uint32_t b = w < words ? bits[w] : 0u;
+    uint32_t total;
+    uint32_t k = tile_off[blockIdx.x] + block_excl_sum<EARLY_THREADS>((uint32_t)__popc(b), lds, &total);
+    while (b) {
+        const int bit = __builtin_ctz(b);
+        holes[k++] = src[w * 32 + bit];
+        b &= b - 1u;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_copy_u32(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int64_t n)
 {
     const int64_t stride = (int64_t)gridDim.x * 256;

@@ -280,6 +280,41 @@ def test_staged_download_sizes(oracle, monkeypatch, n):
     assert np.array_equal(div.astype(np.uint32), exp[1:])
 
 
+@pytest.mark.parametrize("gen,n,seed,div", [("english_corpus", 3_000_001, 3, "1"), ("english_corpus", (4 << 20) + 77, 4, "3"), ("dna_repeats", 2_500_000, 5, "1"),
+                                            ("periodic", 1_200_007, 1, "1"), ("twice", 2_000_000, 9, "1")])
+@pytest.mark.parametrize("sentinel", [True, False])
+def test_early_download_patches_the_slots_that_were_still_tied(oracle, monkeypatch, gen, n, seed, div, sentinel):
+    """the front of the array starts its way to the host while refinement rounds still run (host/host_path.hpp, EarlyPull): the
+    entries that were tied when the copy began arrive stale and are patched from the values sent behind.  Forced here at small
+    sizes: 64 KiB chunks, the copy starts as soon as at most n / div suffixes are tied, and the build WAITS until eight chunks
+    have been copied, so every run has early chunks with stale entries in them -- through both entry points (with and without
+    the sentinel entry in front)"""
+    monkeypatch.setenv("SA_AMD_STAGED_MIN_BYTES", "0")
+    monkeypatch.setenv("SA_AMD_EARLY_MIN_BYTES", "0")
+    monkeypatch.setenv("SA_AMD_EARLY_CHUNK_BYTES", "65536")
+    monkeypatch.setenv("SA_AMD_EARLY_DIV", div)
+    monkeypatch.setenv("SA_AMD_EARLY_WAIT_CHUNKS", "8")
+    if gen == "periodic":
+        t = np.resize(np.frombuffer(b"abcabcabd" * 7 + b"x", dtype=np.uint8), n).copy()
+    elif gen == "twice":
+        t = np.concatenate([corpus.english(n // 2, seed)] * 2)
+    else:
+        t = getattr(corpus, gen)(n, seed)
+    exp = oracle.sais(t)
+    for it in range(3):
+        if sentinel:
+            out = np.full(t.size + 1, 0xDEADBEEF, dtype=np.uint32)
+            sa.saca(t, out)
+            assert np.array_equal(out, exp), (gen, it)
+        else:
+            out = np.full(t.size + 1, 0xDEADBEEF, dtype=np.uint32)          # (n entries + one that must stay untouched)
+            assert sa.lib().sa_amd_divsufsort(t.ctypes.data, out.ctypes.data, t.size) == 0
+            assert np.array_equal(out[:-1], exp[1:]) and out[-1] == 0xDEADBEEF, (gen, it)
+        ht = sa.last_host_timing()
+        assert 0 < ht["early_fraction"] <= 0.76, ht              # (some chunks travelled early, never more than three quarters)
+        assert sa.last_stats()["rounds"] >= 1
+
+
 def test_batch_entry_point(oracle):
     texts = [corpus.uniform(50_000, 50 + i) for i in range(3)] + [np.zeros(0, dtype=np.uint8), corpus.dna(30_000, 1)]
     outs = sa.saca_batch(texts)
@@ -848,7 +883,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_NO_FIRST_TAIL", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_GRAM_TAIL", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
