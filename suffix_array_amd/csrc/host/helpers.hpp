@@ -123,6 +123,7 @@ public:
         if (cpus > 0 && want_ > cpus) want_ = cpus;
     }
     int node() const { return node_; }
+    int helpers() const { return want_; }      // threads the pool has or will start (0: every job runs on its caller)
 
     // fn(0) .. fn(count-1), each once, on the helpers and on the calling thread; returns when all have run.
     // Tasks must not throw.  Helper threads are started on first use; if none can be started the caller does all the work.

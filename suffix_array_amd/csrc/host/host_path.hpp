@@ -109,8 +109,9 @@ static int64_t lanes_min_n() { return env_int("SA_AMD_LANES_MIN_N", (int64_t)32 
 // From the moment the build says that only the slots of its tied list can still change until the build is done, a few helper
 // threads pull the array chunk by chunk, front to back: device -> pinned staging block (one DMA per chunk on a copy stream of
 // their own) -> the caller's buffer (memcpy by the helper that asked for the chunk; one thread moves ~28 GB/s, four keep up with
-// the link).  A plain hipMemcpy into the pageable buffer from a helper thread reaches the link rate too, but the runtime stages
-// it under its own locks and the build thread's read-backs queued behind them: the rounds ran 25 % slower while it copied.
+// the link).  (A plain hipMemcpy into the pageable buffer from one helper reaches the link rate too -- the runtime stages it
+// itself -- but the build ran 0.5 ms slower beside it, same box; with the pinned blocks the rounds keep their pace: 8.51 against
+// 8.65 ms for rounds 3-9 of C3 in the kernel traces with the copy off / on.)
 // The entries that were still tied at that moment arrive with stale values: the build sends their final values behind
 // (compacted, with the bitmap that says which entries they are), the helpers patch them in while the rest of the array is
 // downloaded as before.  C3 (256 MiB): the copy starts ~9 ms before the build ends, 44 % of the array is there when it does.
@@ -317,7 +318,8 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     hipStream_t cst = nullptr;
     pull.chunk = (size_t)env_int("SA_AMD_EARLY_CHUNK_BYTES", (int64_t)STAGE_BYTES, 65536, (int64_t)STAGE_BYTES) & ~(size_t)4095;
     const int64_t early_wait = env_int("SA_AMD_EARLY_WAIT_CHUNKS", 0, 0, 1 << 20);     // tests: the build waits until so many chunks have been copied
-    const bool early_on = staged && early_div > 0 && out_bytes_all >= early_min && out_bytes_all >= 4 * pull.chunk;
+    // (the pullers are helper threads: a pool without helpers would run them only when the build is over)
+    const bool early_on = staged && early_div > 0 && out_bytes_all >= early_min && out_bytes_all >= 4 * pull.chunk && hp.helpers() > 0;
     if (early_on && rc == SA_AMD_OK && pool().stream(cur, &cst) == SA_AMD_OK) {
         early.off = with_sentinel ? 1 : 0;
         early.threshold = (int64_t)n / early_div;
@@ -348,10 +350,11 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
         early.stop = [pp, early_wait]() -> int64_t {
             if (early_wait > 0) {
                 const size_t want = (size_t)early_wait < pp->max_chunks ? (size_t)early_wait : pp->max_chunks;
+                const double t_give_up = wall_ms() + 2000.0;
                 for (;;) {
                     size_t have = 0;
                     while (have < want && pp->done[have].load()) ++have;
-                    if (have >= want || pp->rc.load() != SA_AMD_OK) break;
+                    if (have >= want || pp->rc.load() != SA_AMD_OK || wall_ms() > t_give_up) break;
                     std::this_thread::yield();
                 }
             }

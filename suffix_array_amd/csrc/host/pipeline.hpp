@@ -1072,6 +1072,7 @@ struct DeviceBuild {
         HIP_TRY(hipMemsetAsync(w.early_bits, 0, (((size_t)n + 1 + 31) / 32 + EARLY_THREADS) * 4, st));
         int64_t blocks = ceil_div(m, 256 * 8);
         if (blocks > 65536) blocks = 65536;
+        if ((((uintptr_t)Ucur) & 15) != 0) return SA_AMD_OK;       // (the list slabs are 256-byte aligned: cannot happen)
         PROF(KC_MISC, m, st, hipLaunchKernelGGL((k_early_mark), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)Ucur, m, (uint32_t)early->off, w.early_bits));
         HIP_TRY(hipEventRecord(early->ev, st));
         early->started = true;

@@ -101,12 +101,32 @@ __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 constexpr int EARLY_TILE = 8192;          // entries per counting tile: 256 bitmap words
 constexpr int EARLY_THREADS = 256;
 
+// (the list is in slot order: a thread takes eight consecutive members, whose bits fall into one or two bitmap words most of the
+// time, and issues one atomic per word instead of one per member -- 37 M members of C3: 1.13 -> ~0.3 ms)
 __global__ __launch_bounds__(256) void k_early_mark(const uint32_t *__restrict__ U, int64_t m, uint32_t off, uint32_t *__restrict__ bits)
 {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
-        const uint32_t j = U[i] + off;
-        atomicOr(&bits[j >> 5], 1u << (j & 31u));
+    const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i0 < m; i0 += stride) {
+        uint32_t u[8];
+        if (i0 + 8 <= m) {
+            const uint4 a = *(const uint4 *)(U + i0), b = *(const uint4 *)(U + i0 + 4);
+            u[0] = a.x; u[1] = a.y; u[2] = a.z; u[3] = a.w; u[4] = b.x; u[5] = b.y; u[6] = b.z; u[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[k] = i0 + k < m ? U[i0 + k] : 0xffffffffu;
+        }
+        uint32_t word = 0xffffffffu, acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (u[k] == 0xffffffffu) continue;
+            const uint32_t j = u[k] + off, w = j >> 5;
+            if (w != word) {
+                if (acc) atomicOr(&bits[word], acc);
+                word = w; acc = 0;
+            }
+            acc |= 1u << (j & 31u);
+        }
+        if (acc) atomicOr(&bits[word], acc);
     }
 }
 
