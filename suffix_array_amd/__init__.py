@@ -143,6 +143,8 @@ def diag_lib() -> ctypes.CDLL:
         L.sa_amd_test_sort_pairs.restype = ctypes.c_int32
         L.sa_amd_test_sort_pairs32.argtypes = [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
         L.sa_amd_test_sort_pairs32.restype = ctypes.c_int32
+        L.sa_amd_test_sample_sort64.argtypes = [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32, c_vp]
+        L.sa_amd_test_sample_sort64.restype = ctypes.c_int32
         L.sa_amd_test_bucket_sort32.argtypes = [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32, c_vp]
         L.sa_amd_test_bucket_sort32.restype = ctypes.c_int32
         L.sa_amd_test_build_keys.argtypes = [c_vp, ctypes.c_int32, c_vp, c_vp, c_vp]

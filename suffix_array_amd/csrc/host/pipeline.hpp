@@ -553,6 +553,82 @@ static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint3
     return SA_AMD_OK;
 }
 
+#ifdef SA_AMD_DIAG
+// ------------------------------------------------------------------------------------------
+// Sample sort of the 64-bit stage (kernels/sample_sort.hpp): (key, i) pairs of keys_a[0 .. n) -> keys in order in keys_b, the
+// suffixes in final_vals.  Scratch: keys_c (the sample and its sort), vals_a / vals_b (the values between the levels), u0 / u1
+// (values of the sample's sort), big (n / 8 + 1 MiB bytes at least: the tiles' counts), small (2 MiB: totals, bases, segments,
+// tile descriptors come behind), words (two counters + the list of reported buckets).
+// *done = false: some bucket that is no equality bucket did not fit a workgroup (keys_a no longer holds the keys): the caller
+// builds the keys again and sorts them with the LSD engine.  One read-back (the reported buckets).
+// ------------------------------------------------------------------------------------------
+static int64_t sample_count(int64_t n, const Tuning &tn)
+{
+    int lg = tn.sample_log ? tn.sample_log : (n >= ((int64_t)1 << 28) ? 22 : (n >= ((int64_t)1 << 27) ? 21 : 20));
+    while (lg > 16 && ((int64_t)1 << lg) * 4 > n) --lg;
+    return (int64_t)1 << lg;
+}
+
+static int sample_sort64(uint64_t *keys_a, uint64_t *keys_b, uint64_t *keys_c, uint32_t *vals_a, uint32_t *vals_b, uint32_t *u0, uint32_t *u1,
+                         uint32_t *big, uint32_t *small, uint32_t *words, uint32_t *final_vals, int64_t n, int key_bits, const SortScratch &ss,
+                         hipStream_t st, sa_amd_stats *local, const Tuning &tn, bool *done, bool trace)
+{
+    *done = false;
+    const int64_t S = sample_count(n, tn);
+    if (S < 65536 || n < 4 * S || n >= ((int64_t)1 << 32)) return SA_AMD_OK;
+    // ---- the sample, sorted (its values are scratch) ----
+    uint64_t *samp = keys_c, *samp_alt = keys_c + S;
+    PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_ss_sample), dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, st, (const uint64_t *)keys_a, n, S, samp));
+    SortResult sr;
+    int rc = sort_pairs(samp, u0, samp_alt, u1, S, 0, key_bits, ss, nullptr, st, &sr, tn, true);
+    if (rc) return rc;
+    local->sort_passes += sr.passes; local->sorted_elements += (int64_t)sr.passes * S;
+    const uint64_t *sample = sr.keys;
+    // ---- scratch layout ----
+    const int64_t tiles1 = ceil_div(n, SS_TILE), max_tiles2 = tiles1 + SS_WAYS;
+    const int64_t per = ceil_div(tiles1, SS_CHUNKS);
+    const int chunks = (int)ceil_div(tiles1, per);
+    uint32_t *counts = big;                                            // level 1: tiles1 x 256, level 2: max_tiles2 x 512
+    uint32_t *tot1 = small, *base1 = tot1 + SS_CHUNKS * SS_WAYS, *seg_start = base1 + SS_CHUNKS * SS_WAYS, *seg_first = seg_start + 320;
+    uint32_t *tot2 = seg_first + 320, *bstart = tot2 + SS_WAYS * SS_IDS2;
+    uint32_t *tile_seg = bstart + SS_BUCKETS + 64, *tile_base = tile_seg + ((max_tiles2 + 63) & ~(int64_t)63);
+    // ---- level 1 ----
+    PROF(KC_SS_COUNT, n, st, hipLaunchKernelGGL((k_ss_count<1>), dim3((unsigned)tiles1), dim3(SS_THREADS), 0, st, (const uint64_t *)keys_a, n, sample, S,
+                                                (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, counts));
+    PROF(KC_RR_SCAN, tiles1, st, hipLaunchKernelGGL((k_ss_scan_tiles<SS_WAYS>), dim3((unsigned)chunks), dim3(SS_WAYS), 0, st, counts, tiles1, per,
+                                                    (const uint32_t *)nullptr, tot1));
+    PROF(KC_RR_SCAN, chunks, st, hipLaunchKernelGGL((k_ss_bases1), dim3(1), dim3(SS_WAYS), 0, st, (const uint32_t *)tot1, chunks, base1, seg_start, seg_first));
+    PROF(KC_RR_SCAN, max_tiles2, st, hipLaunchKernelGGL((k_ss_tiles), dim3(SS_WAYS + 1), dim3(256), 0, st, (const uint32_t *)seg_start, (const uint32_t *)seg_first,
+                                                        max_tiles2, tile_seg, tile_base));
+    PROF(KC_SS_SCATTER, n, st, hipLaunchKernelGGL((k_ss_scatter<1>), dim3((unsigned)tiles1), dim3(SS_THREADS), 0, st, (const uint64_t *)keys_a, (const uint32_t *)nullptr, n,
+                                                  sample, S, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                                  (const uint32_t *)counts, (const uint32_t *)base1, per, keys_b, vals_a));
+    // ---- level 2 (the pairs of a segment stay inside it: keys_b -> keys_a) ----
+    PROF(KC_SS_COUNT, n, st, hipLaunchKernelGGL((k_ss_count<2>), dim3((unsigned)max_tiles2), dim3(SS_THREADS), 0, st, (const uint64_t *)keys_b, n, sample, S,
+                                                (const uint32_t *)tile_seg, (const uint32_t *)tile_base, (const uint32_t *)seg_start, counts));
+    PROF(KC_RR_SCAN, max_tiles2, st, hipLaunchKernelGGL((k_ss_scan_tiles<SS_IDS2>), dim3(SS_WAYS), dim3(SS_IDS2), 0, st, counts, max_tiles2, (int64_t)0,
+                                                        (const uint32_t *)seg_first, tot2));
+    PROF(KC_RR_SCAN, SS_WAYS, st, hipLaunchKernelGGL((k_ss_bases2), dim3(SS_WAYS), dim3(SS_IDS2), 0, st, (const uint32_t *)tot2, (const uint32_t *)seg_start, bstart, (uint32_t)n));
+    PROF(KC_SS_SCATTER, n, st, hipLaunchKernelGGL((k_ss_scatter<2>), dim3((unsigned)max_tiles2), dim3(SS_THREADS), 0, st, (const uint64_t *)keys_b, (const uint32_t *)vals_a, n,
+                                                  sample, S, (const uint32_t *)tile_seg, (const uint32_t *)tile_base, (const uint32_t *)seg_start,
+                                                  (const uint32_t *)counts, (const uint32_t *)bstart, (int64_t)1, keys_a, vals_b));
+    // ---- level 3: every bucket in LDS (keys_a -> keys_b, values -> final_vals) ----
+    HIP_TRY(hipMemsetAsync(words, 0, 16, st));
+    PROF(KC_SS_BUCKET, n, st, hipLaunchKernelGGL((k_ss_bucket_sort<SB_SMALL_THREADS, SB_SMALL_ITEMS, 9, 0, false>), dim3((unsigned)SS_BUCKETS), dim3(SB_SMALL_THREADS), 0, st,
+                                                 (const uint64_t *)keys_a, (const uint32_t *)vals_b, (const uint32_t *)bstart, keys_b, final_vals, words, words + 4));
+    PROF(KC_SS_BUCKET, 0, st, hipLaunchKernelGGL((k_ss_bucket_sort<SB_THREADS, SB_ITEMS, 10, SB_SMALL_CAP, true>), dim3((unsigned)SS_BUCKETS), dim3(SB_THREADS), 0, st,
+                                                 (const uint64_t *)keys_a, (const uint32_t *)vals_b, (const uint32_t *)bstart, keys_b, final_vals, words, words + 4));
+    uint32_t res[2] = { 0, 0 };
+    { const int rcw = read_words(res, words, 8, st); if (rcw) return rcw; }
+    local->sort_passes += 3; local->sorted_elements += 3 * n;
+    if (trace) fprintf(stderr, "suffix_array_amd: sample sort: %lld samples, largest bucket %u (a workgroup holds %d), %u oversize buckets that are no equality buckets\n",
+                       (long long)S, res[1], SB_CAP, res[0]);
+    *done = res[0] == 0;
+    return SA_AMD_OK;
+}
+
+#endif  // SA_AMD_DIAG
+
 // symbol codes and key geometry from the sigma = 256 histogram; returns the number of key bits to sort
 static int make_key_params(const uint32_t *hist, KeyParams *P, int *sigma_out, int kb_max = 64)
 {
@@ -1376,9 +1452,35 @@ struct DeviceBuild {
                                                               counted ? fc.counts : (uint32_t *)nullptr, fc.chunk_elems, fc.G, (1u << nb0) - 1u));
             // (a text of ONE byte value -- a zero-filled file -- has the same key everywhere but at its end: its passes are the identity
             // and are looked for; any other text does not pay the read-backs)
+            // diagnostic library, SA_AMD_SAMPLE_SORT=1 (a measured dead end, profiles/r04_sample_sort_64.txt): the sample sort -- two
+            // distribution passes over quantile digits + every bucket ordered in LDS -- instead of one LSD pass per digit
+            bool ss_done = false;
+#ifdef SA_AMD_DIAG
+            if (iota && counted && tn.sample_sort && n >= tn.sample_sort_min_n && key_bits > 32 && onesweep_on(w.ss, tn) && !timing_only()) {
+                const size_t need_big = ((size_t)ceil_div(n, SS_TILE) + SS_WAYS) * SS_IDS2 * 4;
+                if (need_big <= (size_t)n * 4 && (size_t)n * 4 >= ((size_t)4 << 20)) {
+                    rc = sample_sort64(w.keysA, w.keysB, w.keysC, w.valsA, w.valsB, w.U0, w.U1, w.isa, w.G0, w.bk_start, SA, n, key_bits, w.ss, st, &local, tn,
+                                       &ss_done, trace);
+                    if (rc) return rc;
+                    if (ss_done) { sr.keys = w.keysB; sr.vals = SA; sr.passes = 3; sr.skipped = 0; }
+                    else {
+                        // (cannot sort this text in workgroup-sized buckets: the keys again, then the LSD engine)
+                        HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
+                        if (P.gram > 0)
+                            PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false, true>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                                          w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out, fc.counts, fc.chunk_elems, fc.G, (1u << nb0) - 1u));
+                        else
+                            PROF(KC_BUILD_KEYS, n, st, hipLaunchKernelGGL((k_build_keys<false>), dim3((unsigned)ceil_div(ceil_div(n, KB_TILE), KB_TPW)), dim3(KB_THREADS), 0, st, dT, n, P,
+                                                                          w.keysA, vals0, (uint32_t *)nullptr, 0, packed_out, fc.counts, fc.chunk_elems, fc.G, (1u << nb0) - 1u));
+                    }
+                }
+            }
+#endif
+            if (!ss_done) {
             rc = sort_pairs(w.keysA, w.valsA, w.keysB, w.valsB, n, 0, key_bits, w.ss, SA, st, &sr, tn, iota, sigma == 1, counted);
             if (rc) return rc;
             local.sort_passes += sr.passes; local.sorted_elements += (int64_t)sr.passes * n;
+            }
         }
         P.packed = packed_out;
         if (sr.vals != SA) {   // n == 1: no pass ran, the values are still in the input buffer

@@ -11,6 +11,7 @@
 #include "../kernels/extras.hpp"
 #include "../kernels/small.hpp"
 #ifdef SA_AMD_DIAG
+#include "../kernels/sample_sort.hpp"
 #include "../kernels/radix_sort_diag.hpp"
 #include "../kernels/induce_proto.hpp"
 #endif
@@ -97,14 +98,23 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
 enum KClass { KC_BYTE_HIST = 0, KC_BUILD_KEYS, KC_UPSWEEP, KC_SPINE, KC_DOWNSWEEP, KC_RR_COUNT, KC_RR_SCAN, KC_RR_APPLY,
-              KC_GATHER, KC_SCATTER, KC_LOCAL, KC_MISC, KC_UPSWEEP32, KC_DOWNSWEEP32, KC_ONESWEEP, KC_ONESWEEP32, KC_FINISH, KC_BUCKET, KC_COUNT };
+              KC_GATHER, KC_SCATTER, KC_LOCAL, KC_MISC, KC_UPSWEEP32, KC_DOWNSWEEP32, KC_ONESWEEP, KC_ONESWEEP32, KC_FINISH, KC_BUCKET,
+#ifdef SA_AMD_DIAG
+              KC_SS_COUNT, KC_SS_SCATTER, KC_SS_BUCKET,
+#endif
+              KC_COUNT };
 static const char *const kclass_names[KC_COUNT] = { "k_byte_hist", "k_build_keys", "k_radix_upsweep", "k_spine_rows",
                                                     "k_radix_downsweep", "k_rr_count", "k_rr_scan", "k_rr_apply",
                                                     "k_gather_key2", "k_scatter_pairs", "k_group_sort", "misc",   // (k_gather_key2: the plain gathers; k_group_sort: all fused gather + sort kernels)
                                                     "k_radix_upsweep32", "k_radix_downsweep32",
                                                     "k_onesweep", "k_onesweep32",      // single-pass tile scatter, 64- / 32-bit keys (kernels/onesweep.hpp)
                                                     "k_finish_sorted",                 // one pass over the sorted keys that orders the small groups in place
-                                                    "k_bucket_sort" };                 // the low 16 bits of the 32-bit first stage, bucket by bucket in LDS (kernels/bucket_sort.hpp)
+                                                    "k_bucket_sort"                    // the low 16 bits of the 32-bit first stage, bucket by bucket in LDS (kernels/bucket_sort.hpp)
+#ifdef SA_AMD_DIAG
+                                                    , "k_ss_count", "k_ss_scatter",    // diagnostic library: sample sort of the 64-bit stage (kernels/sample_sort.hpp), the two distribution
+                                                    "k_ss_bucket_sort"                 // levels and every bucket ordered in LDS
+#endif
+                                                    };
 struct Profiler {
     bool on = false;
     uint64_t mask = ~0ull;      // kernel classes that get events (each pair costs a few microseconds of host time)

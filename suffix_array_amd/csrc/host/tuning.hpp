@@ -85,6 +85,11 @@ struct Tuning {
     int bucket_bits = 0;             // SA_AMD_BUCKET_BITS: key bits ordered by the two global passes in front of the bucket sort (0 = by text size, 16, 18)
     int bucket_shape = -1;           // SA_AMD_BUCKET_SHAPE: workgroup shape of that sort tried first (host/pipeline.hpp, bk_shapes; -1 = the smallest default one that holds the largest bucket)
 #ifdef SA_AMD_DIAG
+    // the sample sort of the 64-bit stage (kernels/sample_sort.hpp): a measured dead end of round 4 (profiles/r04_sample_sort_64.txt),
+    // kept in the diagnostic library with its tests -- correct, not faster than the eight LSD passes
+    bool sample_sort = false;        // SA_AMD_SAMPLE_SORT=1: the 64-bit stage's initial sort is the sample sort for texts of at least ...
+    int64_t sample_sort_min_n = (int64_t)1 << 26;   // ... SA_AMD_SAMPLE_SORT_MIN_N bytes
+    int sample_log = 0;              // SA_AMD_SAMPLE_LOG: log2 of the number of sampled keys (16..24; 0 = by the size of the text)
     bool timing_only_initial_sort = false;     // SA_AMD_TIMING_ONLY_INITIAL_SORT (diag library only: the array is NOT finished)
 #endif
 
@@ -139,6 +144,7 @@ struct Tuning {
         if (t.onesweep32_shape >= n_os32) t.onesweep32_shape = 0;
         t.no_big_group_sort = env_flag("SA_AMD_NO_BIG_GROUP_SORT");
         t.no_defer = env_flag("SA_AMD_NO_DEFER");
+
         t.no_text_keys = env_flag("SA_AMD_NO_TEXT_KEYS");
         t.no_bucket_sort = env_flag("SA_AMD_NO_BUCKET_SORT");
         t.bucket_min_n = env_int("SA_AMD_BUCKET_MIN_N", (int64_t)1 << 25, 1, (int64_t)1 << 40);
@@ -148,6 +154,10 @@ struct Tuning {
         if (t.bucket_bits != 16 && t.bucket_bits != 18) t.bucket_bits = 0;
         t.bucket_shape = (int)env_int("SA_AMD_BUCKET_SHAPE", -1, -1, 64);
 #ifdef SA_AMD_DIAG
+        t.sample_sort = env_flag("SA_AMD_SAMPLE_SORT");
+        t.sample_sort_min_n = env_int("SA_AMD_SAMPLE_SORT_MIN_N", (int64_t)1 << 26, (int64_t)1 << 17, (int64_t)1 << 40);
+        t.sample_log = (int)env_int("SA_AMD_SAMPLE_LOG", 0, 0, 24);
+        if (t.sample_log != 0 && t.sample_log < 16) t.sample_log = 16;
         t.timing_only_initial_sort = env_flag("SA_AMD_TIMING_ONLY_INITIAL_SORT");
 #endif
         return t;

@@ -19,6 +19,9 @@ int32_t sa_amd_debug_sort_variant_count(void);
 const char *sa_amd_debug_sort_variant_name(int32_t index);
 /* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit); host buffers */
 int32_t sa_amd_test_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit, int32_t end_bit);
+/* the sample sort of the 64-bit stage (kernels/sample_sort.hpp; count >= 262 144): keys in order out, vals[i] = the index key i came
+ * from; *done = 0: a bucket that is no equality bucket did not fit a workgroup -- the pipeline then takes the LSD sort */
+int32_t sa_amd_test_sample_sort64(uint64_t *keys, uint32_t *vals, int64_t count, int32_t key_bits, int32_t *done);
 /* the 32-bit-key form of the same sort (first stage of the two-stage initial sort) */
 int32_t sa_amd_test_sort_pairs32(uint32_t *keys, uint32_t *vals, int64_t count, int32_t begin_bit, int32_t end_bit);
 /* the same order through two global passes over the top 16 (or 18: nine-bit digits) key bits + the in-LDS bucket sort of the

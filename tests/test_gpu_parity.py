@@ -117,6 +117,67 @@ def test_bucket_sort_32bit_keys(count, tops, shape, top_bits, monkeypatch):
         assert np.array_equal(pair_of[v2], k2)
 
 
+def _sample_sort_cases(rng):
+    """key sets for the sample sort of the 64-bit stage: flat, clustered, with keys that thousands to millions of elements share
+    (equality buckets), constant, two-valued, already in order"""
+    n = 1_500_000
+    flat = rng.integers(0, 1 << 61, size=n, dtype=np.uint64)
+    cases = {"flat": flat}
+    heavy = flat.copy()
+    heavy[rng.random(n) < 0.45] = np.uint64(0x0123456789ABCDE)              # one key on 45 % of the elements
+    for k, reps in enumerate((200_000, 20_000, 9_000, 5_000, 3_000, 1_000)):   # and medium-heavy ones around a workgroup's capacity
+        heavy[rng.integers(0, n, size=reps)] = np.uint64(0x1000000000000000 + 977 * k)
+    cases["heavy keys"] = heavy
+    cases["clustered"] = (rng.integers(0, 3000, size=n, dtype=np.uint64) << np.uint64(40)) | rng.integers(0, 1 << 12, size=n, dtype=np.uint64)
+    cases["constant"] = np.full(400_000, 7, dtype=np.uint64)
+    cases["two values"] = np.where(rng.random(700_000) < 0.3, np.uint64(5), np.uint64(1 << 60)).astype(np.uint64)
+    cases["in order"] = np.sort(flat[:900_000])
+    cases["few distinct"] = rng.integers(0, 97, size=1_000_003, dtype=np.uint64) * np.uint64((1 << 54) + 12345)      # (< 2^61)
+    cases["smallest"] = rng.integers(0, 1 << 50, size=262_144, dtype=np.uint64)
+    return cases
+
+
+def test_sample_sort_of_the_64_bit_stage(monkeypatch):
+    """kernels/sample_sort.hpp through the diagnostic library's hook: two distribution levels over sampled splitters (equality
+    buckets for keys that are splitters) + every bucket ordered in LDS == numpy's sort, the values say where each key came from"""
+    D = sa.diag_lib()
+    rng = np.random.default_rng(20261005)
+    for name, keys in _sample_sort_cases(rng).items():
+        for bits in (61, 64):
+            k = keys.copy()
+            if bits == 64 and name == "flat":
+                k |= rng.integers(0, 8, size=k.size, dtype=np.uint64) << np.uint64(61)
+            vals = np.zeros(k.size, dtype=np.uint32)
+            done = ctypes.c_int32(-1)
+            src = k.copy()
+            assert D.sa_amd_test_sample_sort64(k.ctypes.data, vals.ctypes.data, k.size, bits, ctypes.byref(done)) == 0, name
+            assert done.value == 1, name
+            assert np.array_equal(k, np.sort(src)), name
+            assert np.array_equal(src[vals], k), name
+            assert np.array_equal(np.sort(vals), np.arange(k.size, dtype=np.uint32)), name
+
+
+def test_sample_sort_as_the_initial_sort_of_a_build(oracle, monkeypatch):
+    """diagnostic library, SA_AMD_SAMPLE_SORT=1: whole builds whose 64-bit initial sort is the sample sort (a word-structured text,
+    one with a stock sentence that tens of thousands of suffixes share -- equality buckets --, a periodic one) give the oracle's
+    arrays; the trace of the dead end's numbers is profiles/r04_sample_sort_64.txt"""
+    D = sa.diag_lib()
+    monkeypatch.setenv("SA_AMD_SAMPLE_SORT", "1")
+    monkeypatch.setenv("SA_AMD_SAMPLE_SORT_MIN_N", str(1 << 17))
+    monkeypatch.setenv("SA_AMD_NO_TOP32", "1")
+    stock = np.frombuffer(b" the quick brown fox jumps over the lazy dog and runs away;", dtype=np.uint8)
+    base = corpus.english(3_000_000, 17)
+    with_stock = base.copy()
+    for at in np.random.default_rng(5).integers(0, base.size - stock.size, size=40_000):
+        with_stock[at:at + stock.size] = stock
+    texts = [corpus.english_corpus(2_000_003, 3), with_stock, np.resize(np.frombuffer(b"abcdefghij" * 37 + b"z", dtype=np.uint8), 1_500_000).copy(),
+             corpus.english(400_000, 9)]
+    for t in texts:
+        out = np.zeros(t.size + 1, dtype=np.uint32)
+        assert D.sa_amd_saca_u8(t.ctypes.data, out.ctypes.data, t.size) == 0
+        assert np.array_equal(out, oracle.sais(t)), t.size
+
+
 @pytest.mark.parametrize("engine", ["single-pass", "three-kernel"])
 def test_radix_sort_constant_and_skewed_digits(engine, monkeypatch):
     if engine == "three-kernel":
@@ -883,7 +944,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_NO_FIRST_TAIL", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_GRAM_TAIL", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS", "SA_AMD_SAMPLE_SORT", "SA_AMD_SAMPLE_SORT_MIN_N", "SA_AMD_SAMPLE_LOG",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
