@@ -105,7 +105,8 @@ void sa_amd_release_cache(void);
  * [0] acquire device block + stream, [1] text upload, [2] build on the device, [3] suffix array download,
  * [4] release, [5] total, [6] helper threads of the staged download (0 = one plain hipMemcpy), [7] the fraction of the
  * array that was copied to the host before the build was done (early download: large arrays whose last refinement rounds
- * touch few slots start travelling while those rounds run; [3] is then the time behind the build only).  Returns 8. */
+ * touch few slots start travelling while those rounds run; [3] is then the time behind the build only), [8] bytes of the
+ * workspace that lived in pinned host memory (reduced-memory route: the device could not give the whole workspace).  Returns 9. */
 int32_t sa_amd_last_host_timing(double *ms, int32_t capacity);
 
 /* statistics of the most recent build issued by the calling thread (any entry point) */

@@ -243,10 +243,10 @@ def saca_batch(texts, devices=None):
 
 def last_host_timing() -> dict:
     """wall-clock phases (ms) of this thread's most recent host-pointer build (sa_amd_last_host_timing)"""
-    v = (ctypes.c_double * 8)()
-    lib().sa_amd_last_host_timing(v, 8)
+    v = (ctypes.c_double * 9)()
+    lib().sa_amd_last_host_timing(v, 9)
     return {"acquire": v[0], "h2d": v[1], "build": v[2], "d2h": v[3], "release": v[4], "total": v[5], "staged_threads": int(v[6]),
-            "early_fraction": v[7]}
+            "early_fraction": v[7], "workspace_bytes_in_host_memory": int(v[8])}
 
 
 def last_stats() -> dict:

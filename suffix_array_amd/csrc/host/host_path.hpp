@@ -34,7 +34,7 @@ static double wall_ms()
 }
 
 // phases of the last host-pointer call of this thread, in milliseconds (sa_amd_last_host_timing)
-struct HostTiming { double acquire = 0, h2d = 0, build = 0, d2h = 0, release = 0, total = 0; int staged = 0; double early = 0; };      // early: fraction of the array that travelled before the build was done
+struct HostTiming { double acquire = 0, h2d = 0, build = 0, d2h = 0, release = 0, total = 0; int staged = 0; double early = 0, spill = 0; };      // early: fraction of the array that travelled before the build was done
 static thread_local HostTiming g_host_timing;
 
 // ---- device -> caller's pageable buffer through pinned staging + helper threads ----
@@ -239,13 +239,40 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     const size_t tb = align_up((size_t)n, 256), sb = align_up(((size_t)n + 1) * 4, 256);
     const size_t need = tb + sb + wb;
     DevBlock blk;
+    PinBlock spill;                                              // reduced-memory route: the workspace slabs the device block cannot hold
+    struct SpillEnd { PinBlock &b_; ~SpillEnd() { if (b_.p) pool().release_pinned(b_); } } spill_end{ spill };
+    size_t ws_dev = wb, ws_host = 0;                             // bytes of the workspace in the device block / in pinned host memory
+    void *dW2 = nullptr;
     hipStream_t st = nullptr;
     int rc = pool().stream(cur, &st);
     if (rc != SA_AMD_OK) return rc;
     rc = pool().acquire(cur, need, &blk);
+    if (rc == SA_AMD_ENOMEM && env_int("SA_AMD_NO_REDUCED", 0, 0, 1) == 0) {
+        // The device cannot give text + array + the whole workspace (another tenant, or a text near MAX_LENGTH next to other
+        // blocks).  The reference's engine needs 257 KiB beside its output, so "out of memory" is not an answer a drop-in should
+        // give lightly: take what the device has, keep the text, the array and the most-used slabs there (carve() orders them by
+        // need) and put the slabs that do not fit into pinned host memory, which the kernels reach over PCIe -- slow (the lists
+        // and the third key buffer go first), correct.  SA_AMD_NO_REDUCED=1: SA_AMD_ENOMEM as before.
+        (void)hipGetLastError();
+        size_t free_b = 0, total_b = 0;
+        const size_t margin = (size_t)256 << 20;
+        const size_t floor_ws = carve(nullptr, n, ~(size_t)0, nullptr).bytes - (size_t)n * 32 - 64 * 8;      // everything but one value buffer, isa, the lists and the third key buffer
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > margin + tb + sb + floor_ws) {
+            const size_t cap = ((free_b - margin) & ~(((size_t)2 << 20) - 1)) - tb - sb;
+            const Workspace dry = carve(nullptr, n, cap, nullptr);
+            rc = pool().acquire(cur, tb + sb + align_up(dry.bytes, 256), &blk);
+            if (rc == SA_AMD_OK && dry.bytes2 > 0) {
+                rc = pool().pinned(dry.bytes2, node, cur, &spill);
+                if (rc == SA_AMD_OK) rc = hip_status(hipHostGetDevicePointer(&dW2, spill.p, 0));
+                if (rc != SA_AMD_OK) { pool().release(blk); blk = DevBlock(); }
+            }
+            if (rc == SA_AMD_OK) { ws_dev = align_up(dry.bytes, 256); ws_host = dry.bytes2; }
+        } else (void)hipGetLastError();
+    }
     if (rc != SA_AMD_OK) { pool().release_stream(cur, st); return rc; }
     double t0 = wall_ms();
     tm.acquire = t0 - t_begin;
+    tm.spill = (double)ws_host;
     uint8_t *dT = (uint8_t *)blk.p;
     uint32_t *dSA = (uint32_t *)((char *)blk.p + tb);
     void *dW = (char *)blk.p + tb + sb;
@@ -319,7 +346,8 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     pull.chunk = (size_t)env_int("SA_AMD_EARLY_CHUNK_BYTES", (int64_t)STAGE_BYTES, 65536, (int64_t)STAGE_BYTES) & ~(size_t)4095;
     const int64_t early_wait = env_int("SA_AMD_EARLY_WAIT_CHUNKS", 0, 0, 1 << 20);     // tests: the build waits until so many chunks have been copied
     // (the pullers are helper threads: a pool without helpers would run them only when the build is over)
-    const bool early_on = staged && early_div > 0 && out_bytes_all >= early_min && out_bytes_all >= 4 * pull.chunk && hp.helpers() > 0;
+    // (not on the reduced-memory route: the values sent behind would come out of a slab that may live in host memory)
+    const bool early_on = staged && early_div > 0 && out_bytes_all >= early_min && out_bytes_all >= 4 * pull.chunk && hp.helpers() > 0 && ws_host == 0;
     if (early_on && rc == SA_AMD_OK && pool().stream(cur, &cst) == SA_AMD_OK) {
         early.off = with_sentinel ? 1 : 0;
         early.threshold = (int64_t)n / early_div;
@@ -371,7 +399,7 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     } pull_end{ hp, pull_job, pull };
     if (rc == SA_AMD_OK) {
         LaneTurn turn(lanes.run, turns);
-        rc = build_device(dT, dSA, n, dW, (int64_t)wb, st, nullptr, early.start ? &early : nullptr);
+        rc = build_device(dT, dSA, n, dW, (int64_t)ws_dev, st, nullptr, early.start ? &early : nullptr, dW2, (int64_t)ws_host);
     }
     // (usually done by now; otherwise no further unit is started -- SA_AMD_PREFAULT_WAIT=1: every page is mapped first, A/B)
     if (env_int("SA_AMD_PREFAULT_WAIT", 0, 0, 1) == 0) prefault_stop.store(true, std::memory_order_relaxed);
@@ -448,8 +476,9 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     tm.total = wall_ms() - t_begin;
     g_host_timing = tm;
     if (env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 2)
-        fprintf(stderr, "suffix_array_amd: n=%d device %d numa node %d acquire %.2f h2d %.2f build %.2f d2h %.2f (staged %d, %.0f %% of the array sent before the build was done) release %.2f total %.2f ms\n", n,
-                cur, node, tm.acquire, tm.h2d, tm.build, tm.d2h, tm.staged, tm.early * 100.0, tm.release, tm.total);
+        fprintf(stderr, "suffix_array_amd: n=%d device %d numa node %d acquire %.2f h2d %.2f build %.2f d2h %.2f (staged %d, %.0f %% of the array sent before the build was done) release %.2f total %.2f ms%s\n", n,
+                cur, node, tm.acquire, tm.h2d, tm.build, tm.d2h, tm.staged, tm.early * 100.0, tm.release, tm.total,
+                tm.spill > 0 ? " -- REDUCED-MEMORY route: part of the workspace in pinned host memory" : "");
     return rc;
 }
 

@@ -79,52 +79,65 @@ struct Workspace {
     uint32_t *bk_start;             // bucket sort of the 32-bit first stage: 2^16 + 1 or 2^18 + 1 bucket starts
     uint32_t *early_bits, *early_cnt;    // early download: bitmap over the n + 1 entries of the downloaded array, marked entries per tile
     SortScratch ss;
-    size_t bytes;
+    size_t bytes, bytes2;           // in the first (device) block, in the second (reduced-memory route: pinned host) block
 };
 
-static Workspace carve(void *base, int64_t n)
+// Slabs are laid out in the order of the take() calls below.  cap / base2: the REDUCED-MEMORY route of the host-pointer entry
+// points (host/host_path.hpp): when the device cannot give the whole workspace, the first `cap` bytes' worth of slabs live in
+// the device block `base` and every slab that no longer fits lives in `base2`, a block of pinned host memory that the kernels
+// reach over PCIe (slow, correct: the alternative is SA_AMD_ENOMEM).  So the order below is by need: first the small slabs that
+// workgroups talk through (look-back granules, tickets, counters -- they must be device memory), then the big ones from the most
+// to the least used.  w.bytes = bytes in the first block, w.bytes2 = bytes in the second (0 without a cap).
+static Workspace carve(void *base, int64_t n, size_t cap = ~(size_t)0, void *base2 = nullptr)
 {
     Workspace w;
     const size_t N = (size_t)(n > 0 ? n : 1);
-    size_t off = 0;
-    auto take = [&](size_t b) { size_t o = off; off = align_up(off + b, 256); return (char *)base + o; };
+    size_t off = 0, off2 = 0;
+    auto take = [&](size_t b) {
+        if (off + b <= cap) { size_t o = off; off = align_up(off + b, 256); return (char *)base + o; }
+        size_t o = off2; off2 = align_up(off2 + b, 256); return (char *)base2 + o;
+    };
+    const size_t rr_tiles = (size_t)ceil_div((int64_t)N, RR_TILE);
+    const size_t ft_tiles = (size_t)ceil_div((int64_t)N, FT_TILE) + 1;
+    const size_t gram_entries = N < GRAM_MAX_ENTRIES ? N : GRAM_MAX_ENTRIES;
+    // ---- small, shared between workgroups ----
+    w.spine = (uint32_t *)take((size_t)RADIX * SORT_MAX_WG * 4);
+    w.digit_tot = (uint32_t *)take(RADIX * 4);
+    w.os_status = (unsigned long long *)take(((size_t)ceil_div((int64_t)N, OS_MIN_TILE) + 1) * RADIX * 8);
+    w.os_err = (uint32_t *)take(256);
+    w.hist = (uint32_t *)take(256 * 4);
+    w.total = (uint32_t *)take(256);
+    w.chg = (uint32_t *)take((size_t)RR_CHG_COUNTERS * 32 * 4);      // (directly behind w.total: read back together)
+    w.tcnt = (uint32_t *)take(rr_tiles * 4);
+    w.thead = (uint32_t *)take(rr_tiles * 4);
+    w.tnext = (uint32_t *)take(rr_tiles * 4);
+    w.surv_cnt = (uint32_t *)take(rr_tiles * 4);          // (not tcnt: refine_list uses that one for its own compaction)
+    w.ft_cnt = (uint32_t *)take(ft_tiles * 4);
+    w.ft_head = (uint32_t *)take(ft_tiles * 4);
+    w.bk_start = (uint32_t *)take(((size_t)BK_BUCKETS_MAX + 1) * 4);
+    w.early_cnt = (uint32_t *)take(((N + 1 + EARLY_TILE - 1) / EARLY_TILE + 8) * 4);
+    w.gram_table = (uint4 *)take((gram_entries / 64 + 1) * 16);
+    // ---- n / 8 .. n / 2 bytes ----
+    w.has_isa = (uint32_t *)take((N + 31) / 32 * 4);
+    w.surv_bits = (uint32_t *)take((N + 31) / 32 * 4);
+    w.todo_bits = (uint32_t *)take((N + 31) / 32 * 4);
+    w.early_bits = (uint32_t *)take(((N + 1 + 31) / 32 + EARLY_THREADS) * 4);           // (whole tiles of 256 words)
+    w.gram_flags = (uint8_t *)take(gram_entries + 64);
+    w.packed = (uint8_t *)take(N / 2 + 64);
+    // ---- the big ones, most used first ----
     w.keysA = (uint64_t *)take((N + 64) * 8);         // (+64: as two halves of n + 1 32-bit entries each, see scatter_binned)
     w.keysB = (uint64_t *)take((N + 64) * 8);
-    w.keysC = (uint64_t *)take((N + 64) * 8);
     w.valsA = (uint32_t *)take(N * 4);
     w.valsB = (uint32_t *)take(N * 4);
     w.isa = (uint32_t *)take(N * 4);
     w.U0 = (uint32_t *)take(N * 4);
-    w.U1 = (uint32_t *)take(N * 4);
     w.G0 = (uint32_t *)take(N * 4);
+    w.U1 = (uint32_t *)take(N * 4);
     w.G1 = (uint32_t *)take(N * 4);
-    w.spine = (uint32_t *)take((size_t)RADIX * SORT_MAX_WG * 4);
-    w.digit_tot = (uint32_t *)take(RADIX * 4);
-    const size_t rr_tiles = (size_t)ceil_div((int64_t)N, RR_TILE);
-    w.tcnt = (uint32_t *)take(rr_tiles * 4);
-    w.thead = (uint32_t *)take(rr_tiles * 4);
-    w.tnext = (uint32_t *)take(rr_tiles * 4);
-    w.hist = (uint32_t *)take(256 * 4);
-    w.total = (uint32_t *)take(256);
-    w.chg = (uint32_t *)take((size_t)RR_CHG_COUNTERS * 32 * 4);      // (directly behind w.total: read back together)
-    w.has_isa = (uint32_t *)take((N + 31) / 32 * 4);
-    w.packed = (uint8_t *)take(N / 2 + 64);
-    const size_t gram_entries = N < GRAM_MAX_ENTRIES ? N : GRAM_MAX_ENTRIES;
-    w.gram_flags = (uint8_t *)take(gram_entries + 64);
-    w.gram_table = (uint4 *)take((gram_entries / 64 + 1) * 16);
-    w.surv_bits = (uint32_t *)take((N + 31) / 32 * 4);
-    w.surv_cnt = (uint32_t *)take(rr_tiles * 4);          // (not tcnt: refine_list uses that one for its own compaction)
-    w.todo_bits = (uint32_t *)take((N + 31) / 32 * 4);
-    const size_t ft_tiles = (size_t)ceil_div((int64_t)N, FT_TILE) + 1;
-    w.ft_cnt = (uint32_t *)take(ft_tiles * 4);
-    w.ft_head = (uint32_t *)take(ft_tiles * 4);
-    w.os_status = (unsigned long long *)take(((size_t)ceil_div((int64_t)N, OS_MIN_TILE) + 1) * RADIX * 8);
-    w.os_err = (uint32_t *)take(256);
-    w.bk_start = (uint32_t *)take(((size_t)BK_BUCKETS_MAX + 1) * 4);
-    w.early_bits = (uint32_t *)take(((N + 1 + 31) / 32 + EARLY_THREADS) * 4);           // (whole tiles of 256 words)
-    w.early_cnt = (uint32_t *)take(((N + 1 + EARLY_TILE - 1) / EARLY_TILE + 8) * 4);
+    w.keysC = (uint64_t *)take((N + 64) * 8);
     w.ss.spine = w.spine; w.ss.digit_tot = w.digit_tot; w.ss.status = w.os_status; w.ss.err = w.os_err;
     w.bytes = off;
+    w.bytes2 = off2;
     return w;
 }
 
@@ -1970,7 +1983,8 @@ struct DeviceBuild {
 };
 
 static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWork, int64_t work_bytes, hipStream_t st,
-                        sa_amd_stats *stats, EarlyDownload *early = nullptr)
+                        sa_amd_stats *stats, EarlyDownload *early = nullptr,
+                        void *dWork2 = nullptr, int64_t work2_bytes = 0)      // reduced-memory route: the slabs that do not fit work_bytes live here (device-visible pinned host memory)
 {
     const int64_t n = n32;
     DeviceBuild B;
@@ -1989,9 +2003,9 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
         if (stats) *stats = local;
         return SA_AMD_OK;
     }
-    B.w = carve(dWork, n);
+    B.w = dWork2 ? carve(dWork, n, (size_t)work_bytes, dWork2) : carve(dWork, n);
     const Workspace &w = B.w;
-    if ((int64_t)w.bytes > work_bytes) return SA_AMD_EINVAL;
+    if ((int64_t)w.bytes > work_bytes || (int64_t)w.bytes2 > work2_bytes) return SA_AMD_EINVAL;
     if (n <= tn.small_max) {
         // small texts: the whole construction in one launch of one workgroup, everything in LDS (kernels/small.hpp)
         if (n <= SM_LITE_SINGLE_N)

@@ -1,7 +1,11 @@
 // host/pool.hpp -- process-wide pool of device blocks, streams and pinned host blocks (mutex-protected).
 // One device block = text + SA + workspace of one build, so neither repeated calls of the host-pointer entry points
 // (the contract of `saca()`, reference src/saca.rs:9-15) nor the worker threads of sa_amd_saca_batch pay hipMalloc /
-// hipFree per call; the pool retains at most SA_AMD_CACHE_MAX_BYTES (default 128 GiB of the 288 GB: one 1 GiB text is a 58 GiB block) and
+// hipFree per call.  What the pool keeps PER DEVICE follows the work: at most twice the largest block any of the device's last
+// eight builds asked for (two workers of a batch alternate on two blocks), never more than SA_AMD_CACHE_MAX_BYTES (default
+// 128 GiB of a device's 288 GB: one 1 GiB text is a 58 GiB block) -- a process that indexed one 1 GiB text and goes on with
+// 64 MiB ones gives the 58 GiB back after eight of them instead of holding them for its lifetime -- and blocks that have not
+// been used for SA_AMD_CACHE_IDLE_MS (default 10 s) are freed by the next call that touches the pool.
 // sa_amd_release_cache() empties it.  Pinned blocks remember the NUMA node they were first touched on (helpers.hpp).
 #pragma once
 #include "helpers.hpp"
@@ -16,7 +20,7 @@ static size_t cache_limit()
 }
 
 // ---- pool of device blocks, streams and pinned staging buffers (process-wide, mutex-protected) ----
-struct DevBlock { int device = -1; void *p = nullptr; size_t bytes = 0; uint64_t stamp = 0; };      // stamp: when it was last handed back
+struct DevBlock { int device = -1; void *p = nullptr; size_t bytes = 0; uint64_t stamp = 0; double idle_since = 0; };      // stamp: order in which blocks were handed back; idle_since: when (ms)
 struct PinBlock { void *p = nullptr; size_t bytes = 0; int node = -1; uint64_t stamp = 0; };      // node: NUMA node its pages were first touched on (-1: wherever); stamp: when it was last handed back
 
 class ResourcePool {
@@ -26,13 +30,18 @@ class ResourcePool {
     std::vector<PinBlock> pinned_;
     size_t retained_ = 0, pinned_retained_ = 0;
     uint64_t clock_ = 0;
+    std::map<int, std::deque<size_t>> recent_;     // per device: what its last eight builds asked for
 
 public:
     // a free block of `device` with at least `need` bytes (the smallest such), else a new allocation
     int acquire(int device, size_t need, DevBlock *out)
     {
+        trim_idle();
         {
             std::lock_guard<std::mutex> lk(mu_);
+            std::deque<size_t> &rq = recent_[device];
+            rq.push_back(need);
+            if (rq.size() > 8) rq.pop_front();
             int best = -1;
             for (int i = 0; i < (int)blocks_.size(); ++i)
                 if (blocks_[i].device == device && blocks_[i].bytes >= need && (best < 0 || blocks_[i].bytes < blocks_[best].bytes)) best = i;
@@ -51,6 +60,7 @@ public:
             const size_t limit = cache_limit();
             if (want > limit) want = need > limit ? need : limit;
         }
+        if (device_limit_locked(device) < want) want = need;          // (slack that would be dropped on release anyway)
         void *p = nullptr;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
@@ -66,31 +76,69 @@ public:
     void release(const DevBlock &b)
     {
         if (!b.p) return;
-        const size_t limit = cache_limit();
         std::vector<DevBlock> drop;
         {
             std::lock_guard<std::mutex> lk(mu_);
+            const size_t limit = device_limit(b.device);
             if (b.bytes > limit) drop.push_back(b);
             else {
-                // evict the blocks that have been idle longest until the newcomer fits (it is the size the caller is working at).
-                // Not "the largest first": two workers of a batch alternate on two large blocks next to an older small one, and
+                // evict the device's blocks that have been idle longest until the newcomer fits (it is the size the caller is working
+                // at).  Not "the largest first": two workers of a batch alternate on two large blocks next to an older small one, and
                 // dropping the large idle block made the next call pay a 30 GiB hipMalloc -- 2 s, with the other worker's
                 // copies stalled behind it (profiles/r03_host_path.txt)
-                while (retained_ + b.bytes > limit && !blocks_.empty()) {
-                    int old = 0;
-                    for (int i = 1; i < (int)blocks_.size(); ++i) if (blocks_[i].stamp < blocks_[old].stamp) old = i;
+                for (;;) {
+                    size_t held = 0;
+                    int old = -1;
+                    for (int i = 0; i < (int)blocks_.size(); ++i)
+                        if (blocks_[i].device == b.device) {
+                            held += blocks_[i].bytes;
+                            if (old < 0 || blocks_[i].stamp < blocks_[old].stamp) old = i;
+                        }
+                    if (held + b.bytes <= limit || old < 0) break;
                     retained_ -= blocks_[old].bytes;
                     drop.push_back(blocks_[old]);
                     blocks_.erase(blocks_.begin() + old);
                 }
                 DevBlock kept = b;
                 kept.stamp = ++clock_;
+                kept.idle_since = now_ms();
                 blocks_.push_back(kept);
                 retained_ += b.bytes;
             }
         }
         for (auto &d : drop) (void)hipFree(d.p);
     }
+    // blocks nobody has asked for in SA_AMD_CACHE_IDLE_MS go back to the device (checked by whoever uses the pool next: there is no
+    // background thread -- a process that never calls again keeps its last blocks until sa_amd_release_cache or exit)
+    void trim_idle()
+    {
+        const double idle_ms = (double)env_int("SA_AMD_CACHE_IDLE_MS", 10000, 0, (int64_t)1 << 40);
+        if (idle_ms <= 0) return;
+        const double now = now_ms();
+        std::vector<DevBlock> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (int i = (int)blocks_.size() - 1; i >= 0; --i)
+                if (now - blocks_[i].idle_since > idle_ms) {
+                    retained_ -= blocks_[i].bytes;
+                    drop.push_back(blocks_[i]);
+                    blocks_.erase(blocks_.begin() + i);
+                }
+        }
+        for (auto &d : drop) (void)hipFree(d.p);
+    }
+    // what the pool may keep of a device's memory (mu_ held): twice the largest recent request, at least 256 MiB, at most the cap
+    size_t device_limit(int device)
+    {
+        size_t big = 0;
+        auto it = recent_.find(device);
+        if (it != recent_.end()) for (size_t v : it->second) big = v > big ? v : big;
+        size_t lim = 2 * (big + (big / 8 < ((size_t)1 << 30) ? big / 8 : ((size_t)1 << 30))) + ((size_t)256 << 20);      // (two blocks with acquire()'s slack)
+        if (lim < ((size_t)256 << 20)) lim = (size_t)256 << 20;
+        const size_t cap = cache_limit();
+        return lim < cap ? lim : cap;
+    }
+    size_t device_limit_locked(int device) { std::lock_guard<std::mutex> lk(mu_); return device_limit(device); }
     void trim(int device, size_t keep_bytes)                          // device < 0: all devices
     {
         std::vector<DevBlock> drop;
@@ -194,6 +242,7 @@ public:
             std::lock_guard<std::mutex> lk(mu_);
             drop.swap(blocks_); pdrop.swap(pinned_); sdrop.swap(streams_);
             retained_ = 0; pinned_retained_ = 0;
+            recent_.clear();
         }
         for (auto &d : drop) (void)hipFree(d.p);
         for (auto &d : pdrop) (void)hipHostFree(d.p);

@@ -577,9 +577,9 @@ SA_EXPORT void sa_amd_last_stats(sa_amd_stats *out)
 SA_EXPORT int32_t sa_amd_last_host_timing(double *ms, int32_t capacity)
 {
     const sa::HostTiming &t = sa::g_host_timing;
-    const double v[8] = { t.acquire, t.h2d, t.build, t.d2h, t.release, t.total, (double)t.staged, t.early };
-    for (int i = 0; i < capacity && i < 8; ++i) ms[i] = v[i];
-    return 8;
+    const double v[9] = { t.acquire, t.h2d, t.build, t.d2h, t.release, t.total, (double)t.staged, t.early, t.spill };
+    for (int i = 0; i < capacity && i < 9; ++i) ms[i] = v[i];
+    return 9;
 }
 
 SA_EXPORT int32_t sa_amd_device_count(void)

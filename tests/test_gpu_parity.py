@@ -376,6 +376,76 @@ def test_early_download_patches_the_slots_that_were_still_tied(oracle, monkeypat
         assert sa.last_stats()["rounds"] >= 1
 
 
+def _hip():
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipMemGetInfo.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    return hip
+
+
+def _free_hbm(hip):
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+    return int(f.value)
+
+
+def test_reduced_memory_route_when_the_device_is_nearly_full(oracle, monkeypatch):
+    """another tenant holds nearly all of the HBM: the full workspace (53.6 n bytes) cannot be had, and instead of SA_AMD_ENOMEM
+    the build keeps the text, the array and the most-used slabs on the device and puts the rest of the workspace into pinned
+    host memory (host/host_path.hpp) -- the oracle's array either way; SA_AMD_NO_REDUCED=1 restores the error"""
+    hip = _hip()
+    t = corpus.english_corpus(40 << 20, 6)
+    exp = oracle.sais(t)
+    sa.lib().sa_amd_release_cache()
+    need = int(t.size) * 5 + sa.workspace_bytes(int(t.size))
+    free = _free_hbm(hip)
+    hog = ctypes.c_void_p()
+    leave = int(need * 0.7)                                      # the device part gets ~70 % of what a build asks for, less the margin
+    assert hip.hipMalloc(ctypes.byref(hog), free - leave) == 0
+    try:
+        out = np.zeros(t.size + 1, dtype=np.uint32)
+        monkeypatch.setenv("SA_AMD_NO_REDUCED", "1")
+        with pytest.raises(sa.SuffixArrayError) as e:
+            sa.saca(t, out)
+        assert e.value.code == -2
+        monkeypatch.delenv("SA_AMD_NO_REDUCED")
+        sa.saca(t, out)
+        ht = sa.last_host_timing()
+        assert ht["workspace_bytes_in_host_memory"] > 0, ht
+        assert np.array_equal(out, exp)
+    finally:
+        hip.hipFree(hog)
+        sa.lib().sa_amd_release_cache()
+    out2 = np.zeros(t.size + 1, dtype=np.uint32)
+    sa.saca(t, out2)                                             # and with the memory back: the ordinary route
+    assert sa.last_host_timing()["workspace_bytes_in_host_memory"] == 0 and np.array_equal(out2, exp)
+
+
+def test_pool_gives_back_what_recent_builds_do_not_need(oracle, monkeypatch):
+    """the device-block pool keeps at most twice what the largest of a device's last eight builds asked for: a process that built
+    one large array and goes on with small ones does not sit on the large block (3.7 GiB here) for its lifetime; blocks idle for
+    SA_AMD_CACHE_IDLE_MS are freed by the next call"""
+    hip = _hip()
+    sa.lib().sa_amd_release_cache()
+    big, small = corpus.uniform(64 << 20, 3), corpus.uniform(1 << 20, 4)
+    out_b, out_s = np.zeros(big.size + 1, dtype=np.uint32), np.zeros(small.size + 1, dtype=np.uint32)
+    sa.saca(big, out_b)
+    held = _free_hbm(hip)
+    for _ in range(9):
+        sa.saca(small, out_s)
+    assert _free_hbm(hip) > held + (3 << 30)                     # the 3.7 GiB block went back after eight small builds
+    assert np.array_equal(out_s, oracle.sais(small))
+    monkeypatch.setenv("SA_AMD_CACHE_IDLE_MS", "1")
+    sa.saca(big, out_b)
+    held = _free_hbm(hip)
+    import time
+    time.sleep(0.05)
+    sa.saca(small, out_s)                                        # (touches the pool: the idle big block is freed)
+    assert _free_hbm(hip) > held + (3 << 30)
+    sa.lib().sa_amd_release_cache()
+
+
 def test_batch_entry_point(oracle):
     texts = [corpus.uniform(50_000, 50 + i) for i in range(3)] + [np.zeros(0, dtype=np.uint8), corpus.dna(30_000, 1)]
     outs = sa.saca_batch(texts)
@@ -944,7 +1014,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_NO_FIRST_TAIL", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_GRAM_TAIL", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS", "SA_AMD_SAMPLE_SORT", "SA_AMD_SAMPLE_SORT_MIN_N", "SA_AMD_SAMPLE_LOG",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS", "SA_AMD_SAMPLE_SORT", "SA_AMD_SAMPLE_SORT_MIN_N", "SA_AMD_SAMPLE_LOG", "SA_AMD_CACHE_IDLE_MS", "SA_AMD_NO_REDUCED",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
