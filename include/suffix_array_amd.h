@@ -92,6 +92,9 @@ int64_t sa_amd_workspace_bytes(int32_t n);
  * dWork: sa_amd_workspace_bytes(n) bytes of device scratch, 256-byte aligned (else SA_AMD_EINVAL); stream: a
  * hipStream_t (NULL = default stream) on the current device.  Blocks until the array is
  * complete (the refinement loop reads a 4-byte counter back per round).  stats may be NULL.
+ * dT may sit at any byte address; when it is not 4-byte aligned the kernels that read the text in words round the address
+ * down and may READ (never write) up to three bytes in front of it -- inside the same device allocation, whose start is
+ * aligned.
  */
 int32_t sa_amd_saca_device(const uint8_t *dT, uint32_t *dSA, int32_t n, void *dWork,
                            int64_t work_bytes, void *stream, sa_amd_stats *stats);

@@ -103,6 +103,23 @@ struct LaneTurn {
     LaneTurn &operator=(const LaneTurn &) = delete;
 };
 
+// a pooled stream / pinned block that goes back to the pool on every path out of a scope (also when something throws:
+// the entry points catch at the ABI boundary, sa_api.hip)
+struct PooledStream {
+    int device; hipStream_t st = nullptr;
+    explicit PooledStream(int d) : device(d) {}
+    ~PooledStream() { if (st) pool().release_stream(device, st); }
+    PooledStream(const PooledStream &) = delete;
+    PooledStream &operator=(const PooledStream &) = delete;
+};
+struct PooledPin {
+    PinBlock b;
+    ~PooledPin() { if (b.p) pool().release_pinned(b); }
+    PooledPin() = default;
+    PooledPin(const PooledPin &) = delete;
+    PooledPin &operator=(const PooledPin &) = delete;
+};
+
 static int64_t lanes_min_n() { return env_int("SA_AMD_LANES_MIN_N", (int64_t)32 << 20, 0, (int64_t)1 << 40); }
 
 // ---- early download: the front of the array travels while the last refinement rounds run (EarlyDownload, host/pipeline.hpp) ----
@@ -204,12 +221,14 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
         // block over PCIe (zero-copy; hipHostMalloc memory is mapped into the device), so there is no device block, no
         // hipMemcpy and no read-back: 0.2 ms -> tens of microseconds for the sizes of the reference's own tests (src/tests.rs:14).
         const size_t tb = align_up((size_t)n, 256), need = tb + ((size_t)n + 1) * 4;
-        PinBlock pb;
-        hipStream_t st = nullptr;
-        int rc = pool().stream(cur, &st);
+        PooledStream ps(cur);
+        PooledPin pp;
+        int rc = pool().stream(cur, &ps.st);
         if (rc != SA_AMD_OK) return rc;
-        rc = pool().pinned(need < ((size_t)64 << 10) ? ((size_t)64 << 10) : need, -1, cur, &pb);
-        if (rc != SA_AMD_OK) { pool().release_stream(cur, st); return rc; }
+        hipStream_t st = ps.st;
+        rc = pool().pinned(need < ((size_t)64 << 10) ? ((size_t)64 << 10) : need, -1, cur, &pp.b);
+        if (rc != SA_AMD_OK) return rc;
+        PinBlock &pb = pp.b;
         void *dbase = nullptr;
         rc = hip_status(hipHostGetDevicePointer(&dbase, pb.p, 0));
         if (rc == SA_AMD_OK) {
@@ -228,8 +247,6 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
                 if (with_sentinel) memcpy(SA_host, src, ((size_t)n + 1) * 4); else memcpy(SA_host, src + 1, (size_t)n * 4);
             }
         }
-        pool().release_pinned(pb);
-        pool().release_stream(cur, st);
         { sa_amd_stats z; memset(&z, 0, sizeof(z)); g_last_stats = z; }
         tm.total = tm.build = wall_ms() - t_begin;
         g_host_timing = tm;
@@ -497,9 +514,10 @@ static int build_host_small_batch(const uint8_t *const *T, uint32_t *const *SA, 
     if (guard.rc != SA_AMD_OK) { for (size_t k = 0; k < count; ++k) status[items[k]] = guard.rc; return guard.rc; }
     int cur = 0;
     int rc = hip_status(hipGetDevice(&cur));
-    hipStream_t st = nullptr;
-    if (rc == SA_AMD_OK) rc = pool().stream(cur, &st);
+    PooledStream ps(cur);
+    if (rc == SA_AMD_OK) { ps.device = cur; rc = pool().stream(cur, &ps.st); }
     if (rc != SA_AMD_OK) { for (size_t k = 0; k < count; ++k) status[items[k]] = rc; return rc; }
+    hipStream_t st = ps.st;
     int first = SA_AMD_OK;
     HelperPool &hp = helper_pool(device_numa_node(cur));
     const int copy_slices = (int)env_int("SA_AMD_COPY_THREADS", 12, 0, 32) > 1 ? (int)env_int("SA_AMD_COPY_THREADS", 12, 0, 32) : 1;
@@ -514,8 +532,9 @@ static int build_host_small_batch(const uint8_t *const *T, uint32_t *const *SA, 
             tbytes += tb; sbytes += sb; ++k1;
         }
         const size_t cnt = k1 - k0, dbytes = align_up(cnt * 16, 256), need = dbytes + align_up(tbytes, 256) + sbytes;
-        std::vector<uint32_t> slot_of(cnt);               // (before the pinned block is taken: the only thing here that can throw)
-        PinBlock pb;
+        std::vector<uint32_t> slot_of(cnt);
+        PooledPin pp;                                     // (back to the pool at the end of the chunk, also when a helper job throws)
+        PinBlock &pb = pp.b;
         int rcc = pool().pinned(need < ((size_t)64 << 10) ? ((size_t)64 << 10) : need, -1, cur, &pb);
         void *dbase = nullptr;
         if (rcc == SA_AMD_OK) rcc = hip_status(hipHostGetDevicePointer(&dbase, pb.p, 0));
@@ -561,12 +580,10 @@ static int build_host_small_batch(const uint8_t *const *T, uint32_t *const *SA, 
                     for (size_t k = b; k < e; ++k) { const uint4 d = desc[slot[k - k0]]; memcpy(SA[items[k]], spart + d.y, ((size_t)d.z + 1) * 4); }
                 });
         }
-        if (pb.p) pool().release_pinned(pb);
         for (size_t k = k0; k < k1; ++k) status[items[k]] = rcc;
         if (first == SA_AMD_OK) first = rcc;
         k0 = k1;
     }
-    pool().release_stream(cur, st);
     return first;
 }
 

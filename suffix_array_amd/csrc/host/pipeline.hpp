@@ -19,6 +19,8 @@ static_assert(32 - 16 <= BK_MAX_LBITS, "two 8-bit passes inside a bucket");
 constexpr size_t GRAM_MAX_ENTRIES = (size_t)1 << 24;   // gram keys: the rank table has sigma^g <= min(n, 2^24) entries
 static_assert(GROUP_CAP_MAX == GS_CAP, "Tuning clamps SA_AMD_GROUP_CAP to the kernel's cap");
 
+#ifdef SA_AMD_DIAG
+// (three-kernel pass of rounds 1-2: diagnostic library only, see kernels/radix_sort.hpp)
 // Tile-scatter kernel shapes (threads, items per thread, workgroups per CU).  SA_AMD_SORT_VARIANT selects one at run
 // time for A/B measurements; every entry of the PRODUCT table sorts correctly.  The diagnostic library appends the
 // first-generation scatter, its timing ablations (wrong orders, on purpose) and the phase-stamp build.
@@ -57,12 +59,19 @@ static SortGrid sort_grid(int64_t count, const SortVariant &sv)
     return g;
 }
 
+#else
+constexpr int N_SORT_VARIANTS = 1;      // (the product has one sort engine: the single-pass tile scatter)
+#endif
+
 // what a radix sort needs besides its ping-pong buffers
 struct SortScratch {
     uint32_t *spine;                // RADIX * SORT_MAX_WG words: per-chunk counts (three-kernel pass) / two zones of segment counts + tickets (single-pass)
     uint32_t *digit_tot;            // RADIX words
     unsigned long long *status;     // single-pass scatter: 256 granules per tile (nullptr: the three-kernel pass is used)
-    uint32_t *err;                  // single-pass scatter: look-back give-ups (must stay 0)
+    uint32_t *err;                  // single-pass scatter: look-back give-ups (must stay 0).  A tile whose look-back gave up (2^22 polls without
+                                    // an answer: never seen, the bound turns a hang into an error) has scattered with a partial prefix -- in bounds,
+                                    // wrong order --, so EVERY user of a SortScratch reads err[0] before it trusts a result: build_device at its end
+                                    // (SA_AMD_EINTERNAL), sa_amd_check_integrity_device behind its sorts, the diagnostic hooks behind theirs
 };
 
 // device scratch layout for a text of n bytes
@@ -165,7 +174,11 @@ static_assert(OS_NSEG <= OS_TICKETS, "one ticket word per segment");
 constexpr int OS_MAX_ZONES = 2 * 8 + 2;         // eight passes, each possibly behind a skipped one that needed a recount, + the producer's zone
 static_assert(OS_MAX_ZONES * OS_ZONE <= RADIX * SORT_MAX_WG, "the zones live in the spine slab");
 
+#ifdef SA_AMD_DIAG
 static bool onesweep_on(const SortScratch &ss, const Tuning &tn) { return ss.status != nullptr && !tn.no_onesweep; }
+#else
+static bool onesweep_on(const SortScratch &ss, const Tuning &) { return ss.status != nullptr; }      // (the product's only engine)
+#endif
 
 struct OnesweepGeom { int tiles, nseg, tiles_per_seg; int64_t seg_elems; };
 static OnesweepGeom onesweep_geom(int64_t count, int tile)
@@ -324,6 +337,7 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
         }
 #undef OS_CALL64
     }
+#ifdef SA_AMD_DIAG
     uint32_t *spine = ss.spine, *digit_tot = ss.digit_tot;
     const SortVariant &sv = sort_variants[tn.sort_variant];
     const SortGrid g = sort_grid(count, sv);
@@ -378,10 +392,14 @@ static int sort_pairs(uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_alt, 
     }
     res->keys = kin; res->vals = vin;
     return SA_AMD_OK;
+#else
+    return SA_AMD_EINTERNAL;        // (no scratch for the single-pass scatter: cannot happen, every caller carves it)
+#endif
 }
 
-// 32-bit keys (two-stage initial sort): same three-kernel pass, 12 Ki-pair tiles by default (the LDS stage holds more 4-byte elements)
 struct SortResult32 { uint32_t *keys; uint32_t *vals; int passes; };
+#ifdef SA_AMD_DIAG
+// 32-bit keys (two-stage initial sort): same three-kernel pass, 12 Ki-pair tiles by default (the LDS stage holds more 4-byte elements)
 constexpr int SORT32_THREADS = 1024;
 typedef void (*Downsweep32Fn)(const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, int64_t, int,
                               uint32_t, int64_t, int);
@@ -407,6 +425,10 @@ static SortGrid32 sort_grid32(int64_t count, const Sort32Variant &sv)
     g.G = (int)ceil_div(tiles, g.tiles_per_wg);
     return g;
 }
+
+#else
+constexpr int N_SORT32_VARIANTS = 1;
+#endif
 
 static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit,
                         int end_bit, const SortScratch &ss, uint32_t *final_vals, hipStream_t st, SortResult32 *res,
@@ -436,6 +458,7 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
         }
 #undef OS_CALL32
     }
+#ifdef SA_AMD_DIAG
     uint32_t *spine = ss.spine, *digit_tot = ss.digit_tot;
     const Sort32Variant &sv = sort32_variants[tn.sort32_variant];
     const SortGrid32 g32 = sort_grid32(count, sv);
@@ -475,6 +498,9 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
     }
     res->keys = kin; res->vals = vin;
     return SA_AMD_OK;
+#else
+    return SA_AMD_EINTERNAL;
+#endif
 }
 
 static FirstCounts sort_first_counts(const SortScratch &ss, const Tuning &tn, int64_t count, bool keys32)
@@ -488,6 +514,7 @@ static FirstCounts sort_first_counts(const SortScratch &ss, const Tuning &tn, in
         f.zero_ptr = ss.spine; f.zero_bytes = (size_t)OS_ZONE * 4;
         return f;
     }
+#ifdef SA_AMD_DIAG
     f.counts = ss.spine; f.zero_ptr = ss.spine;
     if (keys32) {
         const SortGrid32 g32 = sort_grid32(count, sort32_variants[tn.sort32_variant]);
@@ -498,6 +525,10 @@ static FirstCounts sort_first_counts(const SortScratch &ss, const Tuning &tn, in
     }
     f.zero_bytes = (size_t)RADIX * f.G * 4;
     return f;
+#else
+    f.counts = ss.spine; f.zero_ptr = ss.spine; f.chunk_elems = count; f.G = 1; f.zero_bytes = (size_t)RADIX * 4;      // (not reached)
+    return f;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -4,7 +4,8 @@
 // `cdivsufsort::sort_in_place` (reference src/saca.rs:14).
 //
 // A stable LSD sort may stop early: after the passes over the key bits 16..31 the pairs are grouped by their top 16 bits
-// (a BUCKET, contiguous, its members in text order), and what the two passes over the bits 0..15 would have done --
+// (a BUCKET, contiguous; the order of its members among themselves is UNSPECIFIED -- the text-keyed first pass hands a lane
+// consecutive positions and is not stable), and what the two passes over the bits 0..15 would have done --
 // 2 x 16 bytes per pair through a 256-way scatter -- is a sort INSIDE every bucket.  With n = 2^28 suffixes of random
 // bytes a bucket holds 4096 +- 64 pairs: it fits in LDS, so one workgroup per bucket reads its pairs once (coalesced),
 // orders them by two counting passes in LDS and writes them back in order (coalesced, sequential): 16 bytes per pair at
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_bucket_sort(const uint32_t *_
                     ii = (uint32_t)idx;
                     se = (uint32_t)sb | ((uint32_t)eb << 16);
                     vv = lds_v[idx];
-                } else ++n_unowned;                // too large for this round: reported, left in text order
+                } else ++n_unowned;                // too large for this round: reported, left as it is (order among equal keys: unspecified)
             }
             fi[r] = ii; fse[r] = se; fv[r] = vv;
             own_mask |= own << r;

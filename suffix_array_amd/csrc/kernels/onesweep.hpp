@@ -34,6 +34,11 @@ namespace sa {
 constexpr int OS_NSEG = 8;           // segments per pass (one per XCD; fewer when there are fewer tiles)
 constexpr int OS_LB = 3;             // predecessors read speculatively per look-back round (measured: 1 slower, 2 and 3 equal, 4 and 8
                                      // slower on 32-bit keys -- rows of granules nobody needs are L2 traffic too; profiles/r03_onesweep_experiments.txt)
+// four words from a 4-byte aligned address in one load (global_load_dwordx4 needs dword alignment only; a plain uint4 dereference
+// would promise the compiler 16): the text-key readers below round a byte address down to a word and cut their keys out of the
+// words with v_alignbyte.  Up to three bytes in front of an unaligned text pointer are read that way (same allocation: a
+// caller's dT that is not 4-byte aligned sits inside a block whose start is) -- stated in include/suffix_array_amd.h.
+struct __attribute__((packed, aligned(4))) Words4 { uint32_t x, y, z, w; };
 constexpr int OS_MIN_TILE = 4096;    // smallest tile of any shape in use (the granule slab is sized by it)
 
 __device__ __forceinline__ unsigned os_xcc_id()
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_text_upsweep32(const uint8_t *
         const uintptr_t a = (uintptr_t)(T + i);
         const uint32_t *W = (const uint32_t *)(a & ~(uintptr_t)3);
         const uint32_t sh = (uint32_t)(a & 3u);
-        const uint4 q = *(const uint4 *)W;
+        const Words4 q = *(const Words4 *)W;
         const uint32_t w4 = W[4], w5 = W[5];
         const uint32_t v[6] = { __builtin_amdgcn_alignbyte(q.y, q.x, sh), __builtin_amdgcn_alignbyte(q.z, q.y, sh), __builtin_amdgcn_alignbyte(q.w, q.z, sh),
                                 __builtin_amdgcn_alignbyte(w4, q.w, sh), __builtin_amdgcn_alignbyte(w5, w4, sh), 0u };
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
             const uintptr_t a = (uintptr_t)(P.text + base + ebv);
             const uint32_t *W = (const uint32_t *)(a & ~(uintptr_t)3);
             const uint32_t sh = (uint32_t)(a & 3u);                // (the same for every lane: tile, wave block and lane stride are multiples of 4)
-            const uint4 q = *(const uint4 *)W;                     // (global_load_dwordx4 needs dword alignment only)
+            const Words4 q = *(const Words4 *)W;                   // (one 16-byte load from a dword-aligned address)
             const uint32_t w4 = W[4];
             const uint32_t v0 = __builtin_amdgcn_alignbyte(q.y, q.x, sh), v1 = __builtin_amdgcn_alignbyte(q.z, q.y, sh),
                            v2 = __builtin_amdgcn_alignbyte(q.w, q.z, sh), v3 = __builtin_amdgcn_alignbyte(w4, q.w, sh);

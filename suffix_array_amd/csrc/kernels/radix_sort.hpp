@@ -1,4 +1,5 @@
-// kernels/radix_sort.hpp -- stable LSD radix sort of (key, suffix) pairs: upsweep / spine / carry-completed-line downsweep.
+// kernels/radix_sort.hpp -- digit extraction and the counting kernels of the LSD radix sort (product); the three-kernel pass
+// upsweep / spine / carry-completed-line downsweep of rounds 1-2 (diagnostic library only: -DSA_AMD_DIAG).
 // Part of the MI355X-native suffix-array engine (gfx950 / CDNA4, wave64); see DESIGN.md section 3.
 #pragma once
 #include "common.hpp"
@@ -131,6 +132,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_upsweep32(const uint32_t
     else if (s) atomicAdd(&counts[(int64_t)threadIdx.x * G + g], s);
 }
 
+#ifdef SA_AMD_DIAG
+// ---- the three-kernel pass of rounds 1-2 (upsweep / spine / carry-completed-line downsweep): DIAGNOSTIC LIBRARY ONLY since round 4.
+// The product sorts with the single-pass tile scatter (kernels/onesweep.hpp) and keeps only the counting kernels above (first pass
+// of a sort whose producer did not count).  SA_AMD_NO_ONESWEEP=1 / SA_AMD_SORT_VARIANT select this engine in
+// libsuffix_array_amd_diag.so for A/B measurements and for the primitive tests that compare the two engines. ----
 // Spine of one radix pass: block d turns counts[d][0..G) into exclusive prefixes (in place) and
 // writes the digit total; the downsweep prologue scans the 256 totals itself.  G <= 1024.
 __global__ __launch_bounds__(SPINE_THREADS) void k_spine_rows(uint32_t *__restrict__ counts,
@@ -400,5 +406,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_radix_downsweep_wcl(
         if (i < (uint32_t)(RADIX * GR) && k < apnd[d]) { keys_out[aold[d] + k] = carry_k[i]; vals_out[aold[d] + k] = carry_v[i]; }
     }
 }
+
+#endif  // SA_AMD_DIAG
 
 }  // namespace sa

@@ -20,6 +20,15 @@ def build(text):
     return sa.SuffixArray(text).into_parts()[1]
 
 
+def build_diag(text):
+    """the same build through libsuffix_array_amd_diag.so: the engines that exist only there (the three-kernel radix pass of
+    rounds 1-2 behind SA_AMD_NO_ONESWEEP / SA_AMD_SORT_VARIANT, the sample sort) are reached through its copy of the entry point"""
+    t = np.ascontiguousarray(np.frombuffer(bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else text)
+    out = np.zeros(t.size + 1, dtype=np.uint32)
+    assert sa.diag_lib().sa_amd_saca_u8(t.ctypes.data if t.size else None, out.ctypes.data, t.size) == 0
+    return out
+
+
 def test_device_visible():
     assert sa.lib().sa_amd_device_count() >= 1
 
@@ -826,8 +835,9 @@ def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n,
     assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_TEXT_KEYS", "1")        # (all 256 byte values: the first global pass would read its keys from the text)
     assert np.array_equal(build(text), exp)
-    monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")         # the global passes by the three-kernel engine
-    assert np.array_equal(build(text), exp)
+    monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")         # the global passes by the three-kernel engine (diagnostic library)
+    assert np.array_equal(build_diag(text), exp)
+    monkeypatch.delenv("SA_AMD_NO_ONESWEEP")
     monkeypatch.setenv("SA_AMD_NO_FUSED_FINISH", "1")     # ties on the top 32 bits through the general path
     assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_BUCKET_SORT", "1")
@@ -935,8 +945,8 @@ def test_first_round_from_sorted_keys(oracle, monkeypatch, gen, n, seed, cap):
 
 @pytest.mark.parametrize("v64,v32", [("1", "1"), ("2", "2"), ("3", "3"), ("3", "4"), ("99", "-7")])
 def test_sort_kernel_variants(oracle, monkeypatch, v64, v32):
-    """the non-default tile-scatter kernel shapes of the product library (no prefetch, 512 x 16, granule 8; out-of-range
-    values fall back to the default) give the same arrays"""
+    """the tile-scatter kernel shapes of the three-kernel pass (diagnostic library since round 4: no prefetch, 512 x 16, granule 8;
+    out-of-range values fall back to the default) give the same arrays"""
     monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")            # (the shapes belong to the three-kernel pass)
     monkeypatch.setenv("SA_AMD_SORT_VARIANT", v64)
     monkeypatch.setenv("SA_AMD_SORT32_VARIANT", v32)
@@ -947,7 +957,7 @@ def test_sort_kernel_variants(oracle, monkeypatch, v64, v32):
             monkeypatch.delenv("SA_AMD_FORCE_TOP32", raising=False)
             monkeypatch.delenv("SA_AMD_NO_TOP32", raising=False)
             monkeypatch.setenv(top32, "1")
-            assert np.array_equal(build(text), exp)
+            assert np.array_equal(build_diag(text), exp)
 
 
 @pytest.mark.parametrize("engine", ["single-pass", "shapes-1-1", "shapes-2-2", "shapes-0-3", "early-look", "three-kernel"])
@@ -968,7 +978,7 @@ def test_sort_engines_full_path(oracle, monkeypatch, engine):
         for switch in (None, "SA_AMD_FORCE_TOP32", "SA_AMD_NO_TOP32", "SA_AMD_FORCE_DENSE", "SA_AMD_BINNED_ISA_ALWAYS"):
             if switch:
                 monkeypatch.setenv(switch, "1")
-            got = build(text)
+            got = build_diag(text) if engine == "three-kernel" else build(text)      # (the three-kernel pass lives in the diagnostic library)
             if switch:
                 monkeypatch.delenv(switch)
             assert np.array_equal(got, exp), (engine, gen, switch)
