@@ -62,7 +62,7 @@ echo "adversarial done"
 ( if [ -x tools/bin/pcie_probe ]; then timeout -k 10 300 tools/bin/pcie_probe 1024; fi; timeout -k 10 300 python tools/host_api_timing.py ) > $O/host_path.txt 2>&1
 timeout -k 10 300 python tools/small_latency.py > $O/small_latency.txt 2>&1
 timeout -k 10 300 python tools/midsize_timing.py > $O/midsize_timing.txt 2>&1
-( for sz in 131072 1048576 4194304; do SA_AMD_VERBOSE=3 timeout -k 10 60 python tools/mid_build.py english_corpus $sz 8 2>&1 | grep -E "best|read-backs" | cut -c1-120; done ) >> $O/midsize_timing.txt 2>&1
+( for sz in 131072 1048576 4194304; do SA_AMD_VERBOSE=3 timeout -k 10 60 python tools/mid_build.py english_corpus $sz 8 2>&1 | grep -E "best|read-backs" | cut -c1-120 | uniq; done ) >> $O/midsize_timing.txt 2>&1
 timeout -k 10 300 python tools/extras_bench.py > $O/extras.txt 2>&1
 timeout -k 10 300 python tools/search_bench.py > $O/search_throughput.txt 2>&1
 timeout -k 10 300 python tools/ab_env.py c3_english_256m - SA_AMD_NO_DEFER=1 SA_AMD_ONESWEEP_FLAGS=1 SA_AMD_NO_REPEAT_PROBE=1 SA_AMD_FORCE_DENSE=1 SA_AMD_CHASE=1 SA_AMD_CHASE=3 SA_AMD_CHASE=15 SA_AMD_SCATTER_LEVELS=1 SA_AMD_BINNED_MIN=4194304 SA_AMD_GROUP_CAP=512 SA_AMD_NO_GRAM_KEYS=1 > $O/ab_knobs_c3.txt 2>&1
