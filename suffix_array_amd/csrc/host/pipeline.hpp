@@ -658,8 +658,12 @@ static int sample_sort64(uint64_t *keys_a, uint64_t *keys_b, uint64_t *keys_c, u
                                                   (const uint32_t *)counts, (const uint32_t *)bstart, (int64_t)1, keys_a, vals_b));
     // ---- level 3: every bucket in LDS (keys_a -> keys_b, values -> final_vals) ----
     HIP_TRY(hipMemsetAsync(words, 0, 16, st));
+    if (!tn.sample_merge)
     PROF(KC_SS_BUCKET, n, st, hipLaunchKernelGGL((k_ss_bucket_sort<SB_SMALL_THREADS, SB_SMALL_ITEMS, 9, 0, false>), dim3((unsigned)SS_BUCKETS), dim3(SB_SMALL_THREADS), 0, st,
                                                  (const uint64_t *)keys_a, (const uint32_t *)vals_b, (const uint32_t *)bstart, keys_b, final_vals, words, words + 4));
+    else
+    PROF(KC_SS_BUCKET, n, st, hipLaunchKernelGGL((k_ss_bucket_merge<SB_SMALL_THREADS, SB_SMALL_ITEMS>), dim3((unsigned)SS_BUCKETS), dim3(SB_SMALL_THREADS), 0, st,
+                                                 (const uint64_t *)keys_a, (const uint32_t *)vals_b, (const uint32_t *)bstart, keys_b, final_vals, words));
     PROF(KC_SS_BUCKET, 0, st, hipLaunchKernelGGL((k_ss_bucket_sort<SB_THREADS, SB_ITEMS, 10, SB_SMALL_CAP, true>), dim3((unsigned)SS_BUCKETS), dim3(SB_THREADS), 0, st,
                                                  (const uint64_t *)keys_a, (const uint32_t *)vals_b, (const uint32_t *)bstart, keys_b, final_vals, words, words + 4));
     uint32_t res[2] = { 0, 0 };

@@ -89,6 +89,7 @@ struct Tuning {
     // kept in the diagnostic library with its tests -- correct, not faster than the eight LSD passes
     bool sample_sort = false;        // SA_AMD_SAMPLE_SORT=1: the 64-bit stage's initial sort is the sample sort for texts of at least ...
     int64_t sample_sort_min_n = (int64_t)1 << 26;   // ... SA_AMD_SAMPLE_SORT_MIN_N bytes
+    bool sample_merge = false;       // SA_AMD_SAMPLE_MERGE=1: the ordinary bucket by a merge sort in LDS (variant 3, slower) instead of LSD passes
     int sample_log = 0;              // SA_AMD_SAMPLE_LOG: log2 of the number of sampled keys (16..24; 0 = by the size of the text)
     bool timing_only_initial_sort = false;     // SA_AMD_TIMING_ONLY_INITIAL_SORT (diag library only: the array is NOT finished)
 #endif
@@ -155,6 +156,7 @@ struct Tuning {
         t.bucket_shape = (int)env_int("SA_AMD_BUCKET_SHAPE", -1, -1, 64);
 #ifdef SA_AMD_DIAG
         t.sample_sort = env_flag("SA_AMD_SAMPLE_SORT");
+        t.sample_merge = env_flag("SA_AMD_SAMPLE_MERGE");
         t.sample_sort_min_n = env_int("SA_AMD_SAMPLE_SORT_MIN_N", (int64_t)1 << 26, (int64_t)1 << 17, (int64_t)1 << 40);
         t.sample_log = (int)env_int("SA_AMD_SAMPLE_LOG", 0, 0, 24);
         if (t.sample_log != 0 && t.sample_log < 16) t.sample_log = 16;

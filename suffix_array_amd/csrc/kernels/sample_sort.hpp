@@ -30,7 +30,7 @@
 
 namespace sa {
 
-constexpr int SS_THREADS = 1024;
+constexpr int SS_THREADS = 1024;                       // (512 -- 4 096-pair tiles, two workgroups per CU -- measured slower: runs of 16 pairs, 5.4 against 4.7 ms for both levels)
 constexpr int SS_ITEMS = 8;
 constexpr int SS_TILE = SS_THREADS * SS_ITEMS;        // pairs per distribution tile
 constexpr int SS_WAYS = 256;                           // buckets per level
@@ -38,26 +38,36 @@ constexpr int SS_IDS2 = 2 * SS_WAYS;                   // level 2: bucket ids pe
 constexpr int SS_BUCKETS = SS_WAYS * SS_IDS2;          // bucket ids in all (131 072)
 constexpr int SS_CHUNKS = 256;                         // level 1: groups of tiles whose counts are scanned by one workgroup
 
-// t[1 .. 255]: ascending splitters (t[0] is not looked at).  Returns how many of them are <= key.
-__device__ __forceinline__ uint32_t ss_upper(const uint64_t *t, uint64_t key)
+// The 255 splitters of a table live in LDS in BREADTH-FIRST order (node k's children are 2 k and 2 k + 1; t[1] = the median): the
+// nodes of one level are neighbours, so the lanes of a wave -- which all look at the same level in the same step -- hit different
+// banks.  (In sorted order the first four steps of a binary search look at indices that are multiples of 16: one bank, up to 16
+// different addresses; 70 % of the LDS cycles of variant 2's distribution kernels were such conflicts.)  t[0] = the coarse
+// splitter the segment starts at (level 2; every key of the segment is >= it), 0 for level 1 and the first segment.
+// Returns u = how many of the 255 splitters are <= key and *last = the largest of them (t[0] when u = 0).
+__device__ __forceinline__ uint32_t ss_upper(const uint64_t *t, uint64_t key, uint64_t *last)
 {
-    uint32_t lo = 0;
+    uint32_t k = 1;
+    uint64_t best = t[0];
 #pragma unroll
-    for (int step = SS_WAYS / 2; step >= 1; step >>= 1) {
-        const uint32_t mid = lo + (uint32_t)step;
-        if (t[mid] <= key) lo = mid;
+    for (int level = 0; level < 8; ++level) {
+        const uint64_t v = t[k];
+        const bool right = v <= key;
+        if (right) best = v;
+        k = 2u * k + (right ? 1u : 0u);
     }
-    return lo;
+    *last = best;
+    return k - (uint32_t)SS_WAYS;
 }
 
-// level-2 id of a key inside its segment, t[0] = the coarse splitter the segment starts at (every key of the segment is >= it):
-// u = fine splitters <= key; id = 2 u when the key EQUALS t[u] (the equality bucket of that splitter), 2 u + 1 when it lies above
-// it and below t[u + 1].  Monotone in the key.  (A heavy key that is the segment's coarse splitter itself must not fall into the
-// regular bucket behind it: all of its copies are in this segment.)
+// level-2 id of a key inside its segment: u = fine splitters <= key; id = 2 u when the key EQUALS the last of them (the equality
+// bucket of that splitter; u = 0: of the segment's own coarse splitter), 2 u + 1 when it lies above it and below the next one.
+// Monotone in the key.  (A heavy key that is the segment's coarse splitter itself must not fall into the regular bucket behind
+// it: all of its copies are in this segment.)
 __device__ __forceinline__ uint32_t ss_id2(const uint64_t *t, uint64_t key)
 {
-    const uint32_t u = ss_upper(t, key);
-    return 2u * u + (t[u] == key ? 0u : 1u);
+    uint64_t last;
+    const uint32_t u = ss_upper(t, key, &last);
+    return 2u * u + (last == key ? 0u : 1u);
 }
 
 // S samples, one from every stratum of n / S consecutive suffixes, at a hashed offset inside it
@@ -98,19 +108,30 @@ __device__ __forceinline__ SsTile ss_tile(int64_t n, const uint32_t *__restrict_
     return T;
 }
 
-// the splitter table of a tile into LDS: level 1 every (S / 256)-th sample, level 2 every (S / 65 536)-th one of the segment's part
+// the splitter table of a tile into LDS, breadth-first: node k of level L (k = 2^L + p) holds the sorted splitter number
+// (2 p + 1) << (7 - L); level 1 takes every (S / 256)-th sample, level 2 every (S / 65 536)-th one of the segment's part
 template <int LEVEL>
 __device__ __forceinline__ void ss_load_table(uint64_t *t, const uint64_t *__restrict__ sample, int64_t S, uint32_t seg)
 {
     if (threadIdx.x < SS_WAYS) {
         const int64_t coarse = S / SS_WAYS, fine = coarse / SS_WAYS;
-        const int64_t at = LEVEL == 1 ? (int64_t)threadIdx.x * coarse : (int64_t)seg * coarse + (int64_t)threadIdx.x * fine;
-        t[threadIdx.x] = (threadIdx.x || (LEVEL == 2 && seg)) ? sample[at] : 0ull;
+        const uint32_t k = threadIdx.x;
+        uint32_t i = 0;                                                    // (k = 0: the segment's own coarse splitter)
+        if (k) {
+            const int L = 31 - __builtin_clz(k);
+            i = (2u * (k - (1u << L)) + 1u) << (7 - L);
+        }
+        const int64_t at = LEVEL == 1 ? (int64_t)i * coarse : (int64_t)seg * coarse + (int64_t)i * fine;
+        t[k] = (k || (LEVEL == 2 && seg)) ? sample[at] : 0ull;
     }
 }
 
 template <int LEVEL>
-__device__ __forceinline__ uint32_t ss_digit(const uint64_t *t, uint64_t key) { return LEVEL == 1 ? ss_upper(t, key) : ss_id2(t, key); }
+__device__ __forceinline__ uint32_t ss_digit(const uint64_t *t, uint64_t key)
+{
+    if (LEVEL == 1) { uint64_t last; return ss_upper(t, key, &last); }
+    return ss_id2(t, key);
+}
 
 // one LDS atomic per pair, or one per wave when the whole wave carries the same digit (an equality bucket's tile: 8192 adds on one
 // address otherwise); returns the pair's rank among the tile's pairs of its digit (in arrival order: not stable, need not be)
@@ -314,6 +335,78 @@ constexpr int SB_SMALL_ITEMS = 12;
 constexpr int SB_SMALL_CAP = SB_SMALL_THREADS * SB_SMALL_ITEMS;      // 6 144: the shape of the ordinary bucket, two workgroups per CU
 constexpr int SB_BBITS = 8;                           // stable passes: ballot ranking, thread d owns digit d
 constexpr int SB_OVER_MAX = 1024;                     // reported oversize buckets at most (more: the caller falls back)
+
+// ---- variant 3 of level 3 (SA_AMD_SAMPLE_MERGE=1; measured SLOWER than the LSD passes: 12.9 against 8.0 ms on C3 -- every merge
+// step is a dependent LDS read, and four waves per SIMD do not hide the chain): merge sort instead of LSD passes.  A thread orders ITEMS consecutive pairs in registers (odd-even
+// transposition), then log2(THREADS) rounds merge neighbouring runs: every thread finds where its ITEMS outputs start in the two
+// runs (merge path: a binary search along its diagonal) and merges them sequentially.  ~4x fewer instructions than six ballot-ranked
+// passes, two barriers per round, and the pairs travel as (key, 16-bit place): 10 bytes of LDS per pair, two workgroups per CU.
+// Ties are broken by the place, so the padding behind a partial bucket (key ~0, places >= size) stays behind every real pair.
+__device__ __forceinline__ bool ss_before(uint64_t ka, uint32_t xa, uint64_t kb, uint32_t xb) { return ka < kb || (ka == kb && xa <= xb); }
+
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS, 4) void k_ss_bucket_merge(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                               const uint32_t *__restrict__ bstart, uint64_t *__restrict__ keys_out,
+                                                               uint32_t *__restrict__ vals_out, uint32_t *__restrict__ words)
+{
+    constexpr int CAP = THREADS * ITEMS;
+    static_assert(CAP < 65536 && (THREADS & (THREADS - 1)) == 0, "16-bit places; the runs pair up");
+    __shared__ __attribute__((aligned(16))) uint64_t lk[CAP];
+    __shared__ uint16_t lx[CAP];
+    const int tid = threadIdx.x;
+    const uint32_t lo = bstart[blockIdx.x];
+    const int64_t size64 = (int64_t)bstart[blockIdx.x + 1] - (int64_t)lo;
+    if (size64 <= 0 || size64 > CAP || (blockIdx.x & 1u) == 0) return;       // empty, the large shape's, or an equality bucket (ditto)
+    const int size = (int)size64;
+    if (tid == 0) atomicMax(&words[1], (uint32_t)size);
+    for (int i = tid; i < CAP; i += THREADS) { lk[i] = i < size ? keys_in[lo + i] : ~0ull; lx[i] = (uint16_t)i; }
+    __syncthreads();
+    uint64_t k[ITEMS];
+    uint32_t x[ITEMS];
+    const int mine = tid * ITEMS;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { k[j] = lk[mine + j]; x[j] = lx[mine + j]; }
+#pragma unroll
+    for (int pass = 0; pass < ITEMS; ++pass) {
+#pragma unroll
+        for (int j = pass & 1; j + 1 < ITEMS; j += 2) {
+            const bool sw = !ss_before(k[j], x[j], k[j + 1], x[j + 1]);
+            const uint64_t ka = sw ? k[j + 1] : k[j], kb = sw ? k[j] : k[j + 1];
+            const uint32_t xa = sw ? x[j + 1] : x[j], xb = sw ? x[j] : x[j + 1];
+            k[j] = ka; k[j + 1] = kb; x[j] = xa; x[j + 1] = xb;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { lk[mine + j] = k[j]; lx[mine + j] = (uint16_t)x[j]; }
+    for (int run = ITEMS; run < CAP; run <<= 1) {
+        __syncthreads();
+        const int base = mine / (2 * run) * (2 * run);
+        const int diag = mine - base;
+        const uint64_t *A = lk + base, *B = lk + base + run;
+        const uint16_t *XA = lx + base, *XB = lx + base + run;
+        int plo = diag > run ? diag - run : 0, phi = diag < run ? diag : run;
+        while (plo < phi) {
+            const int mid = (plo + phi) >> 1;
+            if (ss_before(A[mid], XA[mid], B[diag - 1 - mid], XB[diag - 1 - mid])) plo = mid + 1; else phi = mid;
+        }
+        int ai = plo, bi = diag - plo;
+        uint64_t ka = ai < run ? A[ai] : 0ull, kb = bi < run ? B[bi] : 0ull;
+        uint32_t xa = ai < run ? XA[ai] : 0u, xb = bi < run ? XB[bi] : 0u;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool ta = bi >= run || (ai < run && ss_before(ka, xa, kb, xb));
+            k[j] = ta ? ka : kb; x[j] = ta ? xa : xb;
+            if (ta) { ++ai; if (ai < run) { ka = A[ai]; xa = XA[ai]; } }
+            else { ++bi; if (bi < run) { kb = B[bi]; xb = XB[bi]; } }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { lk[mine + j] = k[j]; lx[mine + j] = (uint16_t)x[j]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < size; i += THREADS) { keys_out[lo + i] = lk[i]; vals_out[lo + i] = vals_in[lo + lx[i]]; }
+}
 
 // words: [0] oversize buckets that are no equality buckets (their ids follow in over_list), [1] the largest bucket.
 // Two launches over all buckets: the shape <THREADS, ITEMS> takes the buckets of MIN_SIZE < size <= THREADS * ITEMS pairs; the large shape
