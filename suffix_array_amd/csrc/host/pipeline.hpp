@@ -1182,6 +1182,7 @@ struct DeviceBuild {
     bool lists_ready = false, finished32 = false, fused64 = false, sparse = false;
     bool isa_tail_ranks = false;        // the rank set-up of the dense route wrote tail ranks (k_rr_apply FTAIL)
     int s_sym = 0, tkb = 0, key2_bits = 0;
+    bool unary_done = false;            // a text of one byte value: the array was written directly (geometry_and_probes), nothing else runs
     bool prev_clean = true;             // the last refinement round's local pass ordered every member (optimistic for the first one: a miss costs three empty launches)
     int deferred_misses = 0;            // rounds that deferred their mid-round read-back and did have members for the global sort (RoundCtl)
 
@@ -1262,6 +1263,15 @@ struct DeviceBuild {
         { const int rcw = read_words(hist, w.hist, sizeof(hist), st); if (rcw) return rcw; }
         key_bits = make_key_params(hist, &P, &sigma, tn.key_bits_max);      // (gram keys, step 2c, may shorten it)
         local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
+        if (sigma == 1 && !tn.no_unary_shortcut) {
+            // one byte value repeated: every suffix is a proper prefix of every longer one, the order is by length.  (The general
+            // path gets there too -- 23 doubling rounds over one group of n members, 214 ms at 256 MiB -- and stays tested.)
+            int64_t blocks = ceil_div(n, 256 * 16);
+            if (blocks > 16384) blocks = 16384;
+            PROF(KC_MISC, n, st, hipLaunchKernelGGL((k_fill_descending), dim3((unsigned)blocks), dim3(256), 0, st, SA, n));
+            unary_done = true;
+            return SA_AMD_OK;
+        }
 
         g_bits = bit_length((uint64_t)(n - 1 > 0 ? n - 1 : 1));
         bucket_top_bits = choose_bucket_bits();
@@ -2059,12 +2069,14 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     HIP_TRY(hipMemsetAsync(w.os_err, 0, 16, st));          // look-back give-ups of the single-pass scatter: checked at the end
     int rc;
     if ((rc = B.geometry_and_probes())) return rc;
+    if (!B.unary_done) {
     if ((rc = B.initial_sort())) return rc;
     if ((rc = B.first_round_from_sorted_keys())) return rc;
     if ((rc = B.group_heads())) return rc;
     if ((rc = B.finish_top32_ties())) return rc;
     if ((rc = B.rank_setup_and_text_rounds())) return rc;
     if ((rc = B.doubling_rounds())) return rc;
+    }
     if ((rc = B.early_finish())) return rc;
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, dSA, (uint32_t)n);   // reference src/saca.rs:13
     LAUNCH_CHECK(st);

@@ -75,6 +75,7 @@ struct Tuning {
     int onesweep_flags = 0;          // SA_AMD_ONESWEEP_FLAGS: scheduling switches of the single-pass scatter (kernels/onesweep.hpp, OnesweepPass::flags), same result
     int onesweep64_shape = 0;        // SA_AMD_ONESWEEP64_SHAPE / SA_AMD_ONESWEEP32_SHAPE: tile shape of the single-pass scatter (host/pipeline.hpp,
     int onesweep32_shape = 0;        //   os_shapes64 / os_shapes32; out of range = default)
+    bool no_unary_shortcut = false;  // SA_AMD_NO_UNARY_SHORTCUT: a text of one byte value goes through the sort and the rounds like any other (214 ms at 256 MiB instead of 0.3)
     bool no_defer = false;           // SA_AMD_NO_DEFER: every refinement round reads the local pass's counts back in its middle (two blocking read-backs per round instead of one)
     bool no_big_group_sort = false;  // SA_AMD_NO_BIG_GROUP_SORT: groups of 1025..16384 members go through the global radix sort, not k_group_sort_big
     bool no_text_keys = false;       // SA_AMD_NO_TEXT_KEYS: the first global pass of the bucket route always reads a key array (never the text itself)
@@ -145,6 +146,7 @@ struct Tuning {
         if (t.onesweep32_shape >= n_os32) t.onesweep32_shape = 0;
         t.no_big_group_sort = env_flag("SA_AMD_NO_BIG_GROUP_SORT");
         t.no_defer = env_flag("SA_AMD_NO_DEFER");
+        t.no_unary_shortcut = env_flag("SA_AMD_NO_UNARY_SHORTCUT");
 
         t.no_text_keys = env_flag("SA_AMD_NO_TEXT_KEYS");
         t.no_bucket_sort = env_flag("SA_AMD_NO_BUCKET_SORT");

@@ -157,6 +157,14 @@ __global__ __launch_bounds__(EARLY_THREADS) void k_early_gather(const uint32_t *
     }
 }
 
+// the suffix array of a text that is ONE byte value repeated (a zero-filled file): the shorter suffix is a proper prefix of the
+// longer one, so the order is by length -- SA[i] = n - 1 - i, no sorting at all
+__global__ __launch_bounds__(256) void k_fill_descending(uint32_t *__restrict__ SA, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) SA[i] = (uint32_t)(n - 1 - i);
+}
+
 __global__ __launch_bounds__(256) void k_copy_u32(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int64_t n)
 {
     const int64_t stride = (int64_t)gridDim.x * 256;

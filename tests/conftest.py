@@ -16,6 +16,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _one_byte_texts_take_the_general_path(monkeypatch):
+    """a text of ONE byte value has a closed form that the pipeline takes (k_fill_descending); the suite's many one-byte texts are
+    there to exercise giant groups in the sort and the rounds, so every test runs with the shortcut off -- the closed form has a
+    test of its own (test_text_of_one_byte_value_takes_the_closed_form), which switches it back on"""
+    monkeypatch.setenv("SA_AMD_NO_UNARY_SHORTCUT", "1")
+
+
 class Oracle:
     """ctypes view of oracle/liboracle.so -- the CPU checker (never the thing under test)."""
 
