@@ -118,9 +118,20 @@ public:
             snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
             if (read_small_file(path, buf, sizeof(buf)) && parse_cpulist(buf, &cpus_)) { have_cpus_ = true; cpus = CPU_COUNT(&cpus_); }
         }
-        // enough for one download of twelve slices (callers of one device download one at a time) plus a page-touching job; never more than the node has CPUs
+        // enough for one download of twelve slices (callers of one device download one at a time) plus a page-touching job -- PER DEVICE
+        // of the node: the devices that hang off one socket (four of eight on the evidence hosts) share this pool, and one
+        // sa_amd_saca_batch call drives them all at once; never more than the node has CPUs (two left to the callers)
         want_ = (int)env_int("SA_AMD_HELPER_THREADS", 16, 0, 256);
-        if (cpus > 0 && want_ > cpus) want_ = cpus;
+        if (want_ > 0 && node >= 0) {
+            int ndev = 0, here = 0;
+            if (hipGetDeviceCount(&ndev) == hipSuccess) {
+                for (int d = 0; d < ndev; ++d) here += device_numa_node(d) == node ? 1 : 0;
+            } else (void)hipGetLastError();
+            if (here > 1) want_ *= here;
+            if (want_ > 128) want_ = 128;
+        }
+        if (cpus > 2 && want_ > cpus - 2) want_ = cpus - 2;
+        else if (cpus > 0 && want_ > cpus) want_ = cpus;
     }
     int node() const { return node_; }
     int helpers() const { return want_; }      // threads the pool has or will start (0: every job runs on its caller)
