@@ -77,6 +77,9 @@ def parse(argv=None):
     ap.add_argument("--small-batch-texts", type=int, default=4096, help="texts of 4 KiB in the small-text part of the sa_amd_saca_batch leg (0: skip)")
     ap.add_argument("--cpu-sample", type=int, default=256 << 20,
                     help="bytes of the workload timed on the CPU (default: the whole 256 MiB headline text, ~30 s of the stand-in)")
+    ap.add_argument("--batch-api-only", action="store_true", help="(internal) run only the sa_amd_saca_batch leg and print its JSON object")
+    ap.add_argument("--batch-api-inline", action="store_true", help="run the sa_amd_saca_batch leg in this process even when several GPUs are visible")
+    ap.add_argument("--batch-api-timeout", type=int, default=300)
     ap.add_argument("--configs", default="c2_uniform_64m,c2_uniform_256m,c4_dna_1g,c5_uniform_512m",
                     help="N = 1: the other BASELINE configs measured behind the headline workload (comma list; '' or --no-configs: none)")
     ap.add_argument("--no-configs", action="store_true")
@@ -550,6 +553,27 @@ def config_leg(backend, args, workload, barrier, names):
     return res
 
 
+def batch_api_subprocess(args):
+    """batch_api_leg in a child process (`bench.py --batch-api-only`, its own GPU context) with a time limit"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--batch-api-only", "--batch-texts", str(args.batch_texts),
+           "--small-batch-texts", str(args.small_batch_texts)]
+    if args.n is not None:
+        cmd += ["--text-bytes", str(args.n)]
+    try:
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.batch_api_timeout)
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        if proc.returncode == 0 and lines:
+            out = json.loads(lines[-1])
+            out["ran_in"] = "child process (more than one GPU visible)"
+            return out
+        return {"entry_point": "sa_amd_saca_batch", "verified": False, "ran_in": "child process",
+                "error": f"exit code {proc.returncode}: {proc.stderr.strip()[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"entry_point": "sa_amd_saca_batch", "verified": False, "ran_in": "child process", "error": f"no answer within {args.batch_api_timeout} s"}
+    except Exception as ex:
+        return {"entry_point": "sa_amd_saca_batch", "verified": False, "ran_in": "child process", "error": f"{type(ex).__name__}: {ex}"[:300]}
+
+
 def run(args, backend, rank, world, dist=None, share=False):
     """one rank of the benchmark; returns the result dict on rank 0 (None elsewhere).  `backend` is the HipBackend; the
     world-size-2 CPU test of tests/test_dist.py injects its own object with the same methods."""
@@ -610,8 +634,16 @@ def run(args, backend, rank, world, dist=None, share=False):
         raise SystemExit(f"bench.py: {world} ranks but their GPUs are not distinct ({bus_ids}); SA_BENCH_SHARE_GPU=1 allows a rehearsal")
 
     e2e = None
-    if not args.no_end_to_end:
+    if not args.no_end_to_end and world == 1:
+        try:                                                  # (N = 1: a failure here is recorded; at N > 1 the ranks must stay in step, so it is not caught)
+            e = end_to_end(backend, text_h, args.e2e_calls, barrier)
+        except Exception as ex:
+            e, e2e = None, {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    elif not args.no_end_to_end:
         e = end_to_end(backend, text_h, args.e2e_calls, barrier)
+    else:
+        e = None
+    if e is not None:
         # whole job: all ranks run their calls concurrently (shared PCIe switches / host DRAM are part of the figure)
         e2e = {}
         for mode in ("reused_buffer", "fresh_buffer"):
@@ -644,13 +676,36 @@ def run(args, backend, rank, world, dist=None, share=False):
     if world == 1 and not args.no_configs and cfg_names:
         backend.unload()
         t_cfg = time.perf_counter()
-        configs = {c: config_leg(backend, args, c, barrier, names) for c in cfg_names}
+        configs = {}
+        for c in cfg_names:
+            # (a leg behind the headline must not take the line down with it: a failure is recorded, the headline stands)
+            try:
+                configs[c] = config_leg(backend, args, c, barrier, names)
+            except Exception as ex:
+                configs[c] = {"workload": c, "verified": False, "error": f"{type(ex).__name__}: {ex}"[:300]}
+                try:
+                    backend.unload()
+                except Exception:
+                    pass
         configs["_seconds"] = round(time.perf_counter() - t_cfg, 1)
 
     batch_api = None
     if world == 1 and not args.no_batch_api and not args.no_end_to_end:
         backend.unload()
-        batch_api = batch_api_leg(backend, args)
+        try:
+            ndev = backend.device_count()
+        except Exception:
+            ndev = 1
+        if ndev > 1 and not args.batch_api_inline:
+            # several GPUs are visible to this one-rank run (the driver's N = 1 run on a whole node): sa_amd_saca_batch then drives
+            # them ALL from one process -- a path no builder session (one GPU) has ever executed.  It runs in a child process with a
+            # time limit, so that whatever it does the headline line above is still printed; the child's JSON is passed through.
+            batch_api = batch_api_subprocess(args)
+        else:
+            try:
+                batch_api = batch_api_leg(backend, args)
+            except Exception as ex:
+                batch_api = {"entry_point": "sa_amd_saca_batch", "verified": False, "error": f"{type(ex).__name__}: {ex}"[:300]}
 
     if rank != 0:
         return None
@@ -720,7 +775,10 @@ def run(args, backend, rank, world, dist=None, share=False):
         "host": host_info(),
     }
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
-        result["cpu_baseline"] = cpu_baseline(text_h, min(args.cpu_sample, n))
+        try:
+            result["cpu_baseline"] = cpu_baseline(text_h, min(args.cpu_sample, n))
+        except Exception as ex:
+            result["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 1, "kind": "port", "error": f"{type(ex).__name__}: {ex}"[:300]}
     else:
         result["cpu_baseline"] = None
     return result
@@ -741,6 +799,9 @@ def main(argv=None):
     share = os.environ.get("SA_BENCH_SHARE_GPU") == "1"
     use_nccl = os.environ.get("SA_BENCH_CONTROL", "gloo") == "nccl" and not share
     backend = HipBackend(0 if share else local_rank)
+    if args.batch_api_only:                                  # (the child of batch_api_subprocess)
+        print(json.dumps(batch_api_leg(backend, args)), flush=True)
+        return 0
     dist = None
     if world > 1:
         import torch.distributed as dist

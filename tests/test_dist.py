@@ -173,6 +173,32 @@ def test_single_rank_path_with_stand_in():
     assert out["host"]["nproc"] >= 1 and "H0_bits_per_byte" in out["config"]
 
 
+def test_batch_api_child_process_failure_is_a_record_not_a_crash():
+    """with several GPUs visible the N = 1 line runs its sa_amd_saca_batch leg in a child process (bench.batch_api_subprocess): here,
+    without a GPU, the child cannot start a backend -- the parent gets an object that says so instead of an exception, and a leg
+    that raises inside run() is recorded the same way (the headline line must survive everything behind it)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse(["--batch-texts", "2", "--text-bytes", "4096", "--small-batch-texts", "0", "--batch-api-timeout", "120"])
+    out = bench.batch_api_subprocess(args)
+    assert out["verified"] is False and out["ran_in"] == "child process" and "error" in out
+    json.dumps(out)
+
+    class Failing(OracleStandIn):
+        def build_batch(self, texts, outs):
+            raise RuntimeError("device lost")
+
+        def build_host(self, text_h, out_h):
+            raise MemoryError("no staging")
+    args = bench.parse(["--steps", "2", "--warmup", "0", "--workload", "c2_uniform_64m", "--n", "20000", "--cpu-sample", "10000", "--e2e-calls", "1",
+                        "--batch-texts", "2", "--small-batch-texts", "0", "--configs", "c5_uniform_512m", "--config-steps", "1"])
+    line = bench.run(args, Failing(), 0, 1)
+    assert line["verified"] is True and line["value"] > 0                       # the headline stands
+    assert "MemoryError" in line["end_to_end"]["error"] and "RuntimeError" in line["batch_api"]["error"]
+    assert "error" in line["configs"]["c5_uniform_512m"] and line["configs"]["c5_uniform_512m"]["verified"] is False
+    json.dumps(line)
+
+
 def test_gpus_flag_starts_the_ranks_itself(monkeypatch):
     """`python bench.py --gpus 2` without WORLD_SIZE launches torch.distributed.run as a child process and never builds a
     backend (= never touches the GPU) in the parent"""

@@ -1291,6 +1291,21 @@ def test_bench_three_ranks_share_one_gpu():
     assert out["batch_c5"]["texts"] == 3 and out["batch_c5"]["verified"] is True
 
 
+def test_bench_batch_leg_as_a_child_process():
+    """`bench.py --batch-api-only`: what the N = 1 line starts as a child when more than one GPU is visible (one process then drives
+    all of them through ONE sa_amd_saca_batch call) -- on this one-GPU box the same command, small texts"""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch-api-only", "--batch-texts", "3", "--text-bytes", str(4 << 20),
+                           "--small-batch-texts", "64"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["entry_point"] == "sa_amd_saca_batch" and out["texts"] == 3 and out["verified"] is True and out["devices"] >= 1
+    assert out["small_texts"]["texts"] == 64 and out["small_texts"]["verified"] is True
+
+
 def test_bench_single_rank_line_with_batch_api():
     """`python bench.py` at N = 1 (small sizes): the dominant kernel is picked by measured time, the CPU baseline carries its
     probe log, and the config-5 leg calls sa_amd_saca_batch once with several texts"""
