@@ -4,6 +4,7 @@
 //   saca(), MAX_LENGTH                      reference src/saca.rs:6-15
 //   SuffixArray::new_/set/len/is_empty/into_parts/from_parts/unchecked_from_parts
 //                                           reference src/sa.rs:23-70, check_integrity src/sa.rs:72-84
+//   SuffixArray::enable_buckets / buckets   reference src/sa.rs:89-119 (the table, built on the GPU from the text alone)
 // Rust panics (assert!, engine failure) are std::logic_error / std::runtime_error here.
 #pragma once
 #include "suffix_array_amd.h"
@@ -64,6 +65,17 @@ public:
     {
         return SuffixArray(s, n, std::move(sa));                  // src/sa.rs:68-70
     }
+    // enable_buckets: 256 * 257 + 1 right bucket edges in the layout of src/sa.rs:94, from the bigram counts of the text
+    // (src/sa.rs:96-116); a second call is a no-op like the reference's (src/sa.rs:90-92)
+    void enable_buckets()
+    {
+        if (!bkt_.empty()) return;
+        std::vector<std::uint32_t> b(SA_AMD_BUCKET_TABLE_LEN);
+        const std::int32_t rc = sa_amd_bucket_table(s_, static_cast<std::int32_t>(n_), nullptr, b.data());
+        if (rc != SA_AMD_OK) throw std::runtime_error(std::string("suffix_array_amd: ") + sa_amd_strerror(rc));
+        bkt_ = std::move(b);
+    }
+    const std::vector<std::uint32_t> &buckets() const { return bkt_; }     // empty: not enabled (the reference's bkt: None)
 
 private:
     SuffixArray(const std::uint8_t *s, std::size_t n, std::vector<std::uint32_t> sa) : s_(s), n_(n), sa_(std::move(sa)) {}
@@ -83,6 +95,7 @@ private:
     const std::uint8_t *s_;
     std::size_t n_;
     std::vector<std::uint32_t> sa_;
+    std::vector<std::uint32_t> bkt_;
 };
 
 }  // namespace suffix_array

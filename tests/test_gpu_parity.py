@@ -1675,3 +1675,43 @@ int main(void) {
                            "-L", os.path.join(ROOT, "suffix_array_amd"), "-lsuffix_array_amd",
                            "-Wl,-rpath," + os.path.join(ROOT, "suffix_array_amd")])
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_cpp_program_through_the_mirror(tmp_path):
+    """a C++ caller of include/suffix_array_amd.hpp, the host-side mirror of the crate's interface: SuffixArray::new_ / set /
+    from_parts (the literal check_integrity of src/sa.rs:72-84) / enable_buckets on the doc-test text of src/lib.rs:28-29"""
+    import subprocess
+    src = tmp_path / "caller.cpp"
+    src.write_text(r'''
+#include "suffix_array_amd.hpp"
+#include <cstdio>
+#include <cstring>
+using suffix_array::SuffixArray;
+int main() {
+    const char *txt = "splendid splendor";
+    const auto *t = reinterpret_cast<const std::uint8_t *>(txt);
+    const std::size_t n = std::strlen(txt);
+    SuffixArray a = SuffixArray::new_(t, n);
+    static const std::uint32_t want[18] = { 17, 8, 7, 5, 14, 3, 12, 6, 2, 11, 4, 13, 15, 1, 10, 16, 0, 9 };
+    if (a.sa().size() != 18 || std::memcmp(a.sa().data(), want, sizeof(want)) != 0) return 1;
+    a.enable_buckets();
+    const auto &b = a.buckets();
+    if (b.size() != 256 * 257 + 1 || b[0] != 1 || b.back() != 18) return 2;
+    const std::size_t idx = std::size_t('s') * 257 + (std::size_t('p') + 1) + 1;     // sub-bucket ('s', 'p'), src/sa.rs:130
+    if (b[idx] - b[idx - 1] != 2) return 3;                                          // "splend" occurs twice (src/lib.rs:28-29)
+    std::vector<std::uint32_t> good(a.sa()), bad(a.sa());
+    std::swap(bad[3], bad[4]);
+    if (!SuffixArray::from_parts(t, n, good)) return 4;
+    if (SuffixArray::from_parts(t, n, bad)) return 5;
+    a.set(t, 6);                                                                     // "splend": set() re-runs construction, src/sa.rs:30-33
+    if (a.sa().size() != 7 || a.sa()[0] != 6) return 6;
+    try { suffix_array::saca(t, n, good.data(), 5); return 7; } catch (const std::logic_error &) { }   // the assert of src/saca.rs:11
+    std::puts("ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "caller_cpp"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "suffix_array_amd"), "-lsuffix_array_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "suffix_array_amd")])
+    assert subprocess.call([str(exe)]) == 0
