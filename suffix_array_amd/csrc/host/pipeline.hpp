@@ -224,7 +224,8 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
                                const SortScratch &ss, uint32_t *final_vals, hipStream_t st, KeyT **keys_res, uint32_t **vals_res, int *passes,
                                int *skipped, const Tuning &tn, bool iota, bool may_skip, bool first_counted,
                                const uint8_t *text = nullptr, int64_t text_n = 0,      // != nullptr (32-bit keys only): the FIRST pass reads its keys from the text (k_onesweep<..., TEXT_KEYS>)
-                               int text_bits = 8)                                      //   8: the text itself (all 256 byte values), 2: the bit-packed text of a four-symbol alphabet
+                               int text_bits = 8,                                      //   8: the text itself (all 256 byte values), 2: the bit-packed text of a four-symbol alphabet
+                               int val_extra = 0)                                      //   the first pass puts that many key bits below the 32 into the top bits of the values (OnesweepPass::val_extra)
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int R = 1 << RBITS;
@@ -293,6 +294,7 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         P.epoch = ++epoch;
         P.flags = (uint32_t)tn.onesweep_flags;
         P.text = text; P.text_n = text_n; P.text_bits = text_bits;
+        P.val_extra = (text && *passes == 0 && iota) ? val_extra : 0;
         if (!K64 && !SEQ && text && *passes == 0)
             PROF(KC_ONESWEEP32, count, st,
                  hipLaunchKernelGGL((k_onesweep<THREADS, ITEMS, KeyT, SEQ, WG_PER_CU, RBITS, !K64 && !SEQ>), dim3(grid), dim3(THREADS), 0, st, (const KeyT *)kin,
@@ -434,7 +436,8 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
                         int end_bit, const SortScratch &ss, uint32_t *final_vals, hipStream_t st, SortResult32 *res,
                         const Tuning &tn, bool iota = false, bool first_counted = false,
                         int rbits = RADIX_BITS,       // 9: nine-bit digits (single-pass engine only, first digit counted by the producer)
-                        const uint8_t *text = nullptr, int64_t text_n = 0, int text_bits = 8)      // the first pass reads its keys from this text (single-pass engine, default tile, counted)
+                        const uint8_t *text = nullptr, int64_t text_n = 0, int text_bits = 8,      // the first pass reads its keys from this text (single-pass engine, default tile, counted)
+                        int val_extra = 0)
 {
     res->keys = keys_in; res->vals = vals_in; res->passes = 0;
     if (count <= 1 || end_bit <= begin_bit) return SA_AMD_OK;
@@ -444,10 +447,10 @@ static int sort_pairs32(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt
         int skipped = 0;
         if (rbits == 9)
             return sort_pairs_onesweep<uint32_t, 1024, 12, false, 9>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
-                                                                     &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted, text, text_n, text_bits);
+                                                                     &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted, text, text_n, text_bits, val_extra);
         if (text)
             return sort_pairs_onesweep<uint32_t, 1024, 12, false, RADIX_BITS>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st,
-                                                                              &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted, text, text_n, text_bits);
+                                                                              &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted, text, text_n, text_bits, val_extra);
 #define OS_CALL32(T, I, S) sort_pairs_onesweep<uint32_t, T, I, S>(keys_in, vals_in, keys_alt, vals_alt, count, begin_bit, end_bit, ss, final_vals, st, \
                                                                  &res->keys, &res->vals, &res->passes, &skipped, tn, iota, false, first_counted)
         switch (tn.onesweep32_shape) {
@@ -551,12 +554,14 @@ static int64_t bucket_cap_max() { return bucket_cap(N_BK_DEFAULT - 1); }
 // its own) when the shape has room to do it well (*fused); the caller has zeroed fin's bitmap and counters.
 static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, int64_t count, int top_bits,
                          uint32_t *start, uint32_t *words, hipStream_t st, const Tuning &tn, bool *done, uint32_t *largest,
-                         const BucketFinish *fin = nullptr, const KeyParams *P = nullptr, const KeySrc *K = nullptr, bool *fused = nullptr)
+                         const BucketFinish *fin = nullptr, const KeyParams *P = nullptr, const KeySrc *K = nullptr, bool *fused = nullptr,
+                         int val_extra = 0)      // the top val_extra bits of every value are the key bits below the 32 (ordered with them, stripped on the way out)
 {
     *done = false; *largest = 0;
     if (fused) *fused = false;
     if (top_bits < 32 - BK_MAX_LBITS || top_bits > BK_TOP_BITS_MAX) return SA_AMD_EINTERNAL;
     const int lbits = 32 - top_bits;
+    if (val_extra < 0 || lbits + val_extra > BK_MAX_LBITS) return SA_AMD_EINTERNAL;
     const uint32_t nb = 1u << top_bits;
     HIP_TRY(hipMemsetAsync(words, 0, 8, st));
     PROF(KC_MISC, nb, st, hipLaunchKernelGGL((k_bucket_starts), dim3((unsigned)ceil_div((int64_t)nb + 1, BK_STARTS_THREADS)), dim3(BK_STARTS_THREADS),
@@ -580,9 +585,9 @@ static int bucket_sort32(const uint32_t *keys_in, const uint32_t *vals_in, uint3
 #define BK_LAUNCH(T, I, W)                                                                                                               \
     do {                                                                                                                                 \
         if (fuse) PROF(KC_BUCKET, count, st, hipLaunchKernelGGL((k_bucket_sort<T, I, W, true>), dim3(nb), dim3(T), 0, st, keys_in, vals_in,         \
-                                                                (const uint32_t *)start, lbits, keys_out, vals_out, words + 1, *fin, *P, *K));      \
+                                                                (const uint32_t *)start, lbits, keys_out, vals_out, words + 1, *fin, *P, *K, val_extra)); \
         else PROF(KC_BUCKET, count, st, hipLaunchKernelGGL((k_bucket_sort<T, I, W, false>), dim3(nb), dim3(T), 0, st, keys_in, vals_in,             \
-                                                            (const uint32_t *)start, lbits, keys_out, vals_out, words + 1, F0, P0, K0));            \
+                                                            (const uint32_t *)start, lbits, keys_out, vals_out, words + 1, F0, P0, K0, val_extra)); \
     } while (0)
     switch (shape) {
     case 0: BK_LAUNCH(256, 10, 6); break;
@@ -1241,6 +1246,11 @@ struct DeviceBuild {
         const bool wide_ok = onesweep_on(w.ss, tn) && tn.onesweep32_shape == 0;      // (nine-bit digits: single-pass engine, default tile)
         if (tn.bucket_bits == 18 && wide_ok) return 18;
         if (tn.bucket_bits == 16) return 16;
+        // (measured, random bytes and DNA: with the two key bits that travel in the values (initial_sort_top32) 18 bits win from about
+        // 4.9e8 suffixes on -- 2^29: 9.09 against 9.36 ms --, without them only where 16 bits no longer fit)
+        const bool value_bits = wide_ok && !tn.no_value_bits && !tn.no_text_keys && g_bits <= 30 &&
+                                ((sigma == 256 && P.bits == 8) || (sigma == 4 && P.bits == 2 && !tn.no_packed_text));
+        if (value_bits && (n >> 16) > 7500 && (n >> 18) * 10 <= bucket_cap_max() * 9) return 18;
         if ((n >> 16) * 10 <= bucket_cap(2) * 9) return 16;
         if (wide_ok && (n >> 18) * 10 <= bucket_cap_max() * 9) return 18;
         if ((n >> 16) * 10 <= bucket_cap_max() * 9) return 16;
@@ -1405,6 +1415,17 @@ struct DeviceBuild {
             // ... and with four symbols (DNA) the bit-packed text is the stream of keys: it is packed first (n / 4 bytes instead of a
             // key array of 4n), and counted and read by the first pass as it stands
             const bool packed_keys = text_route && sigma == 4 && P.bits == 2 && packed_out != nullptr;
+            // Key bits for free: an index below 2^g_bits leaves 32 - g_bits bits of the value word unused, and the bucket sort stages
+            // 16 bits per pair of which 32 - top_bits are low key bits.  When both have room (texts of 0.6 - 1 GiB: 18 top bits, 30-bit
+            // indices) the first pass puts the two key bits BEHIND the 32 there and the bucket sort orders 34 bits: a quarter of the ties
+            // on all 32 bits are left for its round on the low key bits (1 GiB of DNA: 22 % of the suffixes -> 6 %).
+            int val_extra = 0;
+            if ((text_keys || packed_keys) && !tn.no_value_bits) {
+                val_extra = 32 - g_bits;
+                if (val_extra > BK_MAX_LBITS - (32 - top_bits)) val_extra = BK_MAX_LBITS - (32 - top_bits);
+                if (val_extra > 2) val_extra = 2;
+                if (val_extra < 0) val_extra = 0;
+            }
             if (counted) HIP_TRY(hipMemsetAsync(fc.zero_ptr, 0, fc.zero_bytes, st));
             if (text_keys || packed_keys) {
                 int split = 2048 / fc.G;
@@ -1426,7 +1447,7 @@ struct DeviceBuild {
             SortResult32 s32;
             if (top_bits) {
                 rc = sort_pairs32(k32a, w.valsA, k32b, w.valsB, n, 32 - top_bits, 32, w.ss, nullptr, st, &s32, tn, iota, counted, rbits,
-                                  text_keys ? dT : (packed_keys ? (const uint8_t *)packed_out : (const uint8_t *)nullptr), n, packed_keys ? 2 : 8);
+                                  text_keys ? dT : (packed_keys ? (const uint8_t *)packed_out : (const uint8_t *)nullptr), n, packed_keys ? 2 : 8, val_extra);
                 if (rc) return rc;
                 local.sort_passes += s32.passes; local.sorted_elements += (int64_t)s32.passes * n;
                 uint32_t *kout = (s32.keys == k32a) ? k32b : k32a;
@@ -1449,7 +1470,7 @@ struct DeviceBuild {
                 KeyParams Pf = P;
                 Pf.packed = packed_out;             // (written by now: the fused round's text look-ups take the bit-packed text, a quarter of the lines)
                 rc = bucket_sort32(s32.keys, s32.vals, kout, SA, n, top_bits, w.bk_start, w.os_err + 2, st, tn, &done, &largest,
-                                   fuse ? &F : nullptr, &Pf, &K, &fused);
+                                   fuse ? &F : nullptr, &Pf, &K, &fused, val_extra);
                 if (rc) return rc;
                 bucket_finished = done && fused;
                 if (trace) fprintf(stderr, "suffix_array_amd: 32-bit first stage: %d global passes over the top %d key bits, largest bucket %u -> %s\n", s32.passes, top_bits, largest,

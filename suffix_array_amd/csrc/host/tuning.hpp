@@ -79,6 +79,7 @@ struct Tuning {
     bool no_defer = false;           // SA_AMD_NO_DEFER: every refinement round reads the local pass's counts back in its middle (two blocking read-backs per round instead of one)
     bool no_big_group_sort = false;  // SA_AMD_NO_BIG_GROUP_SORT: groups of 1025..16384 members go through the global radix sort, not k_group_sort_big
     bool no_text_keys = false;       // SA_AMD_NO_TEXT_KEYS: the first global pass of the bucket route always reads a key array (never the text itself)
+    bool no_value_bits = false;      // SA_AMD_NO_VALUE_BITS: the unused top bits of the 32-bit stage's values never carry key bits into the bucket sort
     bool no_bucket_sort = false;     // SA_AMD_NO_BUCKET_SORT: the 32-bit first stage always takes four global passes (never two + the in-LDS bucket sort)
     int64_t bucket_min_n = (int64_t)1 << 25;   // SA_AMD_BUCKET_MIN_N: smallest text whose 32-bit first stage sorts the low 16 key bits bucket by bucket in LDS
     bool no_bucket_finish = false;   // SA_AMD_NO_BUCKET_FINISH: the suffixes tied on the top 32 key bits are ordered by k_finish_sorted in a pass of its own, not inside k_bucket_sort
@@ -149,6 +150,7 @@ struct Tuning {
         t.no_unary_shortcut = env_flag("SA_AMD_NO_UNARY_SHORTCUT");
 
         t.no_text_keys = env_flag("SA_AMD_NO_TEXT_KEYS");
+        t.no_value_bits = env_flag("SA_AMD_NO_VALUE_BITS");
         t.no_bucket_sort = env_flag("SA_AMD_NO_BUCKET_SORT");
         t.bucket_min_n = env_int("SA_AMD_BUCKET_MIN_N", (int64_t)1 << 25, 1, (int64_t)1 << 40);
         t.no_bucket_finish = env_flag("SA_AMD_NO_BUCKET_FINISH");

@@ -98,7 +98,7 @@ template <int THREADS, int ITEMS, int MINW = 1, bool FINISH = false>
 __global__ __launch_bounds__(THREADS, MINW) void k_bucket_sort(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                          const uint32_t *__restrict__ start, int lbits,
                                                          uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                                                         uint32_t *__restrict__ err, BucketFinish F, KeyParams P, KeySrc K)
+                                                         uint32_t *__restrict__ err, BucketFinish F, KeyParams P, KeySrc K, int xbits)
 {
     constexpr int CAP = THREADS * ITEMS;
     constexpr int NWAVES = THREADS / WAVE;
@@ -151,12 +151,15 @@ __global__ __launch_bounds__(THREADS, MINW) void k_bucket_sort(const uint32_t *_
         const int e = e0 + j * WAVE;
         uint32_t kx = 0, vx = 0;
         if (j < J && e < size) { kx = keys_in[lo + e]; vx = vals_in[lo + e]; }
-        key[j] = kx; val[j] = vx;
+        // the key from here on: the low key bits, and below them the xbits further key bits that came in the top of the value
+        key[j] = ((kx & ((1u << lbits) - 1u)) << xbits) | (uint32_t)((uint64_t)vx >> (32 - xbits));
+        val[j] = (uint32_t)(((uint64_t)vx << (32 + xbits)) >> (32 + xbits));
     }
-    const uint32_t hi_bits = (keys_in[lo] >> lbits) << lbits;      // the bucket's number, as key bits (1 <= lbits <= 16, host-checked)
-    const uint32_t lo_mask = (1u << lbits) - 1u;
-    const int bbits = lbits < BK_BBITS ? lbits : BK_BBITS;        // second pass: the top bits of the low key, stable
-    const int abits = lbits - bbits;                               // first pass: the bits below them
+    const uint32_t hi_bits = (keys_in[lo] >> lbits) << lbits;      // the bucket's number, as key bits (1 <= lbits, lbits + xbits <= 16, host-checked)
+    const int sbits = lbits + xbits;                               // key bits ordered here
+    const uint32_t lo_mask = (1u << sbits) - 1u;
+    const int bbits = sbits < BK_BBITS ? sbits : BK_BBITS;        // second pass: the top bits of the staged key, stable
+    const int abits = sbits - bbits;                               // first pass: the bits below them
 
     if (abits > 0) {
         // ---- first pass: a counter per digit hands out the places.  Which of two pairs with the same digit comes first is left
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_bucket_sort(const uint32_t *_
     for (int j = 0; j < ITEMS; ++j) {
         const int idx = tid + j * THREADS;
         if (idx < size) {
-            keys_out[lo + idx] = hi_bits | (uint32_t)lds_k[idx];
+            keys_out[lo + idx] = hi_bits | ((uint32_t)lds_k[idx] >> xbits);
             vals_out[lo + idx] = lds_v[idx];
         }
     }

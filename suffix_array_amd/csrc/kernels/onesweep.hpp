@@ -194,6 +194,8 @@ struct OnesweepPass {
     const uint8_t *text;            // TEXT_KEYS instances: the keys are read from here (text_key32), keys_in is not looked at;
     int64_t text_n;                 //   text_bits = 2: `text` is the bit-packed text of a four-symbol alphabet (packed_window64)
     int text_bits;
+    int val_extra;                  // TEXT_KEYS: the e key bits BELOW the 32 of the key travel in the top e bits of the value (the index needs only
+                                    //   32 - e: host-checked), so that the bucket sort orders 32 + e key bits (kernels/bucket_sort.hpp); e <= 2
     uint32_t flags;                 // bit 0: look at the predecessors' granules before the staging, not after (scheduling A/B, same
                                     // result); bit 7 (diagnostic library only): phase stamps
 };
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
         const bool full = valid == TILE;
         KeyT key[ITEMS];
         uint32_t val[ITEMS], pp[ITEMS / 2];    // pp: tile positions (< 65536), two to a register
+        uint32_t xpack = 0;                    // TEXT_KEYS: the two key bits below key[j] in bits [2j, 2j + 2)
 #define OS_POS(j) ((pp[(j) >> 1] >> (16 * ((j) & 1))) & 0xffffu)
         if (TEXT_KEYS && P.text_bits == 2) {
             // four symbols: 12 consecutive suffixes = 24 + 30 stream bits from byte (base + first position) / 4 on (the zero bytes behind
@@ -311,6 +314,10 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
             const uint64_t win = packed_window64(P.text + ((base + ebv) >> 2));
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) key[j] = (full || ebv + j < valid) ? (KeyT)(uint32_t)(win >> (32 - 2 * j)) : (KeyT)~(KeyT)0;
+            if (P.val_extra) {                 // (uniform) the symbol behind the key: stream bits [2j + 32, 2j + 34)
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) xpack |= (((uint32_t)win >> (30 - 2 * j)) & 3u) << (2 * j);
+            }
         } else if (TEXT_KEYS && base + TILE + 24 <= P.text_n) {   // (uniform) every read below stays inside the text
             static_assert(!TEXT_KEYS || (ITEMS <= 13 && ITEMS % 4 == 0), "ITEMS + 3 bytes out of five aligned words (2 ITEMS + 30 bits out of 64 for the packed text); a lane's first position is word-aligned relative to the tile");
             const uintptr_t a = (uintptr_t)(P.text + base + ebv);
@@ -324,12 +331,18 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j)
                 key[j] = (KeyT)__builtin_bswap32(__builtin_amdgcn_alignbyte(v[(j >> 2) + 1], v[j >> 2], (uint32_t)(j & 3)));
+            if (P.val_extra) {                 // (uniform) the top two bits of the byte behind the key
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) xpack |= ((v[(j + 4) >> 2] >> (8 * ((j + 4) & 3) + 6)) & 3u) << (2 * j);
+            }
         } else {
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int e = OS_ELEM(j);
-            if (TEXT_KEYS) key[j] = (full || e < valid) ? (KeyT)text_key32(P.text, P.text_n, base + e) : (KeyT)~(KeyT)0;
-            else key[j] = (full || e < valid) ? keys_in[base + e] : (KeyT)~(KeyT)0;
+            if (TEXT_KEYS) {
+                key[j] = (full || e < valid) ? (KeyT)text_key32(P.text, P.text_n, base + e) : (KeyT)~(KeyT)0;
+                if (P.val_extra && base + e + 4 < P.text_n) xpack |= ((uint32_t)P.text[base + e + 4] >> 6) << (2 * j);
+            } else key[j] = (full || e < valid) ? keys_in[base + e] : (KeyT)~(KeyT)0;
         }
         }
         if (seg != cur_seg) {                  // (uniform) where do this segment's digit runs start?
@@ -383,6 +396,11 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU * THREADS / 256) void k_onesweep
         } else {                               // no values array: the value is the index itself
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) val[j] = (uint32_t)(base + OS_ELEM(j));
+            if (TEXT_KEYS && P.val_extra) {
+                const int e = P.val_extra;
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) val[j] |= (((xpack >> (2 * j)) & 3u) >> (2 - e)) << (32 - e);
+            }
         }
         };
         if (!SEQ) load_vals();

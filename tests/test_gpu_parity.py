@@ -826,7 +826,7 @@ def test_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed):
     assert np.array_equal(build(text), exp)
 
 
-@pytest.mark.parametrize("gen,n,seed", [("uniform", 500_000, 2), ("uniform", 3_000_001, 3), ("dna", 1 << 20, 4), ("dna", 1_000_003, 6), ("english", 300_000, 3),
+@pytest.mark.parametrize("gen,n,seed", [("uniform", 500_000, 2), ("uniform", 3_000_001, 3), ("dna", 1 << 20, 4), ("dna", 1_000_003, 6), ("dna", (1 << 22) + 5, 8), ("english", 300_000, 3),
                                         ("dna_repeats", 400_000, 5), ("periodic", 100_001, 1), ("sigma2", 250_000, 7), ("sigma200", 900_000, 9)])
 @pytest.mark.parametrize("shape,bits", [("-1", "0"), ("3", "16"), ("4", "0"), ("-1", "18"), ("2", "18")])
 def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n, seed, shape, bits):
@@ -858,6 +858,9 @@ def test_bucket_route_of_the_two_stage_initial_sort(oracle, monkeypatch, gen, n,
     assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_BUCKET_FINISH", "1")    # the round on the low key bits as a pass of its own (k_finish_sorted)
     assert np.array_equal(build(text), exp)
+    monkeypatch.setenv("SA_AMD_NO_VALUE_BITS", "1")       # (18 bits, keys read from the text: two more key bits would travel in the values' top bits)
+    assert np.array_equal(build(text), exp)
+    monkeypatch.delenv("SA_AMD_NO_VALUE_BITS")
     monkeypatch.setenv("SA_AMD_NO_TEXT_KEYS", "1")        # (all 256 byte values: the first global pass would read its keys from the text)
     assert np.array_equal(build(text), exp)
     monkeypatch.setenv("SA_AMD_NO_ONESWEEP", "1")         # the global passes by the three-kernel engine (diagnostic library)
@@ -1049,7 +1052,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_NO_FIRST_TAIL", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_GRAM_TAIL", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS", "SA_AMD_SAMPLE_SORT", "SA_AMD_SAMPLE_SORT_MIN_N", "SA_AMD_SAMPLE_LOG", "SA_AMD_SAMPLE_MERGE", "SA_AMD_CACHE_IDLE_MS", "SA_AMD_NO_REDUCED", "SA_AMD_NO_UNARY_SHORTCUT",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_VALUE_BITS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS", "SA_AMD_SAMPLE_SORT", "SA_AMD_SAMPLE_SORT_MIN_N", "SA_AMD_SAMPLE_LOG", "SA_AMD_SAMPLE_MERGE", "SA_AMD_CACHE_IDLE_MS", "SA_AMD_NO_REDUCED", "SA_AMD_NO_UNARY_SHORTCUT",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 

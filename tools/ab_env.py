@@ -17,6 +17,8 @@ if name.startswith("adv:"):                     # adversarial families: adv:<one
     t = {"one": lambda: np.full(nn, 97, dtype=np.uint8), "ab": lambda: np.resize(np.frombuffer(b"ab", dtype=np.uint8), nn).copy(),
          "fib": lambda: _fib(nn), "twice": lambda: np.concatenate([corpus.english(nn // 2, 5)] * 2),
          "p1000": lambda: np.resize(np.random.default_rng(7).integers(0, 256, 1000, dtype=np.uint8), nn).copy()}[fam]()
+elif "@" in name:                               # <workload>@<n>: the workload's generator at another size
+    t = corpus.workload(name.split("@")[0], 0, int(name.split("@")[1]))
 else:
     t = corpus.workload(name)
 n = t.size
