@@ -1304,7 +1304,7 @@ struct DeviceBuild {
                 const uint32_t H = (uint32_t)S * 4u;
                 HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
                 HIP_TRY(hipMemsetAsync(w.total, 0, 8, st));
-                PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
+                PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3((unsigned)(ceil_div(S, 256) < 4096 ? ceil_div(S, 256) : 4096)), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
                                                         (unsigned long long *)w.keysB, H - 1u, w.total));
                 // the same samples, counted per bucket of the bucket sort: an estimate of its largest bucket (word 1 of the read-back)
                 const int tb = choose_bucket_bits();
@@ -1344,7 +1344,7 @@ struct DeviceBuild {
                                                             -1, w.keysA));
                     HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
                     HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
-                    PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
+                    PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3((unsigned)(ceil_div(S, 256) < 4096 ? ceil_div(S, 256) : 4096)), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
                                                             (unsigned long long *)w.keysB, H - 1u, w.total));
                     uint32_t dups64 = 0;
                     { const int rcw = read_words(&dups64, w.total, 4, st); if (rcw) return rcw; }
@@ -1370,7 +1370,7 @@ struct DeviceBuild {
             const uint32_t H = (uint32_t)S * 4u;
             HIP_TRY(hipMemsetAsync(w.keysB, 0xff, (size_t)H * 8, st));
             HIP_TRY(hipMemsetAsync(w.total, 0, 4, st));
-            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3(256), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
+            PROF(KC_MISC, S, st, hipLaunchKernelGGL((k_count_sample_dups), dim3((unsigned)(ceil_div(S, 256) < 4096 ? ceil_div(S, 256) : 4096)), dim3(256), 0, st, (const uint64_t *)w.keysA, S,
                                                     (unsigned long long *)w.keysB, H - 1u, w.total));
             uint32_t dups = 0;
             { const int rcw = read_words(&dups, w.total, 4, st); if (rcw) return rcw; }
@@ -1614,13 +1614,20 @@ struct DeviceBuild {
                                                      0, st, sorted32, SA, dT, P, n, K, cap, surv_bits, surv_head, w.tcnt, w.total, (uint32_t *)nullptr,
                                                      (uint32_t *)nullptr, (uint32_t *)nullptr));
             }
-            PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+            // (k_bucket_sort counts its survivors itself: the scan of the tiles' counts runs only if there are any)
+            if (!bucket_finished) PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
             uint32_t cnt3[3] = { 0, 0, 0 };                       // still tied on 64 bits, members of groups nobody owned, tied on 32 bits
             {
                 uint32_t words[64 + RR_CHG_COUNTERS * 32];         // (the tied-slot counts are spread over w.chg, directly behind w.total)
                 const int rcw = read_words(words, w.total, sizeof(words), st); if (rcw) return rcw;
                 cnt3[0] = words[0]; cnt3[1] = words[1];
                 for (int c = 0; c < RR_CHG_COUNTERS; ++c) cnt3[2] += words[64 + c * 32];
+                if (bucket_finished) {
+                    cnt3[0] = 0;
+                    for (int c = 0; c < RR_CHG_COUNTERS; ++c) cnt3[0] += words[64 + c * 32 + 1];
+                    if (cnt3[0] != 0 && cnt3[1] == 0)
+                        PROF(KC_RR_SCAN, tiles, st, hipLaunchKernelGGL((k_rr_scan), dim3(1), dim3(SPINE_THREADS), 0, st, w.tcnt, w.thead, tiles, w.total));
+                }
             }
             if (cnt3[1] == 0) {
                 finished32 = true;

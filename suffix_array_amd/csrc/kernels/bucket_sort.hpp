@@ -379,6 +379,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_bucket_sort(const uint32_t *_
                 const int64_t j0 = (int64_t)(lo - lsh) + 32 * (int64_t)i;
                 atomicOr(&F.surv_bits[j0 >> 5], sw);
                 atomicAdd(&F.tile_cnt[j0 / RR_TILE], (uint32_t)__popc(sw));
+                // (how many there are in all, next to the tied-slot counts: a text without any -- random bytes -- skips the scan of tile_cnt)
+                atomicAdd(&F.counters[64 + (blockIdx.x % RR_CHG_COUNTERS) * 32 + 1], (uint32_t)__popc(sw));
             }
         }
     }
