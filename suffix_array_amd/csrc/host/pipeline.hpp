@@ -282,7 +282,12 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         }
         OnesweepPass P;
         P.hist_cur = zone(z) + OS_TICKETS;
-        P.hist_next = last ? nullptr : zone(z + 1) + OS_TICKETS;
+        // (short inputs: the flush of the next digit's counts -- 256 x segments atomics per workgroup on the same few lines -- costs
+        // more than a counting kernel of its own)
+        // (measured, tools/midsize_knobs.py: 1 MiB of random bytes 0.420 -> 0.369 ms, 2 MiB of English 0.902 -> 0.777; the other way
+        // round below 400 K pairs -- a launch more per pass -- and from 8 M on)
+        const bool count_next = !last && (RBITS != RADIX_BITS || count >= tn.count_next_min_n || count < tn.count_next_below_n);
+        P.hist_next = count_next ? zone(z + 1) + OS_TICKETS : nullptr;
         P.tickets = zone(z + 1);
         P.status = ss.status;
         P.err = ss.err;
@@ -309,7 +314,7 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         vout = free_v;
         ++*passes;
         ++z;
-        have_counts = !last;
+        have_counts = count_next;
     }
     *keys_res = kin; *vals_res = vin;
     return SA_AMD_OK;
@@ -730,7 +735,28 @@ struct PinnedWords {
 };
 static thread_local PinnedWords g_pinned;
 static thread_local int g_readbacks = 0;        // blocking read-backs of the calling thread's current build (sa_amd_stats.readbacks)
-static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)     // bytes <= 4096; synchronises the stream
+static thread_local bool g_posted_off = false;  // SA_AMD_NO_POSTED_READBACK (set per build from the tuning)
+static thread_local uint32_t g_post_seq = 0;
+
+// A read-back as a POSTED write: one tiny kernel stores the words into the (mapped) pinned block, every 64-byte line tagged with
+// a sequence number, and the host spins on the tags -- instead of a copy command plus hipStreamSynchronize, whose wake-up costs
+// more than the kernel (measured, tools/readback_probe.hip: kernel + copy + synchronise 15.0 us, kernel + post kernel + spin
+// 10.2 us, kernel + synchronise alone 11.4 us).  Line q of the block = [tag, words 15q .. 15q + 14]; the tag sits in the same
+// line as the data it vouches for, so a line is either old or complete whatever the order the lines arrive in.
+constexpr int POST_LINE = 16;
+__global__ __launch_bounds__(256) void k_post_words(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int words, uint32_t seq)
+{
+    const int lines = (words + POST_LINE - 2) / (POST_LINE - 1);
+    for (int i = threadIdx.x; i < lines * POST_LINE; i += 256) {
+        const int q = i / POST_LINE, j = i % POST_LINE;
+        if (j) { const int k = q * (POST_LINE - 1) + j - 1; dst[i] = k < words ? src[k] : 0u; }
+    }
+    __threadfence_system();
+    __syncthreads();
+    for (int q = threadIdx.x; q < lines; q += 256) __hip_atomic_store(dst + q * POST_LINE, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)     // bytes <= 3840, a multiple of 4; synchronises the stream
 {
     ++g_readbacks;
     if (!g_pinned.b.p && !g_pinned.failed && pool().pinned(4096, -1, -1, &g_pinned.b) != SA_AMD_OK) g_pinned.failed = true;
@@ -738,6 +764,40 @@ static int read_words(void *dst, const void *dsrc, size_t bytes, hipStream_t st)
         HIP_TRY(hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         return SA_AMD_OK;
+    }
+    const int words = (int)(bytes / 4);
+    const int lines = (words + POST_LINE - 2) / (POST_LINE - 1);
+    if (!g_posted_off && (bytes & 3) == 0 && words > 0 && (size_t)lines * POST_LINE * 4 <= 4096) {
+        uint32_t *host = (uint32_t *)g_pinned.b.p;
+        if (++g_post_seq == 0) ++g_post_seq;
+        const uint32_t seq = g_post_seq;
+        // (the pool's pinned blocks are portable and mapped: the host address is valid on every device)
+        hipLaunchKernelGGL(k_post_words, dim3(1), dim3(256), 0, st, (const uint32_t *)dsrc, host, words, seq);
+        if (hipGetLastError() == hipSuccess) {
+            const auto t0 = std::chrono::steady_clock::now();
+            bool done = false, finished = false;
+            for (unsigned spin = 0; !done; ++spin) {
+                done = true;
+                for (int q = lines - 1; q >= 0 && done; --q)
+                    done = __atomic_load_n((volatile uint32_t *)(host + q * POST_LINE), __ATOMIC_ACQUIRE) == seq;
+                if (done) break;
+                if ((spin & 1023u) == 1023u) {
+                    // the stream has drained and the tags are still not there (a second look after the query): the copy path decides
+                    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                    if (us > 200.0) {
+                        if (finished) break;
+                        const hipError_t q = hipStreamQuery(st);
+                        if (q == hipSuccess) finished = true;
+                        else if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+                    }
+                }
+            }
+            if (done) {
+                uint32_t *out = (uint32_t *)dst;
+                for (int k = 0; k < words; ++k) out[k] = host[(k / (POST_LINE - 1)) * POST_LINE + 1 + k % (POST_LINE - 1)];
+                return SA_AMD_OK;
+            }
+        }
     }
     HIP_TRY(hipMemcpyAsync(g_pinned.b.p, dsrc, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -2068,6 +2128,7 @@ static int build_device(const uint8_t *dT, uint32_t *dSA, int32_t n32, void *dWo
     B.trace_t = now_ms();
     memset(&B.local, 0, sizeof(B.local));
     g_readbacks = 0;
+    g_posted_off = B.tn.no_posted_readback;
     const Tuning &tn = B.tn;
     sa_amd_stats &local = B.local;
     if (n == 0) {

@@ -897,6 +897,26 @@ def test_groups_of_thousands_are_ordered_in_lds(oracle, monkeypatch, period, cop
                 monkeypatch.delenv(k)
 
 
+@pytest.mark.parametrize("period,copies", [(700, 97), (700, 130), (500, 300), (333, 700), (211, 1000), (211, 1024)])
+def test_groups_across_tile_boundaries(oracle, monkeypatch, period, copies):
+    """k_group_sort_straddle: a random block repeated `copies` times ties every suffix with `copies` - 1 others, and groups of
+    that many members cut by a 2 048-element tile boundary are ordered by one workgroup each -- by counting up to 96 members,
+    by a bitonic network in LDS beyond; text-keyed rounds, rank rounds and the chase, plus a mixed text"""
+    rng = np.random.default_rng(period * 7 + copies)
+    block = rng.integers(0, 256, period, dtype=np.uint8)
+    text = np.tile(block, copies)
+    mixed = np.concatenate([np.tile(block, copies // 2), corpus.english(50_000, 3), np.tile(block[: period // 3], copies), rng.integers(0, 3, 20_000, dtype=np.uint8)])
+    for t in (text, mixed):
+        exp = oracle.sais(t)
+        for env in ({}, {"SA_AMD_NO_REPEAT_PROBE": "1"}, {"SA_AMD_NO_REPEAT_PROBE": "1", "SA_AMD_NO_GRAM_KEYS": "1", "SA_AMD_KEY_BITS": "24"},
+                    {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_CHASE": "1"}, {"SA_AMD_FORCE_DENSE": "1", "SA_AMD_CHASE": "7"}, {"SA_AMD_NO_BIG_GROUP_SORT": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            assert np.array_equal(build(t), exp), (period, copies, env)
+            for k in env:
+                monkeypatch.delenv(k)
+
+
 def test_bucket_route_is_not_tried_on_a_text_with_one_huge_bucket(oracle, monkeypatch):
     """a text the entropy probe sends to the 32-bit first stage (its 4-byte prefixes are nearly unique) although one value of
     the top 16 key bits holds 1/32 of the suffixes: the probe's samples, counted per bucket, say so and the two global passes
@@ -1052,7 +1072,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_NO_FIRST_TAIL", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_GRAM_TAIL", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_VALUE_BITS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS", "SA_AMD_SAMPLE_SORT", "SA_AMD_SAMPLE_SORT_MIN_N", "SA_AMD_SAMPLE_LOG", "SA_AMD_SAMPLE_MERGE", "SA_AMD_CACHE_IDLE_MS", "SA_AMD_NO_REDUCED", "SA_AMD_NO_UNARY_SHORTCUT",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_VALUE_BITS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_NO_POSTED_READBACK", "SA_AMD_COUNT_NEXT_MIN_N", "SA_AMD_COUNT_NEXT_BELOW_N", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS", "SA_AMD_SAMPLE_SORT", "SA_AMD_SAMPLE_SORT_MIN_N", "SA_AMD_SAMPLE_LOG", "SA_AMD_SAMPLE_MERGE", "SA_AMD_CACHE_IDLE_MS", "SA_AMD_NO_REDUCED", "SA_AMD_NO_UNARY_SHORTCUT",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 
