@@ -1237,6 +1237,7 @@ struct DeviceBuild {
     SortResult sr;
     const uint32_t *sorted32 = nullptr; // top-32 stage: the sorted 32-bit keys (no 64-bit sorted array exists)
     int bucket_top_bits = 0;            // key bits the two global passes in front of the bucket sort order (0: four global passes)
+    bool flat_text = false;             // short text whose byte values are equally frequent: narrower initial keys (geometry_and_probes)
     bool bucket_finished = false;       // ... and k_bucket_sort has already ordered the suffixes tied on those 32 bits by their low key bits
     uint64_t *sorted0 = nullptr;        // the initial keys in SA order (kept for the rank look-ups)
     // ---- the tied list and its buffers (from first_round_from_sorted_keys on) ----
@@ -1317,6 +1318,8 @@ struct DeviceBuild {
         return 0;
     }
 
+    bool flat_rule_applies() const { return n >= 2 && n < tn.top32_probe_min_n && n < ((int64_t)1 << 24) && !tn.no_flat_rule; }
+
     // 1-2. which byte values occur -> symbol codes and key geometry; entropy probe, repeat probe, gram keys (read-backs: the 256 presence flags, two duplicate counts, the number of grams in use)
     int geometry_and_probes()
     {
@@ -1327,11 +1330,31 @@ struct DeviceBuild {
             int64_t blocks = ceil_div(ceil_div(n, 16), BH_THREADS);
             if (blocks > 2048) blocks = 2048;
             if (blocks < 1) blocks = 1;
-            PROF(KC_BYTE_HIST, n, st, hipLaunchKernelGGL((k_byte_hist), dim3((unsigned)blocks), dim3(BH_THREADS), 0, st, dT, n, w.hist));
+            // (texts below the entropy probe's size: with counts, for the flat-histogram rule below)
+            const bool counts = flat_rule_applies();
+            if (counts) PROF(KC_BYTE_HIST, n, st, hipLaunchKernelGGL((k_byte_hist_counts), dim3((unsigned)(blocks > 256 ? 256 : blocks)), dim3(BH_THREADS), 0, st, dT, n, w.hist));
+            else PROF(KC_BYTE_HIST, n, st, hipLaunchKernelGGL((k_byte_hist), dim3((unsigned)blocks), dim3(BH_THREADS), 0, st, dT, n, w.hist));
         }
         uint32_t hist[256];
         { const int rcw = read_words(hist, w.hist, sizeof(hist), st); if (rcw) return rcw; }
-        key_bits = make_key_params(hist, &P, &sigma, tn.key_bits_max);      // (gram keys, step 2c, may shorten it)
+        // Texts too short for the entropy probe (a sampling pass and a read-back of its own): byte values that are all equally
+        // frequent (order-0 entropy = log2 of their number: random bytes, random DNA) say "no structure at order 0", and then
+        // log2 n + 20 key bits separate nearly every suffix -- five radix passes instead of eight at 1 MiB (random bytes 0.36 ->
+        // 0.25 ms; English-like text, whose histogram is anything but flat, would pay 0.50 -> 0.71 for the same keys and keeps all
+        // 64 bits).  A flat text that does repeat (a period, a block copied twice) is ordered by the rounds as before.
+        int kb_max = tn.key_bits_max;
+        if (flat_rule_applies()) {
+            double h0 = 0.0; int used = 0;
+            for (int c = 0; c < 256; ++c)
+                if (hist[c]) { const double pc = (double)hist[c] / (double)n; h0 -= pc * std::log2(pc); ++used; }
+            if (used >= 2 && h0 > std::log2((double)used) - 0.01) {
+                int kb = (bit_length((uint64_t)(n - 1)) + 20 + 7) / 8 * 8;
+                if (kb < 32) kb = 32;
+                if (kb < kb_max) kb_max = kb;
+                flat_text = true;
+            }
+        }
+        key_bits = make_key_params(hist, &P, &sigma, kb_max);      // (gram keys, step 2c, may shorten it)
         local.sigma = sigma; local.bits_per_symbol = P.bits; local.symbols_per_key = P.k;
         if (sigma == 1 && !tn.no_unary_shortcut) {
             // one byte value repeated: every suffix is a proper prefix of every longer one, the order is by length.  (The general

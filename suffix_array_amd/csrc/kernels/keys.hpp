@@ -45,6 +45,41 @@ __global__ __launch_bounds__(BH_THREADS) void k_byte_hist(const uint8_t *__restr
     if (h[threadIdx.x]) hist[threadIdx.x] = 1u;
 }
 
+// The same read with COUNTS (texts of at most a few MiB, where the launch, not the LDS atomics, is the cost): the host also
+// wants to know whether the byte values are evenly used (see DeviceBuild::geometry_and_probes: "flat" texts sort narrower keys).
+__global__ __launch_bounds__(BH_THREADS) void k_byte_hist_counts(const uint8_t *__restrict__ T, int64_t n, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[BH_THREADS / WAVE][256];
+    for (int i = threadIdx.x; i < (BH_THREADS / WAVE) * 256; i += BH_THREADS) (&h[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t *mine = h[wave_id()];
+    const uintptr_t addr = (uintptr_t)T;
+    int64_t head = (int64_t)((16 - (addr & 15)) & 15);
+    if (head > n) head = n;
+    const int64_t nvec = (n - head) / 16;
+    const uint4 *V = (const uint4 *)(T + head);
+    const int64_t gtid = (int64_t)blockIdx.x * BH_THREADS + threadIdx.x;
+    const int64_t gstride = (int64_t)gridDim.x * BH_THREADS;
+    for (int64_t i = gtid; i < nvec; i += gstride) {
+        const uint4 q = V[i];
+        const uint32_t w4[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) atomicAdd(&mine[(w4[a] >> (8 * b)) & 255u], 1u);
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = threadIdx.x; i < head; i += BH_THREADS) atomicAdd(&mine[T[i]], 1u);
+        for (int64_t i = head + nvec * 16 + threadIdx.x; i < n; i += BH_THREADS) atomicAdd(&mine[T[i]], 1u);
+    }
+    __syncthreads();
+    uint32_t c = 0;
+#pragma unroll
+    for (int w = 0; w < BH_THREADS / WAVE; ++w) c += h[w][threadIdx.x];
+    if (c) atomicAdd(&hist[threadIdx.x], c);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_build_keys: key[i] = the first k symbol codes of suffix i, `bits` bits each, most
 // significant symbol first, zero codes past the end of the text; val[i] = i.
