@@ -41,6 +41,35 @@ static thread_local HostTiming g_host_timing;
 constexpr size_t STAGE_BYTES = (size_t)16 << 20;
 constexpr int STAGE_COUNT = 3;
 
+// Device -> pinned stage by a copy KERNEL that stores into the mapped block, not by the copy engine.  Measured
+// (tools/realloc_dma_probe.hip, profiles/r04_realloc_dma_probe.txt): hipMemcpyAsync out of the first device block a process
+// allocates runs at 55 GB/s, out of ANY block allocated after a large one was freed at 29.5 GB/s -- for the rest of the process,
+// and sometimes from its start, depending on what the process before left behind.  A pool that trims idle blocks (pool.hpp), a
+// caller whose texts grow: the download of the next build is then 9 instead of 5 ms per 256 MiB.  128 workgroups of plain
+// 16-byte loads and stores reach 54 GB/s either way (host -> device by the copy engine is 55 GB/s in both states and stays).
+// SA_AMD_NO_KERNEL_D2H=1: the copy engine (A/B).
+struct __attribute__((packed, aligned(4))) D2hWords4 { uint32_t x, y, z, w; };
+__global__ __launch_bounds__(256) void k_copy_to_host(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, size_t words)
+{
+    // (src is only 4-byte aligned -- the array without its sentinel starts one element in --, the stage is 16-byte aligned)
+    const size_t n16 = words / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const D2hWords4 q = *(const D2hWords4 *)(src + 4 * i);
+        *(uint4 *)(dst + 4 * i) = make_uint4(q.x, q.y, q.z, q.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (words & 3)) dst[n16 * 4 + threadIdx.x] = src[n16 * 4 + threadIdx.x];
+}
+static bool kernel_d2h() { return env_int("SA_AMD_NO_KERNEL_D2H", 0, 0, 1) == 0; }
+static int copy_to_stage(void *stage, const void *dsrc, size_t bytes, hipStream_t st, int blocks)
+{
+    if (kernel_d2h() && (bytes & 3) == 0 && (((uintptr_t)dsrc) & 3) == 0 && bytes >= 4) {
+        hipLaunchKernelGGL(k_copy_to_host, dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)dsrc, (uint32_t *)stage, bytes / 4);
+        return hip_status(hipGetLastError());
+    }
+    return hip_status(hipMemcpyAsync(stage, dsrc, bytes, hipMemcpyDeviceToHost, st));
+}
+constexpr int D2H_BLOCKS = 128;             // workgroups of a download's copy kernel
+
 // The calling thread keeps up to STAGE_COUNT device -> stage copies enqueued; when a chunk's event has fired, the chunk
 // is cut into `copy_threads` page-aligned slices that the persistent helpers of the device's NUMA node (and the caller
 // itself) move into the caller's buffer, then the stage takes the chunk STAGE_COUNT further on.  The DMA of the
@@ -55,7 +84,7 @@ static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipSt
     const size_t nchunk = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
     auto len = [&](size_t c) { return c + 1 < nchunk ? STAGE_BYTES : bytes - c * STAGE_BYTES; };
     auto issue = [&](size_t c) {
-        int r = hip_status(hipMemcpyAsync(stage[c % STAGE_COUNT].p, (const char *)dsrc + c * STAGE_BYTES, len(c), hipMemcpyDeviceToHost, st));
+        int r = copy_to_stage(stage[c % STAGE_COUNT].p, (const char *)dsrc + c * STAGE_BYTES, len(c), st, D2H_BLOCKS);
         if (r == SA_AMD_OK) r = hip_status(hipEventRecord(ev[c % STAGE_COUNT], st));
         return r;
     };
@@ -63,8 +92,11 @@ static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipSt
         HelperPool &hp = helper_pool(node);
         const int T = copy_threads < 1 ? 1 : copy_threads;
         for (size_t c = 0; c < nchunk && c < (size_t)STAGE_COUNT && rc == SA_AMD_OK; ++c) rc = issue(c);
+        const bool trace = env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 3;
+        double t_wait = 0, t_copy = 0, t_mark = trace ? wall_ms() : 0;
         for (size_t c = 0; c < nchunk && rc == SA_AMD_OK; ++c) {
             rc = hip_status(hipEventSynchronize(ev[c % STAGE_COUNT]));
+            if (trace) { const double now = wall_ms(); t_wait += now - t_mark; t_mark = now; }
             if (rc != SA_AMD_OK) break;
             const size_t L = len(c), per = (((L + T - 1) / T) + 4095) & ~(size_t)4095;     // whole pages per slice, the last one takes the rest
             char *dst = (char *)dst_host + c * STAGE_BYTES;
@@ -73,8 +105,11 @@ static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipSt
                 const size_t b = (size_t)t * per, e = b + per < L ? b + per : L;
                 if (b < e) memcpy(dst + b, src + b, e - b);
             });
+            if (trace) { const double now = wall_ms(); t_copy += now - t_mark; t_mark = now; }
             if (c + STAGE_COUNT < nchunk) rc = issue(c + STAGE_COUNT);       // the stage is free again
         }
+        if (trace) fprintf(stderr, "suffix_array_amd: staged download of %zu bytes: %.2f ms waiting for the DMA, %.2f ms copying out of the stage (%d slices, %d helpers)\n",
+                           bytes, t_wait, t_copy, T, hp.helpers());
     }
     for (int i = 0; i < STAGE_COUNT; ++i) {
         if (ev[i]) (void)hipEventDestroy(ev[i]);
@@ -156,6 +191,9 @@ struct EarlyPull {
             const size_t c = issued.fetch_add(1);
             if (c >= max_chunks || stop.load()) break;      // (a chunk taken but not copied: the caller downloads it with the rest)
             const size_t b = c * chunk, len = b + chunk < bytes ? chunk : bytes - b;
+            // (the copy engine here, whatever state it is in: copy kernels beside the last rounds of the build cost C3 more build time
+            // than they saved -- build 60.9 against 50.7 ms on a stream like the build's, 55.6 with 32 workgroups on a stream of the
+            // lowest priority, end to end 75.4 against 70.0 with the engine at 55 GB/s and 75.2 against 74.0 with it at 29.5)
             r = hip_status(hipMemcpyAsync(stage.p, src + b, len, hipMemcpyDeviceToHost, cst));
             if (r == SA_AMD_OK) r = hip_status(hipEventRecord(ev, cst));
             if (r == SA_AMD_OK) r = hip_status(hipEventSynchronize(ev));

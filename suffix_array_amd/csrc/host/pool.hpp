@@ -30,7 +30,7 @@ class ResourcePool {
     std::vector<PinBlock> pinned_;
     size_t retained_ = 0, pinned_retained_ = 0;
     uint64_t clock_ = 0;
-    std::map<int, std::deque<size_t>> recent_;     // per device: what its last eight builds asked for
+    std::map<int, std::deque<std::pair<double, size_t>>> recent_;     // per device: (time, bytes) of what its builds of the last SA_AMD_CACHE_IDLE_MS asked for
 
 public:
     // a free block of `device` with at least `need` bytes (the smallest such), else a new allocation
@@ -39,9 +39,14 @@ public:
         trim_idle();
         {
             std::lock_guard<std::mutex> lk(mu_);
-            std::deque<size_t> &rq = recent_[device];
-            rq.push_back(need);
-            if (rq.size() > 8) rq.pop_front();
+            // What the device's builds of the last SA_AMD_CACHE_IDLE_MS asked for (not "the last eight": a dozen 1 MiB texts between
+            // two 256 MiB ones dropped the large block, and the block allocated in its place downloads at half the rate -- see
+            // host_path.hpp, k_copy_to_host; a block nobody has asked for in that time goes back anyway, trim_idle)
+            std::deque<std::pair<double, size_t>> &rq = recent_[device];
+            const double now = now_ms(), keep_ms = idle_ms();
+            while (!rq.empty() && (now - rq.front().first > keep_ms || rq.size() >= 256)) rq.pop_front();
+            if (!rq.empty() && rq.back().second == need) rq.back().first = now;      // (a run of equal requests is one entry)
+            else rq.push_back(std::make_pair(now, need));
             int best = -1;
             for (int i = 0; i < (int)blocks_.size(); ++i)
                 if (blocks_[i].device == device && blocks_[i].bytes >= need && (best < 0 || blocks_[i].bytes < blocks_[best].bytes)) best = i;
@@ -110,9 +115,10 @@ public:
     }
     // blocks nobody has asked for in SA_AMD_CACHE_IDLE_MS go back to the device (checked by whoever uses the pool next: there is no
     // background thread -- a process that never calls again keeps its last blocks until sa_amd_release_cache or exit)
+    static double idle_ms() { return (double)env_int("SA_AMD_CACHE_IDLE_MS", 10000, 0, (int64_t)1 << 40); }
     void trim_idle()
     {
-        const double idle_ms = (double)env_int("SA_AMD_CACHE_IDLE_MS", 10000, 0, (int64_t)1 << 40);
+        const double idle_ms = ResourcePool::idle_ms();
         if (idle_ms <= 0) return;
         const double now = now_ms();
         std::vector<DevBlock> drop;
@@ -132,7 +138,7 @@ public:
     {
         size_t big = 0;
         auto it = recent_.find(device);
-        if (it != recent_.end()) for (size_t v : it->second) big = v > big ? v : big;
+        if (it != recent_.end()) for (const auto &v : it->second) big = v.second > big ? v.second : big;
         size_t lim = 2 * (big + (big / 8 < ((size_t)1 << 30) ? big / 8 : ((size_t)1 << 30))) + ((size_t)256 << 20);      // (two blocks with acquire()'s slack)
         if (lim < ((size_t)256 << 20)) lim = (size_t)256 << 20;
         const size_t cap = cache_limit();

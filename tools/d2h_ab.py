@@ -1,0 +1,25 @@
+"""End-to-end A/B of the download path in the two states of the copy engine: python tools/d2h_ab.py"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import suffix_array_amd as sa
+from suffix_array_amd import corpus
+def run(tag, t, reps=5):
+    out = np.zeros(t.size + 1, dtype=np.uint32); sa.saca(t, out)
+    best = None
+    for _ in range(reps):
+        sa.saca(t, out); ht = sa.last_host_timing()
+        if best is None or ht["total"] < best["total"]: best = ht
+    print(f"{tag:60s}", {k: round(v, 2) for k, v in best.items() if k in ("h2d", "build", "d2h", "total", "early_fraction")}, flush=True)
+u = corpus.uniform(64 << 20, 3); c3 = corpus.workload("c3_english_256m"); small = corpus.uniform(1 << 20, 5)
+for env in ({}, {"SA_AMD_NO_KERNEL_D2H": "1"}):
+    os.environ.pop("SA_AMD_NO_KERNEL_D2H", None); os.environ.update(env)
+    run(f"64 MiB random, first blocks of the process {env}", u)
+    run(f"C3 {env}", c3)
+for _ in range(12):                        # a dozen small builds: the pool's retention limit follows the recent needs down, the
+    run("1 MiB random", small, 1)          # large blocks go back, and what follows is allocated after a free
+for env in ({}, {"SA_AMD_NO_KERNEL_D2H": "1"}, {}):
+    os.environ.pop("SA_AMD_NO_KERNEL_D2H", None); os.environ.update(env)
+    run(f"64 MiB random, after the pool let its blocks go {env}", u)
+    run(f"C3, after the pool let its blocks go {env}", c3)
