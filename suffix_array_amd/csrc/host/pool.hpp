@@ -5,7 +5,7 @@
 // eight builds asked for (two workers of a batch alternate on two blocks), never more than SA_AMD_CACHE_MAX_BYTES (default
 // 128 GiB of a device's 288 GB: one 1 GiB text is a 58 GiB block) -- a process that indexed one 1 GiB text and goes on with
 // 64 MiB ones gives the 58 GiB back after eight of them instead of holding them for its lifetime -- and blocks that have not
-// been used for SA_AMD_CACHE_IDLE_MS (default 10 s) are freed by the next call that touches the pool.
+// been used for SA_AMD_CACHE_IDLE_MS (default 60 s: a block of 14 GiB costs half a second of hipMalloc to get back, and the copy engine reads a re-allocated block at half rate, host_path.hpp) are freed by the next call that touches the pool.
 // sa_amd_release_cache() empties it.  Pinned blocks remember the NUMA node they were first touched on (helpers.hpp).
 #pragma once
 #include "helpers.hpp"
@@ -115,7 +115,7 @@ public:
     }
     // blocks nobody has asked for in SA_AMD_CACHE_IDLE_MS go back to the device (checked by whoever uses the pool next: there is no
     // background thread -- a process that never calls again keeps its last blocks until sa_amd_release_cache or exit)
-    static double idle_ms() { return (double)env_int("SA_AMD_CACHE_IDLE_MS", 10000, 0, (int64_t)1 << 40); }
+    static double idle_ms() { return (double)env_int("SA_AMD_CACHE_IDLE_MS", 60000, 0, (int64_t)1 << 40); }
     void trim_idle()
     {
         const double idle_ms = ResourcePool::idle_ms();
