@@ -3,7 +3,7 @@
 #         command on that workload -> <tag>_<workload>_kernel_stats.csv, so that every roofline fraction of the bench line can be
 #         reproduced from profiles/; PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) on the headline workload -> traffic.json;
 #         the default `python bench.py` line (headline + configs + batch_api + cpu_baseline) and the two-rank rehearsal
-# part 2: timelines, adversarial families, host path (early download off / on), small / mid-size latency, next-row timings, A/B knobs
+# part 2: timelines, adversarial families, host path (early download off / on, copy engine probes), small / mid-size latency, next-row timings, A/B knobs
 # everything lands in gpurun_out/<tag>/, to be copied into profiles/ by tools/copy_evidence.sh
 set -e
 TAG=${1:-r04}
@@ -63,6 +63,13 @@ echo "adversarial done"
 timeout -k 10 300 python tools/small_latency.py > $O/small_latency.txt 2>&1
 timeout -k 10 300 python tools/midsize_timing.py > $O/midsize_timing.txt 2>&1
 ( for sz in 131072 1048576 4194304; do SA_AMD_VERBOSE=3 timeout -k 10 60 python tools/mid_build.py english_corpus $sz 8 2>&1 | grep -E "best|read-backs" | cut -c1-120 | uniq; done ) >> $O/midsize_timing.txt 2>&1
+timeout -k 10 300 python tools/midsize_knobs.py - SA_AMD_NO_FLAT_RULE=1 SA_AMD_NO_POSTED_READBACK=1 SA_AMD_COUNT_NEXT_MIN_N=0,SA_AMD_COUNT_NEXT_BELOW_N=0 > $O/midsize_knobs.txt 2>&1
+# the copy engine's two rates, the read-back's two forms (plain HIP programs), and the library's download in both states
+mkdir -p tools/bin
+for pgm in readback_probe realloc_dma_probe; do hipcc --offload-arch=gfx950 -O2 -o tools/bin/$pgm tools/$pgm.hip > /dev/null 2>&1; done
+timeout -k 10 100 tools/bin/readback_probe > $O/readback_probe.txt 2>&1
+( for v in 1 2 5; do echo "== variant $v"; timeout -k 10 60 tools/bin/realloc_dma_probe $v; done ) > $O/realloc_dma_probe.txt 2>&1
+timeout -k 10 400 python tools/d2h_ab.py 2>&1 | grep -E "MiB random, |C3|copy engine out" > $O/d2h_ab.txt
 timeout -k 10 300 python tools/extras_bench.py > $O/extras.txt 2>&1
 timeout -k 10 300 python tools/search_bench.py > $O/search_throughput.txt 2>&1
 timeout -k 10 300 python tools/ab_env.py c3_english_256m - SA_AMD_NO_DEFER=1 SA_AMD_ONESWEEP_FLAGS=1 SA_AMD_NO_REPEAT_PROBE=1 SA_AMD_FORCE_DENSE=1 SA_AMD_CHASE=1 SA_AMD_CHASE=3 SA_AMD_CHASE=15 SA_AMD_SCATTER_LEVELS=1 SA_AMD_BINNED_MIN=4194304 SA_AMD_GROUP_CAP=512 SA_AMD_NO_GRAM_KEYS=1 > $O/ab_knobs_c3.txt 2>&1
