@@ -42,16 +42,17 @@ constexpr size_t STAGE_BYTES = (size_t)16 << 20;
 constexpr int STAGE_COUNT = 3;
 
 // Device -> pinned stage by the copy engine, or by a copy KERNEL that stores into the mapped block.  Measured
-// (tools/realloc_dma_probe.hip, profiles/r04_realloc_dma_probe.txt): hipMemcpyAsync out of the first device block a process
-// allocates runs at 55 GB/s, out of a block allocated after a large one was freed at 29.5 GB/s -- as long as the block lives,
-// and sometimes from a process's start, depending on what the process before left behind.  A pool that trims idle blocks
-// (pool.hpp), a caller whose texts grow: the download of the next build is then 9 instead of 5 ms per 256 MiB.  128 workgroups
-// of plain 16-byte loads and stores reach 54 GB/s out of either kind of block (host -> device by the engine is 55 GB/s in both
-// states and stays) -- but they are workgroups: a batch whose downloads run beside the next text's build loses 8 % to them
-// (8 x 512 MiB: 390-400 against 360 ms).  So the download MEASURES: the first two chunks of a device block's first download go
-// through the engine and are timed; a block that delivers them at less than 40 GB/s is marked (DevBlock::engine_slow, kept
-// with the block in the pool) and is downloaded by the kernel from then on.
+// (tools/realloc_dma_probe.hip, profiles/r04_realloc_dma_probe.txt): hipMemcpyAsync device -> host runs at 55 GB/s in a process
+// until the process frees a large device block; from then on at 29.5 GB/s out of EVERY block, old or new, however allocated --
+// and some processes start that way, depending on what the process before left behind; now and then it recovers.  A pool that
+// trims idle blocks (pool.hpp), a caller whose texts grow: the download of the next build is then 9 instead of 5 ms per 256 MiB.
+// 128 workgroups of plain 16-byte loads and stores reach 54 GB/s in either state (host -> device by the engine is 55 GB/s in both
+// and stays) -- but they are workgroups: a batch whose downloads run beside the next text's build loses 8 % to them (8 x 512 MiB:
+// 390-400 against 360 ms).  So every download MEASURES: one of its chunks goes through the engine between two events and is timed
+// by the device's clock; below 40 GB/s the rest of the download (and the next one, except for its own timed chunk) is the
+// kernel's, at 40 GB/s or more the engine's.  What the state was last is kept per device (g_engine_slow).
 // SA_AMD_NO_KERNEL_D2H=1: always the engine; SA_AMD_KERNEL_D2H_ALWAYS=1: always the kernel (tests, A/B).
+static std::atomic<int> g_engine_slow[64];         // per device: 1 = the copy engine was last seen at half rate
 struct __attribute__((packed, aligned(4))) D2hWords4 { uint32_t x, y, z, w; };
 __global__ __launch_bounds__(256) void k_copy_to_host(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, size_t words)
 {
@@ -78,22 +79,32 @@ constexpr int D2H_BLOCKS = 128;             // workgroups of a download's copy k
 // is cut into `copy_threads` page-aligned slices that the persistent helpers of the device's NUMA node (and the caller
 // itself) move into the caller's buffer, then the stage takes the chunk STAGE_COUNT further on.  The DMA of the
 // following chunks runs meanwhile.  No thread is created or joined per call (helpers.hpp).
-static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipStream_t st, int copy_threads, int device, int node,
-                           int *engine_slow = nullptr)      // in/out: what is known about the copy engine and this device block (-1: nothing yet)
+static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipStream_t st, int copy_threads, int device, int node)
 {
     PinBlock stage[STAGE_COUNT];
     hipEvent_t ev[STAGE_COUNT] = { nullptr, nullptr, nullptr };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = SA_AMD_OK;
     for (int i = 0; i < STAGE_COUNT && rc == SA_AMD_OK; ++i) rc = pool().pinned(STAGE_BYTES, node, device, &stage[i]);
     for (int i = 0; i < STAGE_COUNT && rc == SA_AMD_OK; ++i) rc = hip_status(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
     const size_t nchunk = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
     auto len = [&](size_t c) { return c + 1 < nchunk ? STAGE_BYTES : bytes - c * STAGE_BYTES; };
     const bool always = env_int("SA_AMD_KERNEL_D2H_ALWAYS", 0, 0, 1) != 0;
-    bool by_kernel = kernel_d2h() && (always || (engine_slow && *engine_slow == 1));
-    const bool probing = kernel_d2h() && !always && engine_slow && *engine_slow < 0 && nchunk >= 4;
+    std::atomic<int> &state = g_engine_slow[(unsigned)device & 63u];
+    bool by_kernel = kernel_d2h() && (always || state.load(std::memory_order_relaxed) == 1);
+    // the timed chunk (a whole one): the first when the engine does the download anyway, the second when the kernel starts it
+    const bool timed = kernel_d2h() && !always && nchunk >= 3;
+    const size_t timed_chunk = by_kernel ? 1 : 0;
+    if (timed && rc == SA_AMD_OK) rc = hip_status(hipEventCreate(&e0));
+    if (timed && rc == SA_AMD_OK) rc = hip_status(hipEventCreate(&e1));
     auto issue = [&](size_t c) {
-        int r = by_kernel ? copy_to_stage(stage[c % STAGE_COUNT].p, (const char *)dsrc + c * STAGE_BYTES, len(c), st, D2H_BLOCKS)
-                          : hip_status(hipMemcpyAsync(stage[c % STAGE_COUNT].p, (const char *)dsrc + c * STAGE_BYTES, len(c), hipMemcpyDeviceToHost, st));
+        const bool probe = timed && c == timed_chunk;
+        int r = SA_AMD_OK;
+        if (probe) r = hip_status(hipEventRecord(e0, st));
+        if (r == SA_AMD_OK)
+            r = (by_kernel && !probe) ? copy_to_stage(stage[c % STAGE_COUNT].p, (const char *)dsrc + c * STAGE_BYTES, len(c), st, D2H_BLOCKS)
+                                      : hip_status(hipMemcpyAsync(stage[c % STAGE_COUNT].p, (const char *)dsrc + c * STAGE_BYTES, len(c), hipMemcpyDeviceToHost, st));
+        if (probe && r == SA_AMD_OK) r = hip_status(hipEventRecord(e1, st));
         if (r == SA_AMD_OK) r = hip_status(hipEventRecord(ev[c % STAGE_COUNT], st));
         return r;
     };
@@ -102,36 +113,22 @@ static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipSt
         const int T = copy_threads < 1 ? 1 : copy_threads;
         const bool trace = env_int("SA_AMD_VERBOSE", 0, 0, 9) >= 3;
         double t_wait = 0, t_copy = 0, t_mark = trace ? wall_ms() : 0;
-        size_t c0 = 0;
-        if (probing) {
-            // the stream is idle (the build is over): two chunks through the engine, nothing else of this call in flight, timed by
-            // the device's clock between two events (the host's clock would count the wake-up of a thread on a busy host)
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            rc = hip_status(hipEventCreate(&e0));
-            if (rc == SA_AMD_OK) rc = hip_status(hipEventCreate(&e1));
-            if (rc == SA_AMD_OK) rc = hip_status(hipEventRecord(e0, st));
-            if (rc == SA_AMD_OK) rc = issue(0);
-            if (rc == SA_AMD_OK) rc = issue(1);
-            if (rc == SA_AMD_OK) rc = hip_status(hipEventRecord(e1, st));
-            if (rc == SA_AMD_OK) rc = hip_status(hipEventSynchronize(e1));
-            float ms = 0.0f;
-            if (rc == SA_AMD_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.0f) {
-                const double gbs = (double)(2 * STAGE_BYTES) / (double)ms * 1e-6;
-                *engine_slow = gbs < 40.0 ? 1 : 0;
-                by_kernel = *engine_slow == 1;
-                if (trace) fprintf(stderr, "suffix_array_amd: copy engine out of this device block: %.1f GB/s -> downloads by %s\n", gbs, by_kernel ? "copy kernel" : "the engine");
-            } else (void)hipGetLastError();
-            if (e0) (void)hipEventDestroy(e0);
-            if (e1) (void)hipEventDestroy(e1);
-            if (rc == SA_AMD_OK && 2 < nchunk) rc = issue(2);
-            if (trace) t_mark = wall_ms();
-        } else {
-            for (size_t c = 0; c < nchunk && c < (size_t)STAGE_COUNT && rc == SA_AMD_OK; ++c) rc = issue(c);
-        }
-        for (size_t c = c0; c < nchunk && rc == SA_AMD_OK; ++c) {
+        const bool started_by_kernel = by_kernel;
+        for (size_t c = 0; c < nchunk && c < (size_t)STAGE_COUNT && rc == SA_AMD_OK; ++c) rc = issue(c);
+        for (size_t c = 0; c < nchunk && rc == SA_AMD_OK; ++c) {
             rc = hip_status(hipEventSynchronize(ev[c % STAGE_COUNT]));
             if (trace) { const double now = wall_ms(); t_wait += now - t_mark; t_mark = now; }
             if (rc != SA_AMD_OK) break;
+            if (timed && c == timed_chunk) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.0f) {
+                    const double gbs = (double)STAGE_BYTES / (double)ms * 1e-6;
+                    const int slow = gbs < 40.0 ? 1 : 0;
+                    state.store(slow, std::memory_order_relaxed);
+                    by_kernel = slow == 1;                        // (the chunks not yet issued follow the measurement)
+                    if (trace) fprintf(stderr, "suffix_array_amd: the copy engine moved a chunk at %.1f GB/s -> the download goes on by %s\n", gbs, by_kernel ? "copy kernel" : "the engine");
+                } else (void)hipGetLastError();
+            }
             const size_t L = len(c), per = (((L + T - 1) / T) + 4095) & ~(size_t)4095;     // whole pages per slice, the last one takes the rest
             char *dst = (char *)dst_host + c * STAGE_BYTES;
             const char *src = (const char *)stage[c % STAGE_COUNT].p;
@@ -142,9 +139,11 @@ static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipSt
             if (trace) { const double now = wall_ms(); t_copy += now - t_mark; t_mark = now; }
             if (c + STAGE_COUNT < nchunk) rc = issue(c + STAGE_COUNT);       // the stage is free again
         }
-        if (trace) fprintf(stderr, "suffix_array_amd: staged download of %zu bytes by %s: %.2f ms waiting for the chunks, %.2f ms copying out of the stage (%d slices, %d helpers)\n",
-                           bytes, by_kernel ? "copy kernel" : "the copy engine", t_wait, t_copy, T, hp.helpers());
+        if (trace) fprintf(stderr, "suffix_array_amd: staged download of %zu bytes (started by %s, ended by %s): %.2f ms waiting for the chunks, %.2f ms copying out of the stage (%d slices, %d helpers)\n",
+                           bytes, started_by_kernel ? "copy kernel" : "the copy engine", by_kernel ? "copy kernel" : "the copy engine", t_wait, t_copy, T, hp.helpers());
     }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     for (int i = 0; i < STAGE_COUNT; ++i) {
         if (ev[i]) (void)hipEventDestroy(ev[i]);
         pool().release_pinned(stage[i]);
@@ -547,7 +546,7 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
             if (rc != SA_AMD_OK || from >= to) return;
             if (staged) {
                 tm.staged = copy_threads;
-                rc = staged_download((char *)SA_host + from, (const char *)src + from, to - from, st, copy_threads, cur, node, &blk.engine_slow);
+                rc = staged_download((char *)SA_host + from, (const char *)src + from, to - from, st, copy_threads, cur, node);
             } else {
                 rc = hip_status(hipMemcpyAsync((char *)SA_host + from, (const char *)src + from, to - from, hipMemcpyDeviceToHost, st));
                 if (rc == SA_AMD_OK) rc = hip_status(hipStreamSynchronize(st));      // (the turn ends when the copy has)

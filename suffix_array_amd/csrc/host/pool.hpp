@@ -20,7 +20,7 @@ static size_t cache_limit()
 }
 
 // ---- pool of device blocks, streams and pinned staging buffers (process-wide, mutex-protected) ----
-struct DevBlock { int device = -1; void *p = nullptr; size_t bytes = 0; uint64_t stamp = 0; double idle_since = 0; int engine_slow = -1; };      // stamp: order in which blocks were handed back; idle_since: when (ms); engine_slow: does the copy engine read this block at half rate (-1: not measured yet; host_path.hpp)
+struct DevBlock { int device = -1; void *p = nullptr; size_t bytes = 0; uint64_t stamp = 0; double idle_since = 0; };      // stamp: order in which blocks were handed back; idle_since: when (ms)
 struct PinBlock { void *p = nullptr; size_t bytes = 0; int node = -1; uint64_t stamp = 0; };      // node: NUMA node its pages were first touched on (-1: wherever); stamp: when it was last handed back
 
 class ResourcePool {

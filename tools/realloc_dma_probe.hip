@@ -77,6 +77,66 @@ int main(int argc, char **argv)
         for (int blocks : { 16, 64, 256, 1024 }) if (measure_kernel("v5: kernel copy, block after free", b, st, stage, blocks)) return 1;
         return 0;
     }
+    if (variant == 6) {            // in the slow state: do other ways of allocating device memory give blocks the engine reads at full rate?
+        CK(hipStreamSynchronize(st)); CK(hipFree(a));
+        char *b; CK(hipMalloc(&b, big)); CK(hipMemsetAsync(b, 3, big, st));
+        if (measure("v6: hipMalloc after free", b, 0, st, stage)) return 1;
+        {
+            void *m = nullptr;
+            if (hipMallocAsync(&m, big, st) == hipSuccess) {
+                CK(hipMemsetAsync(m, 3, big, st));
+                if (measure("v6: hipMallocAsync (stream-ordered pool)", (char *)m, 0, st, stage)) return 1;
+                CK(hipFreeAsync(m, st)); CK(hipStreamSynchronize(st));
+            } else { (void)hipGetLastError(); printf("v6: hipMallocAsync not available\n"); }
+        }
+        {
+            void *m = nullptr;
+            if (hipExtMallocWithFlags(&m, big, hipDeviceMallocUncached) == hipSuccess) {
+                CK(hipMemsetAsync(m, 3, big, st));
+                if (measure("v6: hipExtMallocWithFlags(uncached)", (char *)m, 0, st, stage)) return 1;
+                CK(hipFree(m));
+            } else { (void)hipGetLastError(); printf("v6: hipExtMallocWithFlags(uncached) failed\n"); }
+        }
+        {
+            hipMemAllocationProp prop = {};
+            prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+            size_t gran = 0;
+            if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran) {
+                const size_t sz = (big + gran - 1) / gran * gran;
+                hipMemGenericAllocationHandle_t h;
+                void *va = nullptr;
+                if (hipMemCreate(&h, sz, &prop, 0) == hipSuccess && hipMemAddressReserve(&va, sz, gran, nullptr, 0) == hipSuccess && hipMemMap(va, sz, 0, h, 0) == hipSuccess) {
+                    hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+                    CK(hipMemSetAccess(va, sz, &acc, 1));
+                    CK(hipMemsetAsync(va, 3, big, st));
+                    printf("v6: virtual memory API, granularity %zu\n", gran);
+                    if (measure("v6: hipMemCreate + hipMemMap", (char *)va, 0, st, stage)) return 1;
+                } else { (void)hipGetLastError(); printf("v6: virtual memory API failed\n"); }
+            } else { (void)hipGetLastError(); printf("v6: no allocation granularity\n"); }
+        }
+        // and many smaller blocks instead of one large one
+        {
+            char *parts[16]; const size_t psz = (size_t)256 << 20;
+            for (int i = 0; i < 16; ++i) { CK(hipMalloc(&parts[i], psz)); CK(hipMemsetAsync(parts[i], 1, psz, st)); }
+            if (measure("v6: a 256 MiB hipMalloc block", parts[7], 0, st, stage)) return 1;
+        }
+        return 0;
+    }
+    if (variant == 7) {            // is the rate a property of the block or of the process?
+        char *b; CK(hipMalloc(&b, big)); CK(hipMemsetAsync(b, 3, big, st));
+        if (measure("v7: second block, the first alive", b, 0, st, stage)) return 1;
+        CK(hipStreamSynchronize(st)); CK(hipFree(b));
+        if (measure("v7: the FIRST block after the second was freed", a, 0, st, stage)) return 1;
+        char *c; CK(hipMalloc(&c, big)); CK(hipMemsetAsync(c, 3, big, st));
+        if (measure("v7: a third block", c, 0, st, stage)) return 1;
+        if (measure("v7: the first block again", a, 0, st, stage)) return 1;
+        CK(hipStreamSynchronize(st)); CK(hipFree(c));
+        if (measure("v7: the first block after the third was freed", a, 0, st, stage)) return 1;
+        char *d; CK(hipMalloc(&d, big)); CK(hipMemsetAsync(d, 3, big, st));
+        if (measure("v7: a fourth block", d, 0, st, stage)) return 1;
+        if (measure("v7: the first block again", a, 0, st, stage)) return 1;
+        return 0;
+    }
     if (variant == 4) {            // new pinned stage blocks after the free: is it the host side?
         CK(hipStreamSynchronize(st)); CK(hipFree(a));
         char *b; CK(hipMalloc(&b, big)); CK(hipMemsetAsync(b, 3, big, st));
