@@ -162,6 +162,7 @@ constexpr int GS_ITEMS = 8;
 constexpr int GS_TILE = GS_THREADS * GS_ITEMS;
 constexpr int GS_WORDS = GS_TILE / 64;
 constexpr int GS_CAP = 1024;        // upper bound of the run-time group-size cap
+constexpr int GS_NETWORK_MIN = 64;  // a tile that owns a group of more members than this orders its groups by a bitonic network, not by counting
 constexpr int GB_LIST_MIN = 256;    // k_group_sort_big: a group that runs on beyond its tile is listed when it has this many members inside it
 
 template <int MODE>
@@ -261,23 +262,69 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
     __shared__ uint32_t s_rng[CHASE ? 2 : 1][CHASE ? GS_TILE : 1];
     int start_[GS_ITEMS];
     uint32_t owned_mask = 0;
+    // end of the group of tile position jl = next group start after jl (GS_TILE: the tile ends with the group; -1: it goes on)
+    auto group_end = [&](int jl) -> int {
+        const int wi = jl >> 6;
+        const uint64_t wbits = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
+        return wbits ? wi * 64 + __builtin_ctzll(wbits) : s_nextH[wi + 1];
+    };
+    // A tile with a LARGE owned group: counting costs a wave its largest group per member -- 8 members x 1 000 steps for a group of
+    // a thousand, 100 us on the one compute unit that has the tile, which is what a launch over a few hundred tiles (a text of a
+    // few MiB) then takes.  Such a tile sorts (first place of the member's group or, not owned, its own place | key | place)
+    // composites through a bitonic network instead: 66 steps of 1 024 exchanges, 5 us whatever the groups -- every owned group
+    // comes out ordered in its own places, everything else stays where it is.  (Keys of up to 42 bits: 11 + 42 + 11.)
+    bool by_network = false;
+    uint16_t *s_place = (uint16_t *)s_val;                       // (s_val is written only behind the barrier that follows the ranks)
+    if (!CHASE && K.kb <= 42) {
+        bool large = false;
+#pragma unroll
+        for (int r = 0; r < GS_ITEMS; ++r) {
+            const int jl = r * GS_THREADS + t;
+            const int start = jl - (int)(u[r] - g[r]), end = group_end(jl);
+            large |= base + jl < m && start >= 0 && end >= 0 && end - start <= cap && end - start > GS_NETWORK_MIN;
+        }
+        by_network = __syncthreads_or(large) != 0;
+        if (by_network) {
+#pragma unroll
+            for (int r = 0; r < GS_ITEMS; ++r) {
+                const int jl = r * GS_THREADS + t;
+                const int start = jl - (int)(u[r] - g[r]), end = group_end(jl);
+                const bool owned = base + jl < m && start >= 0 && end >= 0 && end - start <= cap;
+                s_key[jl] = ((uint64_t)(owned ? start : jl) << 53) | (owned ? key[r] << 11 : 0ull) | (uint64_t)jl;
+            }
+            __syncthreads();
+            for (int k = 2; k <= GS_TILE; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+                    for (int x = t; x < GS_TILE / 2; x += GS_THREADS) {
+                        const int lo = ((x & ~(j - 1)) << 1) | (x & (j - 1)), hi = lo | j;
+                        const uint64_t a = s_key[lo], c = s_key[hi];
+                        if ((a > c) == ((lo & k) == 0)) { s_key[lo] = c; s_key[hi] = a; }
+                    }
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < GS_ITEMS; ++r) {
+                const int p = r * GS_THREADS + t;
+                s_place[(int)(s_key[p] & 2047u)] = (uint16_t)p;
+            }
+            __syncthreads();
+        }
+    }
 #pragma unroll
     for (int r = 0; r < GS_ITEMS; ++r) {
         const int jl = r * GS_THREADS + t;
         const bool valid = base + jl < m;
         const int start = jl - (int)(u[r] - g[r]);               // negative: the group starts before the tile
-        // end of the group = next group start after jl (GS_TILE: the tile ends with the group)
-        int end;
-        {
-            const int wi = jl >> 6;
-            const uint64_t wbits = (jl & 63) == 63 ? 0ull : (s_head[wi] & (~0ull << ((jl & 63) + 1)));
-            end = wbits ? wi * 64 + __builtin_ctzll(wbits) : s_nextH[wi + 1];
-        }
+        const int end = group_end(jl);
         const bool owned = valid && start >= 0 && end >= 0 && end - start <= cap;
         int rank = 0;
         start_[r] = start;
         uint32_t rng = ((uint32_t)jl << 16) | 1u;                // not owned: stays where it is, never tied
-        if (owned && CHASE && K.kb <= 32) {
+        if (by_network) {
+            rank = owned ? (int)s_place[jl] - start : 0;
+        } else if (owned && CHASE && K.kb <= 32) {
             const uint32_t *k32 = (const uint32_t *)s_key;
             const uint32_t mine = (uint32_t)key[r];
             int lt_a = 0, le_a = 0, lt_b = 0, le_b = 0;               // members before / behind me with a smaller, smaller-or-equal key
