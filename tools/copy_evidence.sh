@@ -8,7 +8,7 @@ for w in c3_iid_256m c4_dna_repeats_1g; do [ -s $O/bench_$w.json ] && grep "^{" 
 [ -s $O/traffic.json ] && cp $O/traffic.json profiles/traffic.json
 [ -s $O/c3_dispatch_sequence.txt ] && cp $O/c3_dispatch_sequence.txt profiles/${TAG}_c3_dispatch_sequence.txt
 for f in $O/round_trace_*.txt; do [ -s $f ] && grep -v "amdgpu.ids" $f > profiles/${TAG}_$(basename $f); done
-for f in adversarial_256m host_path small_latency midsize_timing midsize_knobs readback_probe realloc_dma_probe extras search_throughput ab_knobs_c3 early_download; do
+for f in adversarial_256m host_path small_latency midsize_timing midsize_knobs readback_probe extras search_throughput ab_knobs_c3 early_download; do
   [ -s $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > profiles/${TAG}_$f.txt
 done
 true
