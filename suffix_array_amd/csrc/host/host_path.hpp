@@ -376,12 +376,13 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     const size_t staged_min = (size_t)env_int("SA_AMD_STAGED_MIN_BYTES", (int64_t)64 << 20, 0, (int64_t)1 << 40);
     const bool staged = copy_threads > 0 && out_bytes_all >= staged_min;
     std::atomic<bool> prefault_stop(false);                     // (declared before the handle: the helpers read it until finish())
+    std::atomic<size_t> prefault_next(0);
     HelperPool::Async prefault;
     HelperPool &hp = helper_pool(node);
     struct PrefaultEnd {                                         // (also when something below throws: the helpers hold a pointer to the handle)
-        HelperPool &pool_; HelperPool::Async &h_;
-        ~PrefaultEnd() { pool_.finish(h_); }
-    } prefault_end{ hp, prefault };
+        HelperPool &pool_; HelperPool::Async &h_; std::atomic<size_t> &next_; std::atomic<bool> &stop_;
+        ~PrefaultEnd() { stop_.store(true); next_.store(~(size_t)0 >> 1); pool_.finish(h_); }      // (no unit is started any more)
+    } prefault_end{ hp, prefault, prefault_next, prefault_stop };
     {
         LaneTurn turn(lanes.up, turns);
         rc = hip_status(hipMemcpyAsync(dT, T, (size_t)n, hipMemcpyHostToDevice, st));
@@ -395,10 +396,14 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
         // t, t + T, ...: when the build is done before the whole array is mapped (a 10 ms build of 512 MiB of random bytes against
         // 25-70 ms for the 2 GiB of its array) the helpers stop after the unit they are in and the download starts at once --
         // into the mapped front part at full speed, page-faulting the rest in as it goes, which costs less than waiting for it.
+        // When the build ends first (random bytes: 4.6 ms of build against 20 ms of page mapping for a 1 GiB array), all but a few
+        // helpers stop after the 2 MiB piece they are in -- the download needs them -- and the few go on mapping AHEAD of the
+        // download, which would otherwise fault every page in from its copy threads (SA_AMD_PREFAULT_KEEP, default 3; 0: all stop).
         char *dst = (char *)SA_host;
         const size_t units = (out_bytes_all + STAGE_BYTES - 1) / STAGE_BYTES;
-        const int T = copy_threads;
+        const int keep = (int)env_int("SA_AMD_PREFAULT_KEEP", 3, 0, 32);
         std::atomic<bool> *stop = &prefault_stop;
+        std::atomic<size_t> *next = &prefault_next;
         hp.start(prefault, copy_threads, [=](int t) {
             auto touch = [](uintptr_t from, uintptr_t to) {
                 while (from < to) {
@@ -411,9 +416,13 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
             // (2 MiB at a time inside a unit: the build waits for the piece a helper is in when it ends -- with whole 16 MiB
             // units a 0.8 ms build of a 16 MiB text took 1.5 ms into a fresh buffer)
             constexpr size_t PIECE = (size_t)2 << 20;
-            for (size_t u = (size_t)t; u < units && !stop->load(std::memory_order_relaxed); u += (size_t)T) {
+            auto over = [=]() { return t >= keep && stop->load(std::memory_order_relaxed); };
+            for (;;) {
+                if (over()) break;
+                const size_t u = next->fetch_add(1, std::memory_order_relaxed);      // units in the order the download fills them
+                if (u >= units) break;
                 const size_t ub = u * STAGE_BYTES, ue = ub + STAGE_BYTES < out_bytes_all ? ub + STAGE_BYTES : out_bytes_all;
-                for (size_t b = ub; b < ue && !stop->load(std::memory_order_relaxed); b += PIECE) {
+                for (size_t b = ub; b < ue && !over(); b += PIECE) {
                     const size_t e = b + PIECE < ue ? b + PIECE : ue;
                     const uintptr_t a = (uintptr_t)(dst + b), end = (uintptr_t)(dst + e);
                     // whole pages: one madvise call maps them writable without a trap per page (Linux >= 5.14; contents untouched);
@@ -497,7 +506,7 @@ static int build_host(const uint8_t *T, uint32_t *SA_host, int32_t n, bool with_
     }
     // (usually done by now; otherwise no further unit is started -- SA_AMD_PREFAULT_WAIT=1: every page is mapped first, A/B)
     if (env_int("SA_AMD_PREFAULT_WAIT", 0, 0, 1) == 0) prefault_stop.store(true, std::memory_order_relaxed);
-    hp.finish(prefault);
+    else hp.finish(prefault);                                    // (otherwise joined when the download is over: PrefaultEnd)
     pull.stop.store(true);
     t0 = wall_ms();
     tm.build = t0 - t1;
