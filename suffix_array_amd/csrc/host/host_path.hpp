@@ -92,9 +92,9 @@ static int staged_download(void *dst_host, const void *dsrc, size_t bytes, hipSt
     const bool always = env_int("SA_AMD_KERNEL_D2H_ALWAYS", 0, 0, 1) != 0;
     std::atomic<int> &state = g_engine_slow[(unsigned)device & 63u];
     bool by_kernel = kernel_d2h() && (always || state.load(std::memory_order_relaxed) == 1);
-    // the timed chunk (a whole one): the first when the engine does the download anyway, the second when the kernel starts it
+    // the timed chunk: the second (a whole one; a process's very first copy into a stage block takes milliseconds of set-up)
     const bool timed = kernel_d2h() && !always && nchunk >= 3;
-    const size_t timed_chunk = by_kernel ? 1 : 0;
+    const size_t timed_chunk = 1;
     if (timed && rc == SA_AMD_OK) rc = hip_status(hipEventCreate(&e0));
     if (timed && rc == SA_AMD_OK) rc = hip_status(hipEventCreate(&e1));
     auto issue = [&](size_t c) {
