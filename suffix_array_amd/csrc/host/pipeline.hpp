@@ -219,6 +219,33 @@ __global__ __launch_bounds__(RADIX) void k_os_digit_totals(const uint32_t *__res
     digit_tot[threadIdx.x] = s;
 }
 
+// Short sorts (fewer than SA_AMD_COUNT_NEXT_MIN_N pairs): ONE segment, and the counts of EVERY pass's digit from one read of the
+// keys in front of the first pass -- a digit's totals do not depend on the order the pairs are in, and with one segment the
+// totals are all a pass needs.  (Per pass either a counting kernel of its own, 7 us, or the flush of the in-pass count, more:
+// 1 MiB of random bytes, five passes: 0.26 -> 0.23 ms.)
+constexpr int HA_THREADS = 256;
+template <typename KeyT>
+__global__ __launch_bounds__(HA_THREADS) void k_radix_hist_all(const KeyT *__restrict__ keys, int64_t count, int begin_bit, int end_bit,
+                                                               uint32_t *__restrict__ zone0, int zone_words, int ticket_words)
+{
+    __shared__ uint32_t h[8][RADIX];
+    for (int i = threadIdx.x; i < 8 * RADIX; i += HA_THREADS) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const int np = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;      // (<= 8, host-checked)
+    for (int64_t i = (int64_t)blockIdx.x * HA_THREADS + threadIdx.x; i < count; i += (int64_t)gridDim.x * HA_THREADS) {
+        const uint64_t k = (uint64_t)keys[i];
+        for (int p = 0; p < np; ++p) {
+            const int sh = begin_bit + p * RADIX_BITS, nb = end_bit - sh < RADIX_BITS ? end_bit - sh : RADIX_BITS;
+            atomicAdd(&h[p][(k >> sh) & ((1u << nb) - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < np * RADIX; i += HA_THREADS) {
+        const uint32_t c = (&h[0][0])[i];
+        if (c) atomicAdd(&zone0[(size_t)(i / RADIX) * zone_words + ticket_words + (i % RADIX)], c);      // (one segment: counts[d * 1 + 0])
+    }
+}
+
 template <typename KeyT, int THREADS, int ITEMS, bool SEQ, int RBITS = RADIX_BITS>
 static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt, uint32_t *vals_alt, int64_t count, int begin_bit, int end_bit,
                                const SortScratch &ss, uint32_t *final_vals, hipStream_t st, KeyT **keys_res, uint32_t **vals_res, int *passes,
@@ -232,18 +259,29 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
     static_assert(R <= OS_MAX_RADIX && (RBITS == RADIX_BITS || TILE >= 2 * OS_MIN_TILE), "zones and granule slab are sized for 8-bit digits of 4 Ki-element tiles");
     static_assert(TILE >= OS_MIN_TILE, "the granule slab is sized for tiles of at least OS_MIN_TILE elements");
     constexpr bool K64 = sizeof(KeyT) == 8;
-    const OnesweepGeom g = onesweep_geom(count, TILE);
+    OnesweepGeom g = onesweep_geom(count, TILE);
     auto zone = [&](int i) { return ss.spine + (size_t)i * OS_ZONE; };
     int z = 0;                                    // zone that holds (or will hold) the counts of the coming pass's digit
     bool have_counts = first_counted;
+    const int npass = (int)ceil_div(end_bit - begin_bit, RBITS);
+    // every pass's counts up front (k_radix_hist_all): short sorts of keys that exist as an array, no pass to be skipped
+    const bool upfront = RBITS == RADIX_BITS && !tn.no_upfront_counts && count < tn.count_next_min_n && !may_skip && !text && npass <= 8 && npass >= 2;
+    if (upfront) { g.nseg = 1; g.tiles_per_seg = g.tiles; g.seg_elems = (int64_t)g.tiles * TILE; }
     HIP_TRY(hipMemsetAsync(ss.status, 0, (size_t)g.tiles * R * 8, st));
     {
         // zone 0 holds the producer's counts (first_counted) and stays; everything behind it starts from zero
-        const int npass = (int)ceil_div(end_bit - begin_bit, RBITS);
         int zones = (may_skip ? 2 * npass : npass) + 1;
         if (zones > OS_MAX_ZONES) return SA_AMD_EINTERNAL;
-        const int z0 = first_counted ? 1 : 0;
+        const int z0 = (first_counted && !upfront) ? 1 : 0;      // (up front: the producer counted per segment of another geometry -- counted again)
         HIP_TRY(hipMemsetAsync(zone(z0), 0, (size_t)(zones - z0) * OS_ZONE * 4, st));
+    }
+    if (upfront) {
+        int blocks = (int)ceil_div(count, (int64_t)HA_THREADS * 16);
+        if (blocks > 512) blocks = 512;
+        if (blocks < 1) blocks = 1;
+        PROF(K64 ? KC_UPSWEEP : KC_UPSWEEP32, count, st, hipLaunchKernelGGL((k_radix_hist_all<KeyT>), dim3((unsigned)blocks), dim3(HA_THREADS), 0, st, (const KeyT *)keys_in, count,
+                                                                        begin_bit, end_bit, zone(0), (int)OS_ZONE, (int)OS_TICKETS));
+        have_counts = true;
     }
     KeyT *kin = keys_in, *kout = keys_alt;
     uint32_t *vin = vals_in, *vout = vals_alt;
@@ -286,7 +324,7 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         // more than a counting kernel of its own)
         // (measured, tools/midsize_knobs.py: 1 MiB of random bytes 0.420 -> 0.369 ms, 2 MiB of English 0.902 -> 0.777; the other way
         // round below 400 K pairs -- a launch more per pass -- and from 8 M on)
-        const bool count_next = !last && (RBITS != RADIX_BITS || count >= tn.count_next_min_n || count < tn.count_next_below_n);
+        const bool count_next = !upfront && !last && (RBITS != RADIX_BITS || count >= tn.count_next_min_n || count < tn.count_next_below_n);
         P.hist_next = count_next ? zone(z + 1) + OS_TICKETS : nullptr;
         P.tickets = zone(z + 1);
         P.status = ss.status;
@@ -314,7 +352,7 @@ static int sort_pairs_onesweep(KeyT *keys_in, uint32_t *vals_in, KeyT *keys_alt,
         vout = free_v;
         ++*passes;
         ++z;
-        have_counts = count_next;
+        have_counts = count_next || upfront;
     }
     *keys_res = kin; *vals_res = vin;
     return SA_AMD_OK;

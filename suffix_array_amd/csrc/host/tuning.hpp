@@ -76,8 +76,10 @@ struct Tuning {
     int onesweep64_shape = 0;        // SA_AMD_ONESWEEP64_SHAPE / SA_AMD_ONESWEEP32_SHAPE: tile shape of the single-pass scatter (host/pipeline.hpp,
     int onesweep32_shape = 0;        //   os_shapes64 / os_shapes32; out of range = default)
     bool no_unary_shortcut = false;  // SA_AMD_NO_UNARY_SHORTCUT: a text of one byte value goes through the sort and the rounds like any other (214 ms at 256 MiB instead of 0.3)
-    int64_t count_next_min_n = (int64_t)1 << 23;    // SA_AMD_COUNT_NEXT_MIN_N / SA_AMD_COUNT_NEXT_BELOW_N: radix sorts of [below_n, min_n) pairs count every digit in a
-    int64_t count_next_below_n = 393216;            //   kernel of its own instead of inside the pass before (0 / 0: never)
+    int64_t count_next_min_n = 20000000;            // SA_AMD_COUNT_NEXT_MIN_N: radix sorts of fewer pairs do not count the next digit inside a pass -- all digits in front of the
+                                                    //   first pass (k_radix_hist_all) or, where a pass may be skipped, each in a kernel of its own, for [below_n, min_n) pairs
+    int64_t count_next_below_n = 393216;            // SA_AMD_COUNT_NEXT_BELOW_N (0 / 0: always inside the pass before)
+    bool no_upfront_counts = false;  // SA_AMD_NO_UPFRONT_COUNTS: short radix sorts count their digits pass by pass, not all of them in front of the first pass
     bool no_flat_rule = false;       // SA_AMD_NO_FLAT_RULE: short texts with a flat byte histogram keep all 64 key bits
     bool no_posted_readback = false; // SA_AMD_NO_POSTED_READBACK: counts come back by copy command + stream synchronise, not by a posted write the host spins on
     bool no_defer = false;           // SA_AMD_NO_DEFER: every refinement round reads the local pass's counts back in its middle (two blocking read-backs per round instead of one)
@@ -153,7 +155,8 @@ struct Tuning {
         t.no_defer = env_flag("SA_AMD_NO_DEFER");
         t.no_posted_readback = env_flag("SA_AMD_NO_POSTED_READBACK");
         t.no_flat_rule = env_flag("SA_AMD_NO_FLAT_RULE");
-        t.count_next_min_n = env_int("SA_AMD_COUNT_NEXT_MIN_N", (int64_t)1 << 23, 0, (int64_t)1 << 40);
+        t.no_upfront_counts = env_flag("SA_AMD_NO_UPFRONT_COUNTS");
+        t.count_next_min_n = env_int("SA_AMD_COUNT_NEXT_MIN_N", 20000000, 0, (int64_t)1 << 40);
         t.count_next_below_n = env_int("SA_AMD_COUNT_NEXT_BELOW_N", 393216, 0, (int64_t)1 << 40);
         t.no_unary_shortcut = env_flag("SA_AMD_NO_UNARY_SHORTCUT");
 

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import suffix_array_amd as sa
 from suffix_array_amd import corpus
-sizes = [1 << 17, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 24]
+sizes = [int(x) for x in os.environ["MIDSIZE_SIZES"].split(",")] if os.environ.get("MIDSIZE_SIZES") else [1 << 17, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 24]
 for gen in ("uniform", "dna", "english_corpus", "english"):
     for n in sizes:
         t = getattr(corpus, gen)(n, 3)

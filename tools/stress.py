@@ -16,7 +16,7 @@ ENV = ["SA_AMD_FORCE_TOP32", "SA_AMD_NO_LOCAL_SORT", "SA_AMD_NO_TEXT_ROUNDS", "S
        "SA_AMD_NO_TOP32", "SA_AMD_FUSED64", "SA_AMD_NO_FUSED_FINISH", "SA_AMD_NO_PACKED_TEXT", "SA_AMD_NO_REPEAT_PROBE",
        "SA_AMD_NO_RUN_SKIP", "SA_AMD_NO_GRAM_KEYS", "SA_AMD_NO_SPLIT", "SA_AMD_NO_ONESWEEP", "SA_AMD_NO_BIG_GROUP_SORT",
        "SA_AMD_NO_FIRST_TAIL", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_NO_TEXT_KEYS",
-       "SA_AMD_NO_DEFER", "SA_AMD_NO_UNARY_SHORTCUT", "SA_AMD_NO_VALUE_BITS", "SA_AMD_NO_POSTED_READBACK", "SA_AMD_NO_FLAT_RULE", "SA_AMD_NO_KERNEL_D2H", "SA_AMD_KERNEL_D2H_ALWAYS"]
+       "SA_AMD_NO_DEFER", "SA_AMD_NO_UNARY_SHORTCUT", "SA_AMD_NO_VALUE_BITS", "SA_AMD_NO_POSTED_READBACK", "SA_AMD_NO_FLAT_RULE", "SA_AMD_NO_KERNEL_D2H", "SA_AMD_KERNEL_D2H_ALWAYS", "SA_AMD_NO_UPFRONT_COUNTS"]
 NUM = {"SA_AMD_SPARSE_DIV": [1, 4, 64, 10**9], "SA_AMD_GROUP_CAP": [2, 3, 7, 40, 300], "SA_AMD_CHASE": [1, 2, 3, 7, 15],
        "SA_AMD_SCATTER_LEVELS": [1, 2], "SA_AMD_DENSE_REKEY_MIN": [1, 1000], "SA_AMD_MAX_TEXT_ROUNDS": [0, 1, 2, 6],
        "SA_AMD_BINNED_MIN": [1, 5000], "SA_AMD_KEY_BITS": [16, 24, 40, 56], "SA_AMD_RUN_SKIP_MIN": [1, 100000],
