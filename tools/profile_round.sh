@@ -63,7 +63,7 @@ echo "adversarial done"
 timeout -k 10 300 python tools/small_latency.py > $O/small_latency.txt 2>&1
 timeout -k 10 300 python tools/midsize_timing.py > $O/midsize_timing.txt 2>&1
 ( for sz in 131072 1048576 4194304; do SA_AMD_VERBOSE=3 timeout -k 10 60 python tools/mid_build.py english_corpus $sz 8 2>&1 | grep -E "best|read-backs" | cut -c1-120 | uniq; done ) >> $O/midsize_timing.txt 2>&1
-timeout -k 10 300 python tools/midsize_knobs.py - SA_AMD_NO_FLAT_RULE=1 SA_AMD_NO_POSTED_READBACK=1 SA_AMD_COUNT_NEXT_MIN_N=0,SA_AMD_COUNT_NEXT_BELOW_N=0 > $O/midsize_knobs.txt 2>&1
+timeout -k 10 300 python tools/midsize_knobs.py - SA_AMD_NO_FLAT_RULE=1 SA_AMD_NO_POSTED_READBACK=1 SA_AMD_NO_UPFRONT_COUNTS=1 SA_AMD_NO_UPFRONT_COUNTS=1,SA_AMD_COUNT_NEXT_MIN_N=0,SA_AMD_COUNT_NEXT_BELOW_N=0 > $O/midsize_knobs.txt 2>&1
 # the copy engine's two rates, the read-back's two forms (plain HIP programs), and the library's download in both states
 mkdir -p tools/bin
 for pgm in readback_probe realloc_dma_probe; do hipcc --offload-arch=gfx950 -O2 -o tools/bin/$pgm tools/$pgm.hip > /dev/null 2>&1; done
