@@ -994,10 +994,12 @@ static int split_giant_groups(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint
 // scratchU / scratchG: two free 4n-byte buffers.
 static int refine_list(uint64_t *rkA, uint64_t *rkB, uint32_t *Vcur, uint32_t *Valt, const uint32_t *Ucur, const uint32_t *Gcur,
                        uint32_t *scratchU, uint32_t *scratchG, int64_t m, int64_t n, const uint8_t *dT, const KeyParams &P,
-                       const KeySrc &K, int g_bits, bool *local_ok, const Workspace &w, hipStream_t st, sa_amd_stats *local,
+                       const KeySrc &K_in, int g_bits, bool *local_ok, const Workspace &w, hipStream_t st, sa_amd_stats *local,
                        Refined *out, const Tuning &tn, bool retry_local = false, int *split_rest = nullptr,   // split_rest: rounds the three-way split sits out after its count pass found no majority
                        RoundCtl *ctl = nullptr)
 {
+    KeySrc K = K_in;
+    K.net_min = tn.network_min;
     const bool resume = ctl && ctl->resume_tot;
     const int64_t tiles = ceil_div(m, RR_TILE);
     const int kb = K.kb;

@@ -79,6 +79,7 @@ struct Tuning {
     int64_t count_next_min_n = 20000000;            // SA_AMD_COUNT_NEXT_MIN_N: radix sorts of fewer pairs do not count the next digit inside a pass -- all digits in front of the
                                                     //   first pass (k_radix_hist_all) or, where a pass may be skipped, each in a kernel of its own, for [below_n, min_n) pairs
     int64_t count_next_below_n = 393216;            // SA_AMD_COUNT_NEXT_BELOW_N (0 / 0: always inside the pass before)
+    int network_min = 256;           // SA_AMD_NETWORK_MIN: k_group_sort orders the groups of a tile that owns one of more members than this by a bitonic network (0: never)
     bool no_upfront_counts = false;  // SA_AMD_NO_UPFRONT_COUNTS: short radix sorts count their digits pass by pass, not all of them in front of the first pass
     bool no_flat_rule = false;       // SA_AMD_NO_FLAT_RULE: short texts with a flat byte histogram keep all 64 key bits
     bool no_posted_readback = false; // SA_AMD_NO_POSTED_READBACK: counts come back by copy command + stream synchronise, not by a posted write the host spins on
@@ -156,6 +157,7 @@ struct Tuning {
         t.no_posted_readback = env_flag("SA_AMD_NO_POSTED_READBACK");
         t.no_flat_rule = env_flag("SA_AMD_NO_FLAT_RULE");
         t.no_upfront_counts = env_flag("SA_AMD_NO_UPFRONT_COUNTS");
+        t.network_min = (int)env_int("SA_AMD_NETWORK_MIN", 256, 0, 1 << 20);
         t.count_next_min_n = env_int("SA_AMD_COUNT_NEXT_MIN_N", 20000000, 0, (int64_t)1 << 40);
         t.count_next_below_n = env_int("SA_AMD_COUNT_NEXT_BELOW_N", 393216, 0, (int64_t)1 << 40);
         t.no_unary_shortcut = env_flag("SA_AMD_NO_UNARY_SHORTCUT");

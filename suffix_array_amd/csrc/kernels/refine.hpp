@@ -42,6 +42,7 @@ struct KeySrc {
     int64_t depth;                  // symbols the initial sort and the text-keyed rounds have ordered
     int top_shift;
     int iters;                      // KS_RANK: rank look-ups per round (1 = plain doubling), see k_group_sort
+    int net_min;                    // k_group_sort: a tile that owns a group of more members than this orders its groups by a bitonic network (0: never)
 };
 
 // Sparse rank lookup (few tied suffixes): no ISA is built.  rank(q) of suffix q under the current order:
@@ -162,7 +163,6 @@ constexpr int GS_ITEMS = 8;
 constexpr int GS_TILE = GS_THREADS * GS_ITEMS;
 constexpr int GS_WORDS = GS_TILE / 64;
 constexpr int GS_CAP = 1024;        // upper bound of the run-time group-size cap
-constexpr int GS_NETWORK_MIN = 64;  // a tile that owns a group of more members than this orders its groups by a bitonic network, not by counting
 constexpr int GB_LIST_MIN = 256;    // k_group_sort_big: a group that runs on beyond its tile is listed when it has this many members inside it
 
 template <int MODE>
@@ -275,13 +275,13 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
     // comes out ordered in its own places, everything else stays where it is.  (Keys of up to 42 bits: 11 + 42 + 11.)
     bool by_network = false;
     uint16_t *s_place = (uint16_t *)s_val;                       // (s_val is written only behind the barrier that follows the ranks)
-    if (!CHASE && K.kb <= 42) {
+    if (!CHASE && K.kb <= 42 && K.net_min > 0) {
         bool large = false;
 #pragma unroll
         for (int r = 0; r < GS_ITEMS; ++r) {
             const int jl = r * GS_THREADS + t;
             const int start = jl - (int)(u[r] - g[r]), end = group_end(jl);
-            large |= base + jl < m && start >= 0 && end >= 0 && end - start <= cap && end - start > GS_NETWORK_MIN;
+            large |= base + jl < m && start >= 0 && end >= 0 && end - start <= cap && end - start > K.net_min;
         }
         by_network = __syncthreads_or(large) != 0;
         if (by_network) {
@@ -293,6 +293,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
                 s_key[jl] = ((uint64_t)(owned ? start : jl) << 53) | (owned ? key[r] << 11 : 0ull) | (uint64_t)jl;
             }
             __syncthreads();
+            // (exchange x of a step pairs elements inside the 128-element block x / 64 as long as the distance is at most 64, and a
+            // wave's 64 exchanges are one such block: 56 of the 66 steps need no workgroup barrier, only the wave's own LDS traffic
+            // to have landed)
             for (int k = 2; k <= GS_TILE; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
@@ -301,7 +304,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_group_sort(const uint32_t *Vin, 
                         const uint64_t a = s_key[lo], c = s_key[hi];
                         if ((a > c) == ((lo & k) == 0)) { s_key[lo] = c; s_key[hi] = a; }
                     }
-                    __syncthreads();
+                    const int next_j = j > 1 ? (j >> 1) : k;                 // (the next step's distance; behind the last step: a barrier)
+                    if (j > 64 || next_j > 64 || (j == 1 && k == GS_TILE)) __syncthreads();
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
             }
 #pragma unroll
@@ -530,7 +535,10 @@ __global__ __launch_bounds__(GX_THREADS) void k_group_sort_straddle(uint64_t *__
                     const uint64_t a = s_key[lo], c = s_key[hi];
                     if ((a > c) == ((lo & k) == 0)) { s_key[lo] = c; s_key[hi] = a; }
                 }
-                __syncthreads();
+                // (distances of at most 64 stay inside a wave's own 128-element blocks: see k_group_sort)
+                const int next_j = j > 1 ? (j >> 1) : k;
+                if (j > 64 || next_j > 64 || (j == 1 && k == P)) __syncthreads();
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
         __shared__ uint64_t s_ghead;                                // the bits above the secondary key: the group's head, the same for every member

@@ -1089,7 +1089,7 @@ ALL_KNOBS = ["SA_AMD_SORT_VARIANT", "SA_AMD_SORT32_VARIANT", "SA_AMD_KEY_BITS", 
              "SA_AMD_MAX_TEXT_ROUNDS", "SA_AMD_BINNED_MIN", "SA_AMD_CHASE", "SA_AMD_NO_REPEAT_PROBE", "SA_AMD_NO_FIRST_TAIL", "SA_AMD_DENSE_REKEY_MIN", "SA_AMD_SCATTER_LEVELS",
              "SA_AMD_CACHE_MAX_BYTES", "SA_AMD_COPY_THREADS", "SA_AMD_STAGED_MIN_BYTES", "SA_AMD_BATCH_THREADS",
              "SA_AMD_NO_GRAM_KEYS", "SA_AMD_GRAM_MIN_N", "SA_AMD_GRAM_G", "SA_AMD_GRAM_TAIL", "SA_AMD_CHASE_BIG", "SA_AMD_CHASE_BIG_MIN", "SA_AMD_NO_SPLIT", "SA_AMD_SPLIT_MIN", "SA_AMD_SPLIT_GROUP_MIN",
-             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_VALUE_BITS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PREFAULT_KEEP", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_NO_UPFRONT_COUNTS", "SA_AMD_NO_KERNEL_D2H", "SA_AMD_KERNEL_D2H_ALWAYS", "SA_AMD_NO_FLAT_RULE", "SA_AMD_NO_POSTED_READBACK", "SA_AMD_COUNT_NEXT_MIN_N", "SA_AMD_COUNT_NEXT_BELOW_N", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS", "SA_AMD_SAMPLE_SORT", "SA_AMD_SAMPLE_SORT_MIN_N", "SA_AMD_SAMPLE_LOG", "SA_AMD_SAMPLE_MERGE", "SA_AMD_CACHE_IDLE_MS", "SA_AMD_NO_REDUCED", "SA_AMD_NO_UNARY_SHORTCUT",
+             "SA_AMD_SMALL_MAX", "SA_AMD_TOP32_PROBE_MIN_N", "SA_AMD_TOP32_PARTNERS_X100", "SA_AMD_TOP32_COLLISIONS_X100", "SA_AMD_NO_ONESWEEP", "SA_AMD_ONESWEEP64_SHAPE", "SA_AMD_ONESWEEP32_SHAPE", "SA_AMD_ONESWEEP_FLAGS", "SA_AMD_NO_BIG_GROUP_SORT", "SA_AMD_NO_TEXT_KEYS", "SA_AMD_NO_VALUE_BITS", "SA_AMD_NO_BUCKET_SORT", "SA_AMD_NO_BUCKET_FINISH", "SA_AMD_BUCKET_FINISH_ALWAYS", "SA_AMD_BUCKET_BITS", "SA_AMD_BUCKET_MIN_N", "SA_AMD_BUCKET_SHAPE", "SA_AMD_NUMA", "SA_AMD_HELPER_THREADS", "SA_AMD_NO_LANES", "SA_AMD_LANES_MIN_N", "SA_AMD_NO_PREFAULT", "SA_AMD_PREFAULT_WAIT", "SA_AMD_PREFAULT_KEEP", "SA_AMD_PINNED_MAX_BYTES", "SA_AMD_NO_DEFER", "SA_AMD_NETWORK_MIN", "SA_AMD_NO_UPFRONT_COUNTS", "SA_AMD_NO_KERNEL_D2H", "SA_AMD_KERNEL_D2H_ALWAYS", "SA_AMD_NO_FLAT_RULE", "SA_AMD_NO_POSTED_READBACK", "SA_AMD_COUNT_NEXT_MIN_N", "SA_AMD_COUNT_NEXT_BELOW_N", "SA_AMD_EARLY_DIV", "SA_AMD_EARLY_MIN_BYTES", "SA_AMD_EARLY_CHUNK_BYTES", "SA_AMD_EARLY_WAIT_CHUNKS", "SA_AMD_SAMPLE_SORT", "SA_AMD_SAMPLE_SORT_MIN_N", "SA_AMD_SAMPLE_LOG", "SA_AMD_SAMPLE_MERGE", "SA_AMD_CACHE_IDLE_MS", "SA_AMD_NO_REDUCED", "SA_AMD_NO_UNARY_SHORTCUT",
              "SA_AMD_DEBUG_SYNC", "SA_AMD_VERBOSE"]
 
 

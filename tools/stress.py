@@ -28,7 +28,7 @@ NUM = {"SA_AMD_SPARSE_DIV": [1, 4, 64, 10**9], "SA_AMD_GROUP_CAP": [2, 3, 7, 40,
        # the early download at small sizes: staged download for every array, 64 KiB pulls, start at n / d tied suffixes, the build waits for w chunks
        "SA_AMD_STAGED_MIN_BYTES": [0, 0, 1 << 20], "SA_AMD_EARLY_MIN_BYTES": [0, 0, 1 << 40], "SA_AMD_EARLY_CHUNK_BYTES": [65536, 65536, 262144],
        "SA_AMD_EARLY_DIV": [0, 1, 1, 2, 8], "SA_AMD_EARLY_WAIT_CHUNKS": [0, 1, 3, 8], "SA_AMD_COPY_THREADS": [0, 1, 4, 12], "SA_AMD_HELPER_THREADS": [0, 2, 16],
-       "SA_AMD_PREFAULT_KEEP": [0, 1, 3, 12], "SA_AMD_COUNT_NEXT_MIN_N": [0, 1 << 40], "SA_AMD_COUNT_NEXT_BELOW_N": [0, 1 << 40, 5000]}
+       "SA_AMD_PREFAULT_KEEP": [0, 1, 3, 12], "SA_AMD_NETWORK_MIN": [0, 1, 8, 300, 2000], "SA_AMD_COUNT_NEXT_MIN_N": [0, 1 << 40], "SA_AMD_COUNT_NEXT_BELOW_N": [0, 1 << 40, 5000]}
 t0 = time.time(); cases = 0; fails = 0
 while time.time() - t0 < budget:
     n = int(rng.choice([rng.integers(0, 300), rng.integers(300, 20000), rng.integers(20000, BIG)]))
